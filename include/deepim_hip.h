@@ -1,0 +1,128 @@
+/* libdeepim_hip.so -- C ABI of the MI355X-native DeepIM refinement hot path.
+ *
+ * Drop-in boundary: these are the entry points a maintainer of wangg12/mx-DeepIM would bind
+ * (ctypes) in place of
+ *   - the numpy/MXNet bodies of the Python custom ops in deepim/operator_py/*.py,
+ *   - the one native function the reference has today,
+ *       void _flow(float* flow, float* valid, float* depth_src, float* depth_tgt, float* KT,
+ *                  float* Kinv, int batch_size, int height, int width, int device_id)
+ *       (lib/flow_c/gpu_flow.hpp:1-3, Cython binding lib/flow_c/gpu_flow.pyx:24-41),
+ *   - the glumpy renderer object lib/render_glumpy/render_py_multi.py:49-147,
+ *   - MXNet's Convolution / FullyConnected operators used by deepim/symbols/deepIM_flownet.py.
+ *
+ * Conventions
+ *   - every function returns DIM_OK (0) or a negative DIM_ERR_* code; dim_last_error() returns a
+ *     thread-local description of the last failure on the calling thread.
+ *   - pointers are DEVICE pointers (caller-owned, fp32, C-contiguous) unless the parameter name
+ *     ends in a digit count (`K9`, `means3`, `T_means3`, ...): those are small HOST arrays.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work;
+ *     nothing here allocates, frees or synchronises, so every call is hipGraph-capturable.
+ *   - image-like tensors are NCHW as in the reference's blobs; the conv stack's activations are
+ *     NHWC (this library's internal layout, produced by dim_zoom_net_input).
+ */
+#ifndef DEEPIM_HIP_H_
+#define DEEPIM_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIM_OK 0
+#define DIM_ERR_ARG (-1)
+#define DIM_ERR_LAUNCH (-2)
+
+const char* dim_last_error(void);
+/* library / device probe: fills name (<= n bytes), returns number of compute units or <0 */
+int dim_device_info(char* name, int n);
+
+/* ---------------------------------------------------------------- zoom ops
+ * bbox of {x > thr} (mode 0, C==1) or {sum_c (x_c + means3[c]) > thr} (mode 1, C==3):
+ *   bbox[b] = {min_x, max_x, min_y, max_y}, empty = {W,-1,H,-1}.
+ * replaces zoom_mask.py:36-70 / zoom_image.py:34-70 (np.max / np.nonzero on host copies). */
+int dim_mask_bbox(const float* x, int B, int C, int H, int W, int mode, float thr, const float* means3, int* bbox, void* stream);
+
+/* zoom window rule -> zoom_factor (B,4) = [wx, wy, tx, ty]   (zoom_mask.py:71-117).
+ * status (B) may be NULL; bit0 = observed box empty (reference raises), bit1 = rendered box empty
+ * (reference prints "NO POINT VALID IN MASK rendered" and uses the observed box). */
+int dim_zoom_factor(const int* bbox_observed, const int* bbox_rendered, const float* src_pose, const float* K9, int B, int H, int W,
+                    float* zoom_factor, int* status, void* stream);
+
+/* affine bilinear gather of C planes with a zoom factor (GridGenerator + BilinearSampler fused).
+ *   inverse   1 = inverse zoom (zoom_flow.py:35-44)
+ *   pre       0 none | 1 binarise input at 0.2          (zoom_mask.py:39-46)
+ *   post      0 none | 1 mx.nd.round | 2 round(x-0.45)   (zoom_mask.py:121-129, zoom_flow.py:74-76)
+ *   add3      HOST per-plane constant added before / removed after sampling (pixel means), or NULL
+ *   scale_mode 0 none | 1 divide by wx | 2 multiply by wx (zoom_flow.py:59-66) */
+int dim_zoom_planes(const float* x, const float* zoom_factor, float* y, int B, int C, int H, int W, int inverse, int pre, int post,
+                    const float* add3, int scale_mode, void* stream);
+
+/* ZoomMask + ZoomImageWithFactor + Concat(/255) fused: X (B,H,W,8) NHWC network input
+ * (deepIM_flownet.py:53-60).  The four z_* NCHW outputs are optional (all or none). */
+int dim_zoom_net_input(const float* image_observed, const float* image_rendered, const float* mask_observed,
+                       const float* mask_rendered, const float* zoom_factor, float* X_nhwc8, int B, int H, int W,
+                       const float* means3, float* z_image_observed, float* z_image_rendered, float* z_mask_observed,
+                       float* z_mask_rendered, void* stream);
+
+/* ZoomTrans (zoom_trans.py:22-76): mode 0 copy, 1 (dx,dy)/wx, 2 (dx,dy)*wx */
+int dim_zoom_trans(const float* zoom_factor, const float* in, float* out, int B, int mode, void* stream);
+
+/* ---------------------------------------------------------------- SE(3)
+ * rot_coord: 0 MODEL, 1 CAMERA, 2 CAMERA_NEW, 3 NAIVE.
+ * pose_out = RT_transform(pose_src, se3[:, :4], se3[:, 4:])  (RT_transform.py:135-161); float64 inside. */
+int dim_se3_compose(const float* pose_src, const float* se3, float* pose_out, double* pose_out_f64, int B, int rot_coord,
+                    const float* T_means3, const float* T_stds3, void* stream);
+/* (rot_quat, trans) = calc_RT_delta(pose_src, pose_tgt, rot_type="QUAT")  (RT_transform.py:16-48) */
+int dim_se3_delta(const float* pose_src, const float* pose_tgt, float* rot_quat, float* trans, int B, int rot_coord,
+                  const float* T_means3, const float* T_stds3, void* stream);
+/* Transform3D custom op (transform3d.py:42-327); points/out/out_grad are (B,3,Npts). */
+int dim_transform3d_fwd(const float* points, const float* rot, const float* trans, const float* pose_src, float* out, int B,
+                        int Npts, int rot_coord, const float* T_means3, const float* T_stds3, void* stream);
+int dim_transform3d_bwd(const float* out_grad, const float* points, const float* rot, const float* trans, const float* pose_src,
+                        float* d_rot, float* d_trans, int B, int Npts, int rot_coord, const float* T_means3, const float* T_stds3,
+                        void* stream);
+
+/* ---------------------------------------------------------------- depth -> flow labels
+ * device-pointer version of _flow (lib/flow_c/gpu_flow.hpp:1-3): flow (B,2,H,W) in (dy,dx), valid (B,1,H,W). */
+int dim_depth_to_flow(const float* depth_src, const float* depth_tgt, const float* KT, const float* Kinv9, int B, int H, int W,
+                      float* flow, float* valid, void* stream);
+
+/* ---------------------------------------------------------------- rasteriser
+ * Mesh table in HBM: verts (sumV,3), uvs (sumV,2), faces (sumF,3 int32, indices local to the mesh),
+ * mesh_table (C,4 int32) = {vert_off, nvert, face_off, nface}; textures = concatenated uint8 RGB images
+ * (row 0 = top of texture_map.png), tex_table (C,3 int32) = {byte_off, Ht, Wt}.
+ * class_index (B int32), poses (B,3,4).  workspace: dim_raster_workspace_bytes().
+ * Outputs (each may be NULL): image (B,3,H,W) = RGB - plane_means3 (the next iteration's image_rendered
+ * blob), depth (B,1,H,W) metres, mask (B,1,H,W) = depth > mask_thr, bgr (B,H,W,3) as Render_Py.render
+ * returns it, bbox (B,4) of the mask.   Replaces render_py_multi.py:112-147 + tester.py:563-578. */
+long dim_raster_workspace_bytes(int B, int vmax, int H, int W);
+int dim_raster_render(const float* verts, const float* uvs, const int* faces, const int* mesh_table, int vmax, int fmax,
+                      const unsigned char* textures, const int* tex_table, const int* class_index, const float* poses,
+                      const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear, const float* plane_means3,
+                      float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox,
+                      void* stream);
+/* mask[b] = rectangle [y0:y1, x0:x1] (end-exclusive) of bbox[b]  (data_pair.py:103-114, UPDATE_MASK box_rendered) */
+int dim_box_mask(const int* bbox, float* mask, int B, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- convolution stack (NHWC, f32 MFMA)
+ * weights: pack once from the reference layout (Cout,Cin,KH,KW).  Cin must be 8 or a multiple of 32,
+ * Cout a multiple of 64.  y = LeakyReLU_slope(conv(x) + bias); slope 1.0 = linear.
+ * splits > 1 = split-K through `workspace` (dim_conv2d_workspace_floats), deterministic reduce.
+ * tile: 0 auto | 1 128x128 | 2 128x64 | 3 64x64 (pixels x channels per workgroup). */
+long dim_conv2d_packed_weight_floats(int Cout, int Cin, int KH, int KW);
+int dim_conv2d_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
+long dim_conv2d_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int splits);
+int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
+                   int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile, void* stream);
+/* FullyConnected weight (Out, C*H*W) [mx Flatten order c,h,w] -> [(h,w,c)][Out] so fc6 is dim_conv2d_fwd
+ * with KH=H, KW=W on the NHWC feature map. */
+int dim_fc_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream);
+/* fc7 + LeakyReLU(0.1) + rot(4) + trans(3) + inverse ZoomTrans -> se3 (B,7)  (deepIM_flownet.py:203-208,:956-971).
+ * weights in the reference (out,in) layout; fc7_out (B,256) optional. */
+int dim_pose_head_fwd(const float* fc6, const float* fc7_w, const float* fc7_b, const float* rot_w, const float* rot_b,
+                      const float* trans_w, const float* trans_b, const float* zoom_factor, float* se3, float* fc7_out, int B,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPIM_HIP_H_ */

@@ -1,0 +1,435 @@
+// im2col-free direct convolution on the CDNA4 f32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the cuDNN Convolution / FullyConnected calls of the reference's FlowNetS encoder
+// (/root/reference/deepim/symbols/deepIM_flownet.py:67-208).  Activations are NHWC fp32 in HBM,
+// weights are pre-packed once into [K = (kh,kw,cin)][Cout]; the kernel is an implicit GEMM
+//     Y[m = (n,ho,wo)][co] = sum_k X[n, ho*s-p+kh, wo*s-p+kw, c] * Wp[k][co]
+// with a 32-deep K chunk that is one tap x 32 channels (Cin % 32 == 0) or, for the 8-channel
+// first layer, four horizontally adjacent taps x 8 channels (= 32 contiguous floats in HBM).
+//
+// Block = 256 threads = 4 waves; wave tile = (BM/WM) x (BN/WN) in 32x32 MFMA tiles.
+// LDS: A chunk stored K-major [32][BM+1] (transposed while staging, conflict-free both ways),
+//      B chunk [32][BN+4]; two buffers, register prefetch of chunk k+1 under the MFMAs of chunk k.
+// Epilogue: bias + LeakyReLU fused; with gridDim.z > 1 (split-K) raw partials go to a slab
+// and dim_splitk_reduce finishes (deterministic, no atomics).
+#include "common.h"
+
+namespace dim {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;        // final output (splits == 1) or slab base (splits > 1)
+  int N, H, W, Cin;
+  int Ho, Wo, Cout;
+  int KH, KW, stride, pad;
+  int M;           // N*Ho*Wo
+  int nchunks;     // total K chunks of 32
+  int chunks_per_split;
+  float slope;     // LeakyReLU slope (1 = linear)
+  int has_bias;
+};
+
+template <int BM, int BN, int WM, int WN, bool CIN8>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+  constexpr int BK = 32;
+  constexpr int LDA = BM + 1;
+  constexpr int LDB = BN + 4;
+  constexpr int TM = BM / WM / 32;  // MFMA tiles per wave along M
+  constexpr int TN = BN / WN / 32;
+  constexpr int A_PER_T = BM / 32;  // float4 loads per thread for the A chunk
+  constexpr int B_PER_T = BN / 32;
+  constexpr int B_ROWS_PER_PASS = 256 / (BN / 4);
+  static_assert(WM * WN == 4, "4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                       // [2][BK][LDA]
+  float* sB = smem + 2 * BK * LDA;        // [2][BK][LDB]  (2*BK*LDA*4 bytes is a multiple of 16)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int split = blockIdx.z;
+  const int kc_begin = split * a.chunks_per_split;
+  const int kc_end = min(a.nchunks, kc_begin + a.chunks_per_split);
+
+  // ---- per-thread A-load descriptors (fixed pixels for the whole K loop)
+  const int q = tid & 7;                  // float4 index inside the 32-float chunk
+  int a_hi0[A_PER_T], a_wi0[A_PER_T];
+  long a_base[A_PER_T];
+  bool a_ok[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    int m = m0 + (tid >> 3) + 32 * i;
+    a_ok[i] = m < a.M;
+    int mm = a_ok[i] ? m : 0;
+    int wo = mm % a.Wo;
+    int t = mm / a.Wo;
+    int ho = t % a.Ho;
+    int n = t / a.Ho;
+    a_hi0[i] = ho * a.stride - a.pad;
+    a_wi0[i] = wo * a.stride - a.pad;
+    a_base[i] = (long)n * a.H * a.W * a.Cin;
+  }
+  // ---- B-load mapping
+  const int b_n4 = tid % (BN / 4);
+  const int b_k = tid / (BN / 4);
+
+  // chunk -> (kh, kw, c0) counters
+  int kh, kw, c0;
+  if (CIN8) {
+    kh = kc_begin >> 1;
+    kw = (kc_begin & 1) * 4;
+    c0 = 0;
+  } else {
+    int cpt = a.Cin >> 5;
+    int tap = kc_begin / cpt;
+    c0 = (kc_begin - tap * cpt) << 5;
+    kh = tap / a.KW;
+    kw = tap - kh * a.KW;
+  }
+
+  float4 ra[A_PER_T], rb[B_PER_T];
+
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      int hi = a_hi0[i] + kh;
+      int wi, coff;
+      if (CIN8) {
+        int tap = kw + (q >> 1);
+        wi = a_wi0[i] + tap;
+        coff = (q & 1) * 4;
+        bool ok = a_ok[i] && tap < a.KW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        ra[i] = ok ? *reinterpret_cast<const float4*>(a.x + a_base[i] + ((long)hi * a.W + wi) * 8 + coff)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        wi = a_wi0[i] + kw;
+        bool ok = a_ok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        ra[i] = ok ? *reinterpret_cast<const float4*>(a.x + a_base[i] + ((long)hi * a.W + wi) * a.Cin + c0 + q * 4)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const float* wsrc = a.w + ((long)kc * BK) * a.Cout + n0 + b_n4 * 4;
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      int k = b_k + B_ROWS_PER_PASS * i;
+      rb[i] = *reinterpret_cast<const float4*>(wsrc + (long)k * a.Cout);
+    }
+  };
+  auto advance = [&]() {
+    if (CIN8) {
+      kw += 4;
+      if (kw >= 8) { kw = 0; ++kh; }
+    } else {
+      c0 += 32;
+      if (c0 == a.Cin) {
+        c0 = 0;
+        if (++kw == a.KW) { kw = 0; ++kh; }
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* dA = sA + buf * BK * LDA;
+    float* dB = sB + buf * BK * LDB;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      int r = (tid >> 3) + 32 * i;
+      dA[(q * 4 + 0) * LDA + r] = ra[i].x;
+      dA[(q * 4 + 1) * LDA + r] = ra[i].y;
+      dA[(q * 4 + 2) * LDA + r] = ra[i].z;
+      dA[(q * 4 + 3) * LDA + r] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      int k = b_k + B_ROWS_PER_PASS * i;
+      *reinterpret_cast<float4*>(dB + k * LDB + b_n4 * 4) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kc_begin < kc_end) {
+    load_chunk(kc_begin);
+    advance();
+    store_chunk(0);
+  }
+  __syncthreads();
+
+  const int a_row = wm * (BM / WM) + (lane & 31);
+  const int b_col = wn * (BN / WN) + (lane & 31);
+  const int khalf = lane >> 5;
+
+  int buf = 0;
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
+    const bool more = (kc + 1) < kc_end;
+    if (more) {
+      load_chunk(kc + 1);
+      advance();
+    }
+    const float* cA = sA + buf * BK * LDA;
+    const float* cB = sB + buf * BK * LDB;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const int k = ks * 2 + khalf;
+      float fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = cA[k * LDA + a_row + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = cB[k * LDB + b_col + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue.  D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool final = gridDim.z == 1;
+  float* out = final ? a.y : a.y + (long)split * a.M * a.Cout;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + b_col + 32 * j;
+    const float bv = (final && a.has_bias) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (m < a.M) {
+          float v = acc[i][j][r] + bv;
+          if (final) v = v > 0.f ? v : v * a.slope;
+          out[(long)m * a.Cout + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// sum split-K slabs + bias + LeakyReLU.  One float4 per thread.
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ y,
+                                     long MC, int Cout, int splits, float slope, int has_bias) {
+  long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long i = i4 * 4;
+  if (i >= MC) return;
+  float4 s = *reinterpret_cast<const float4*>(slabs + i);
+  for (int k = 1; k < splits; ++k) {
+    float4 p = *reinterpret_cast<const float4*>(slabs + (long)k * MC + i);
+    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+  }
+  if (has_bias) {
+    int c = (int)(i % Cout);
+    s.x += bias[c]; s.y += bias[c + 1]; s.z += bias[c + 2]; s.w += bias[c + 3];
+  }
+  s.x = s.x > 0.f ? s.x : s.x * slope;
+  s.y = s.y > 0.f ? s.y : s.y * slope;
+  s.z = s.z > 0.f ? s.z : s.z * slope;
+  s.w = s.w > 0.f ? s.w : s.w * slope;
+  *reinterpret_cast<float4*>(y + i) = s;
+}
+
+// OIHW (MXNet / reference layout) -> packed [chunk][32][Cout]
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KH, int KW,
+                                        int nchunks, int cin8) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)nchunks * 32 * Cout;
+  if (idx >= total) return;
+  int co = (int)(idx % Cout);
+  long kk = idx / Cout;
+  int kc = (int)(kk / 32), kin = (int)(kk % 32);
+  int kh, kw, c;
+  if (cin8) {
+    kh = kc >> 1;
+    kw = (kc & 1) * 4 + (kin >> 3);
+    c = kin & 7;
+  } else {
+    int cpt = Cin >> 5;
+    int tap = kc / cpt;
+    c = (kc - tap * cpt) * 32 + kin;
+    kh = tap / KW;
+    kw = tap - kh * KW;
+  }
+  float v = 0.f;
+  if (kh < KH && kw < KW && c < Cin) v = w[(((long)co * Cin + c) * KH + kh) * KW + kw];
+  wp[idx] = v;
+}
+
+// FullyConnected weight (out, in) with `in` flattened (c,h,w) [mx Flatten of NCHW] -> packed
+// [k = (h,w,c)][out] so that fc6 runs through conv_fwd_kernel on the NHWC conv6_1 output.
+__global__ void pack_fc_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Out, int C, int H, int W) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)Out * C * H * W;
+  if (idx >= total) return;
+  int o = (int)(idx % Out);
+  long k = idx / Out;
+  int c = (int)(k % C);
+  long hw = k / C;
+  wp[idx] = w[(long)o * C * H * W + (long)c * H * W + hw];
+}
+
+// Pose head: fc7 + LeakyReLU + rot (4) + trans (3) + inverse ZoomTrans -> se3 (B,7).
+// deepIM_flownet.py:203-208, :956-971; zoom_trans.py:37-41 (b_inv_zoom: dx*wx, dy*wx).
+__global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict__ fc6, const float* __restrict__ w7,
+                                                         const float* __restrict__ b7, const float* __restrict__ wr,
+                                                         const float* __restrict__ br, const float* __restrict__ wt,
+                                                         const float* __restrict__ bt, const float* __restrict__ zoom_factor,
+                                                         float* __restrict__ se3, float* __restrict__ fc7_out) {
+  __shared__ float s_in[256];
+  __shared__ float s_h[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  s_in[t] = fc6[(long)b * 256 + t];
+  __syncthreads();
+  float acc = b7[t];
+  const float* wrow = w7 + (long)t * 256;
+  for (int k = 0; k < 256; ++k) acc = fmaf(s_in[k], wrow[k], acc);
+  acc = acc > 0.f ? acc : 0.1f * acc;
+  s_h[t] = acc;
+  if (fc7_out) fc7_out[(long)b * 256 + t] = acc;
+  __syncthreads();
+  // 7 outputs, one wave each would be overkill: 7 x 64-lane partial dot + shuffle reduce
+  const int wave = t >> 6, lane = t & 63;
+  for (int o = wave; o < 7; o += 4) {
+    const float* wv = (o < 4) ? (wr + o * 256) : (wt + (o - 4) * 256);
+    float p = 0.f;
+    for (int k = lane; k < 256; k += 64) p = fmaf(s_h[k], wv[k], p);
+    for (int off = 32; off > 0; off >>= 1) p += __shfl_down(p, off, 64);
+    if (lane == 0) {
+      float v = p + ((o < 4) ? br[o] : bt[o - 4]);
+      if (o == 4 || o == 5) v = v * zoom_factor[b * 4 + 0];
+      se3[b * 7 + o] = v;
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool CIN8>
+static int launch_conv(const ConvArgs& a, int splits, hipStream_t st) {
+  constexpr size_t lds = (2 * 32 * (BM + 1) + 2 * 32 * (BN + 4)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<BM, BN, WM, WN, CIN8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(a.M, BM), a.Cout / BN, splits);
+  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, CIN8>), grid, dim3(256), lds, st, a);
+  return check_launch("conv_fwd");
+}
+
+}  // namespace dim
+
+using namespace dim;
+
+extern "C" {
+
+long dim_conv2d_packed_weight_floats(int Cout, int Cin, int KH, int KW) {
+  if (Cin == 8) return (long)KH * 2 * 32 * Cout;  // 8 taps (KW<=8) x 8 ch per row = 2 chunks
+  return (long)KH * KW * Cin * Cout;
+}
+
+int dim_conv2d_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream) {
+  DIM_REQUIRE(w_oihw && w_packed, "null weight pointer");
+  DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
+  DIM_REQUIRE(Cin != 8 || KW <= 8, "Cin==8 path needs KW<=8 (got %d)", KW);
+  int cin8 = Cin == 8;
+  int nchunks = cin8 ? KH * 2 : KH * KW * (Cin / 32);
+  long total = (long)nchunks * 32 * Cout;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed,
+                     Cout, Cin, KH, KW, nchunks, cin8);
+  return check_launch("pack_conv_weight");
+}
+
+int dim_fc_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream) {
+  DIM_REQUIRE(w_out_in && w_packed, "null weight pointer");
+  long total = (long)Out * C * H * W;
+  hipLaunchKernelGGL(pack_fc_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_out_in, w_packed, Out,
+                     C, H, W);
+  return check_launch("pack_fc_weight");
+}
+
+long dim_conv2d_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int splits) {
+  if (splits <= 1) return 0;
+  int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  return (long)splits * N * Ho * Wo * Cout;
+}
+
+// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64
+int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
+                   int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile, void* stream) {
+  DIM_REQUIRE(x && w_packed && y, "null pointer");
+  DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
+  DIM_REQUIRE(Cout % 64 == 0, "Cout must be a multiple of 64 (got %d)", Cout);
+  DIM_REQUIRE(stride >= 1 && pad >= 0 && KH >= 1 && KW >= 1, "bad geometry");
+  DIM_REQUIRE(Cin != 8 || KW <= 8, "Cin==8 path needs KW<=8");
+  ConvArgs a;
+  a.x = x; a.w = w_packed; a.bias = bias;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.Ho = (H + 2 * pad - KH) / stride + 1;
+  a.Wo = (W + 2 * pad - KW) / stride + 1;
+  DIM_REQUIRE(a.Ho > 0 && a.Wo > 0, "empty output");
+  a.M = N * a.Ho * a.Wo;
+  a.nchunks = (Cin == 8) ? KH * 2 : KH * KW * (Cin / 32);
+  if (splits < 1) splits = 1;
+  if (splits > a.nchunks) splits = a.nchunks;
+  a.chunks_per_split = (a.nchunks + splits - 1) / splits;
+  splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+  DIM_REQUIRE(splits == 1 || workspace, "split-K needs a workspace (dim_conv2d_workspace_floats)");
+  a.y = splits > 1 ? workspace : y;
+  a.slope = slope;
+  a.has_bias = bias != nullptr;
+  hipStream_t st = as_stream(stream);
+  if (tile == 0) {
+    long blocks128 = (long)ceil_div(a.M, 128) * (Cout / 128 > 0 ? Cout / 128 : 1);
+    if (Cout % 128 == 0 && blocks128 * splits >= 512) tile = 1;
+    else if (Cout == 64 && a.M >= 128 * 512) tile = 2;
+    else tile = 3;
+  }
+  int rc;
+  if (Cin == 8) {
+    DIM_REQUIRE(tile != 1 || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
+    if (tile == 1) rc = launch_conv<128, 128, 2, 2, true>(a, splits, st);
+    else if (tile == 2) rc = launch_conv<128, 64, 2, 2, true>(a, splits, st);
+    else rc = launch_conv<64, 64, 2, 2, true>(a, splits, st);
+  } else {
+    DIM_REQUIRE(tile != 1 || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
+    if (tile == 1) rc = launch_conv<128, 128, 2, 2, false>(a, splits, st);
+    else if (tile == 2) rc = launch_conv<128, 64, 2, 2, false>(a, splits, st);
+    else rc = launch_conv<64, 64, 2, 2, false>(a, splits, st);
+  }
+  if (rc != DIM_OK) return rc;
+  if (splits > 1) {
+    long MC = (long)a.M * Cout;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MC / 4, 256)), dim3(256), 0, st, workspace, bias, y, MC, Cout, splits,
+                       slope, a.has_bias);
+    return check_launch("splitk_reduce");
+  }
+  return DIM_OK;
+}
+
+int dim_pose_head_fwd(const float* fc6, const float* fc7_w, const float* fc7_b, const float* rot_w, const float* rot_b,
+                      const float* trans_w, const float* trans_b, const float* zoom_factor, float* se3, float* fc7_out, int B,
+                      void* stream) {
+  DIM_REQUIRE(fc6 && fc7_w && fc7_b && rot_w && rot_b && trans_w && trans_b && zoom_factor && se3, "null pointer");
+  DIM_REQUIRE(B > 0, "empty batch");
+  hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(256), 0, as_stream(stream), fc6, fc7_w, fc7_b, rot_w, rot_b, trans_w,
+                     trans_b, zoom_factor, se3, fc7_out);
+  return check_launch("pose_head");
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// depth -> optical-flow label kernel on device-resident tensors.
+// Replaces /root/reference/lib/flow_c/gpu_flow_kernel.cu:32-69 (flow_kernel) and its host wrapper
+// _flow (:82-148) which cudaMalloc/H2D/D2H/cudaFree on every call.  Same per-pixel arithmetic
+// (float32, same operation order), output flow in (dy, dx) order, valid in {0,1}.
+// HBM-bound: 2 planes read + 3 planes written per sample = 6.144 MB at 480x640.
+#include "common.h"
+
+namespace dim {
+
+__global__ __launch_bounds__(256) void depth_flow_kernel(const float* __restrict__ depth_src, const float* __restrict__ depth_tgt,
+                                                         const float* __restrict__ KT, float i0, float i1, float i2, float i3,
+                                                         float i4, float i5, int H, int W, float* __restrict__ flow,
+                                                         float* __restrict__ valid) {
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  const long plane = (long)H * W;
+  const long index = (long)b * plane + (long)h * W + w;
+  const float* kt = KT + 12 * b;
+  const float d = depth_src[index];
+  // no FMA contraction: the CUDA reference compiles these as written only if nvcc does not fuse;
+  // fusing changes results by <= 1 ulp, the oracle comparison tolerates that on `flow` and the
+  // tests exclude pixels within 1e-6 of the 3e-3 / bounds predicates.
+  float x = (w * i0 + h * i1 + i2) * d;
+  float y = (w * i3 + h * i4 + i5) * d;
+  float z = d;
+  float fh = 0.f, fw = 0.f, va = 0.f;
+  if (d > 1E-3) {
+    float xp = x * kt[0] + y * kt[1] + z * kt[2] + kt[3];
+    float yp = x * kt[4] + y * kt[5] + z * kt[6] + kt[7];
+    float zp = (float)((double)(x * kt[8] + y * kt[9] + z * kt[10] + kt[11]) + 1E-15);
+    float wp = xp / zp, hp = yp / zp;
+    int wi = (int)round((double)wp), hi = (int)round((double)hp);
+    if (wp >= 0 && wp <= W - 1 && hp >= 0 && hp <= H - 1) {
+      float dt = depth_tgt[(long)b * plane + (long)hi * W + wi];
+      if (fabsf(zp - dt) < 3E-3) {
+        fh = hp - h;
+        fw = wp - w;
+        va = 1.f;
+      }
+    }
+  }
+  flow[((long)b * 2 + 0) * plane + (long)h * W + w] = fh;
+  flow[((long)b * 2 + 1) * plane + (long)h * W + w] = fw;
+  valid[index] = va;
+}
+
+}  // namespace dim
+
+using namespace dim;
+
+extern "C" int dim_depth_to_flow(const float* depth_src, const float* depth_tgt, const float* KT, const float* Kinv9, int B, int H,
+                                 int W, float* flow, float* valid, void* stream) {
+  DIM_REQUIRE(depth_src && depth_tgt && KT && Kinv9 && flow && valid, "null pointer");
+  if (B == 0) return DIM_OK;
+  hipLaunchKernelGGL(depth_flow_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, as_stream(stream), depth_src, depth_tgt, KT,
+                     Kinv9[0], Kinv9[1], Kinv9[2], Kinv9[3], Kinv9[4], Kinv9[5], H, W, flow, valid);
+  return check_launch("depth_to_flow");
+}

@@ -1,0 +1,315 @@
+// On-device depth/RGB rasteriser: replaces the glumpy/OpenGL renderer and its glReadPixels
+// round trip (/root/reference/lib/render_glumpy/render_py_multi.py:89-147, projection :152-169,
+// view matrix :171-178) so the refinement loop's render -> mask -> next-iteration-input step
+// (deepim/core/tester.py:563-590, lib/pair_matching/data_pair.py:86-135) never leaves HBM.
+//
+// Conventions pinned by the reference: pixel (i,j) samples the pinhole projection at
+// (u,v) = (fx*X/Z+cx, fy*Y/Z+cy) = (i,j)  [u0 = K[0,2]+0.5 with GL pixel centres at +0.5];
+// depth output = camera-frame Z in metres, 0 for background, clipped to [znear, zfar];
+// colour = unlit texture lookup, texture_map.png stored with row 0 = top (v is flipped).
+// Implementation-defined in GL and fixed here (same as oracle/raster.c): 8-bit sub-pixel
+// snapping, top-left fill rule, nearest or bilinear clamp-to-edge texel filter, z-fight ties
+// broken by the lower face index.
+//
+// Passes (all on one stream): clear z-buffer (u64 = depth bits << 32 | face id) -> project
+// vertices -> one thread per triangle, atomicMin per covered pixel -> resolve (textured RGB
+// written straight into the next iteration's network-input blobs + mask + bbox).
+#include "common.h"
+
+namespace dim {
+
+struct Edges {
+  long long A[3], B[3], C[3];
+  long long area;
+  bool tl[3];
+};
+
+__device__ inline int snap_px(float u) { return (int)floorf(u * 256.0f + 0.5f); }
+
+__device__ inline bool setup_edges(const int X[3], const int Y[3], Edges& e) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int a = (i + 1) % 3, b = (i + 2) % 3;
+    e.A[i] = (long long)Y[a] - (long long)Y[b];
+    e.B[i] = (long long)X[b] - (long long)X[a];
+    e.C[i] = (long long)X[a] * (long long)Y[b] - (long long)X[b] * (long long)Y[a];
+  }
+  e.area = e.A[0] * X[0] + e.B[0] * Y[0] + e.C[0];
+  if (e.area == 0) return false;
+  if (e.area < 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { e.A[i] = -e.A[i]; e.B[i] = -e.B[i]; e.C[i] = -e.C[i]; }
+    e.area = -e.area;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e.tl[i] = (e.A[i] > 0) || (e.A[i] == 0 && e.B[i] > 0);
+  return true;
+}
+
+__device__ inline bool inside_tri(const Edges& e, long long px, long long py, long long E[3]) {
+  bool in = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    E[i] = e.A[i] * px + e.B[i] * py + e.C[i];
+    in = in && (E[i] > 0 || (E[i] == 0 && e.tl[i]));
+  }
+  return in;
+}
+
+struct MeshRef {
+  int vert_off, nvert, face_off, nface;
+};
+
+// scr[b][i] = (u, v, Zc) for vertex i of the sample's mesh
+__global__ __launch_bounds__(256) void raster_vertex_kernel(const float* __restrict__ verts, const int* __restrict__ mesh_table,
+                                                            const int* __restrict__ class_index, const float* __restrict__ poses,
+                                                            float fx, float fy, float cx, float cy, int vmax,
+                                                            float* __restrict__ scr) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int* mt = mesh_table + 4 * class_index[b];
+  if (i >= mt[1]) return;
+  const float* p = verts + 3 * (long)(mt[0] + i);
+  const float* P = poses + 12 * b;
+  float xc = __fmaf_rn(P[0], p[0], __fmaf_rn(P[1], p[1], __fmaf_rn(P[2], p[2], P[3])));
+  float yc = __fmaf_rn(P[4], p[0], __fmaf_rn(P[5], p[1], __fmaf_rn(P[6], p[2], P[7])));
+  float zc = __fmaf_rn(P[8], p[0], __fmaf_rn(P[9], p[1], __fmaf_rn(P[10], p[2], P[11])));
+  float* s = scr + ((long)b * vmax + i) * 3;
+  s[0] = __fmaf_rn(fx, __fdiv_rn(xc, zc), cx);
+  s[1] = __fmaf_rn(fy, __fdiv_rn(yc, zc), cy);
+  s[2] = zc;
+}
+
+__device__ inline bool load_tri(const float* scr_b, const int* face, int X[3], int Y[3], float iz[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float* s = scr_b + 3 * (long)face[k];
+    if (!(s[2] > 1e-6f) || !(fabsf(s[0]) < 1.0e6f) || !(fabsf(s[1]) < 1.0e6f)) return false;
+    X[k] = snap_px(s[0]);
+    Y[k] = snap_px(s[1]);
+    iz[k] = __fdiv_rn(1.0f, s[2]);
+  }
+  return true;
+}
+
+__device__ inline float interp_z(const long long E[3], float inv_area, const float iz[3], float b[3]) {
+  b[0] = (float)E[0] * inv_area;
+  b[1] = (float)E[1] * inv_area;
+  b[2] = (float)E[2] * inv_area;
+  float invz = __fmaf_rn(b[2], iz[2], __fmaf_rn(b[1], iz[1], __fmul_rn(b[0], iz[0])));
+  return __fdiv_rn(1.0f, invz);
+}
+
+__global__ __launch_bounds__(256) void raster_tri_kernel(const int* __restrict__ faces, const int* __restrict__ mesh_table,
+                                                         const int* __restrict__ class_index, const float* __restrict__ scr,
+                                                         int vmax, int H, int W, float znear, float zfar,
+                                                         unsigned long long* __restrict__ zbuf) {
+  const int b = blockIdx.y;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int* mt = mesh_table + 4 * class_index[b];
+  if (f >= mt[3]) return;
+  const int* face = faces + 3 * (long)(mt[2] + f);
+  const float* scr_b = scr + (long)b * vmax * 3;
+  int X[3], Y[3];
+  float iz[3];
+  if (!load_tri(scr_b, face, X, Y, iz)) return;
+  Edges e;
+  if (!setup_edges(X, Y, e)) return;
+  int minX = min(X[0], min(X[1], X[2])), maxX = max(X[0], max(X[1], X[2]));
+  int minY = min(Y[0], min(Y[1], Y[2])), maxY = max(Y[0], max(Y[1], Y[2]));
+  int x0 = max((minX + 255) >> 8, 0), x1 = min(maxX >> 8, W - 1);
+  int y0 = max((minY + 255) >> 8, 0), y1 = min(maxY >> 8, H - 1);
+  if (x0 > x1 || y0 > y1) return;
+  const float inv_area = __fdiv_rn(1.0f, (float)e.area);
+  unsigned long long* zb = zbuf + (long)b * H * W;
+  for (int y = y0; y <= y1; ++y)
+    for (int x = x0; x <= x1; ++x) {
+      long long E[3];
+      if (!inside_tri(e, (long long)x * 256, (long long)y * 256, E)) continue;
+      float bw[3];
+      float z = interp_z(E, inv_area, iz, bw);
+      if (!(z >= znear && z <= zfar)) continue;
+      unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned)f;
+      atomicMin(zb + (long)y * W + x, key);
+    }
+}
+
+__device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// One thread per pixel.  Outputs (any may be null):
+//   image  (B,3,H,W): plane c = RGB[c] - plane_means[c]          (lib/utils/image.py:709-720 transform())
+//   depth  (B,1,H,W) metres;  mask (B,1,H,W) = depth > mask_thr   (deepim/core/tester.py:575-577)
+//   bgr    (B,H,W,3) 0..255 as Render_Py.render returns it
+//   bbox   (B,4) {min_x,max_x,min_y,max_y} of mask (pre-initialised to {W,-1,H,-1})
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __restrict__ uvs, const int* __restrict__ faces,
+                                                             const int* __restrict__ mesh_table, const unsigned char* __restrict__ tex,
+                                                             const int* __restrict__ tex_table, const int* __restrict__ class_index,
+                                                             const float* __restrict__ scr, const unsigned long long* __restrict__ zbuf,
+                                                             int vmax, int H, int W, int tex_bilinear, float pm0, float pm1, float pm2,
+                                                             float mask_thr, float* __restrict__ image, float* __restrict__ depth,
+                                                             float* __restrict__ mask, float* __restrict__ bgr, int* __restrict__ bbox) {
+  const int b = blockIdx.z;
+  const int y = blockIdx.y;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const long plane = (long)H * W;
+  float r = 0.f, g = 0.f, bl = 0.f, z = 0.f;
+  bool in_img = x < W;
+  if (in_img) {
+    unsigned long long key = zbuf[(long)b * plane + (long)y * W + x];
+    if (key != 0xFFFFFFFFFFFFFFFFull) {
+      const int cls = class_index[b];
+      const int* mt = mesh_table + 4 * cls;
+      const int f = (int)(unsigned)(key & 0xFFFFFFFFu);
+      z = __uint_as_float((unsigned)(key >> 32));
+      const int* face = faces + 3 * (long)(mt[2] + f);
+      const float* scr_b = scr + (long)b * vmax * 3;
+      int X[3], Y[3];
+      float iz[3], tu[3], tv[3];
+      load_tri(scr_b, face, X, Y, iz);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float* uv = uvs + 2 * (long)(mt[0] + face[k]);
+        tu[k] = uv[0];
+        tv[k] = uv[1];
+      }
+      Edges e;
+      long long E[3];
+      setup_edges(X, Y, e);
+      inside_tri(e, (long long)x * 256, (long long)y * 256, E);
+      const float inv_area = __fdiv_rn(1.0f, (float)e.area);
+      float bw[3];
+      interp_z(E, inv_area, iz, bw);
+      float w0 = __fmul_rn(bw[0], iz[0]), w1 = __fmul_rn(bw[1], iz[1]), w2 = __fmul_rn(bw[2], iz[2]);
+      float u = __fmul_rn(__fmaf_rn(w2, tu[2], __fmaf_rn(w1, tu[1], __fmul_rn(w0, tu[0]))), z);
+      float v = __fmul_rn(__fmaf_rn(w2, tv[2], __fmaf_rn(w1, tv[1], __fmul_rn(w0, tv[0]))), z);
+      const int* tt = tex_table + 3 * cls;
+      const unsigned char* T = tex + tt[0];
+      const int Ht = tt[1], Wt = tt[2];
+      if (!tex_bilinear) {
+        int tx = clampi((int)floorf(__fmul_rn(u, (float)Wt)), 0, Wt - 1);
+        int ty = clampi((int)floorf(__fmul_rn(v, (float)Ht)), 0, Ht - 1);
+        const unsigned char* px = T + ((long)(Ht - 1 - ty) * Wt + tx) * 3;
+        r = px[0]; g = px[1]; bl = px[2];
+      } else {
+        float xf = __fsub_rn(__fmul_rn(u, (float)Wt), 0.5f), yf = __fsub_rn(__fmul_rn(v, (float)Ht), 0.5f);
+        float x0f = floorf(xf), y0f = floorf(yf);
+        float ax = __fsub_rn(xf, x0f), ay = __fsub_rn(yf, y0f);
+        int xa = clampi((int)x0f, 0, Wt - 1), xb = clampi((int)x0f + 1, 0, Wt - 1);
+        int ya = clampi((int)y0f, 0, Ht - 1), yb = clampi((int)y0f + 1, 0, Ht - 1);
+        const unsigned char* p00 = T + ((long)(Ht - 1 - ya) * Wt + xa) * 3;
+        const unsigned char* p01 = T + ((long)(Ht - 1 - ya) * Wt + xb) * 3;
+        const unsigned char* p10 = T + ((long)(Ht - 1 - yb) * Wt + xa) * 3;
+        const unsigned char* p11 = T + ((long)(Ht - 1 - yb) * Wt + xb) * 3;
+        float c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float top = __fmaf_rn(ax, __fsub_rn((float)p01[k], (float)p00[k]), (float)p00[k]);
+          float bot = __fmaf_rn(ax, __fsub_rn((float)p11[k], (float)p10[k]), (float)p10[k]);
+          c[k] = floorf(__fmaf_rn(ay, __fsub_rn(bot, top), top));  // tester.py:244 astype("uint8")
+        }
+        r = c[0]; g = c[1]; bl = c[2];
+      }
+    }
+    const long o = (long)y * W + x;
+    if (image) {
+      float* im = image + (long)b * 3 * plane;
+      im[o] = r - pm0;
+      im[plane + o] = g - pm1;
+      im[2 * plane + o] = bl - pm2;
+    }
+    if (depth) depth[(long)b * plane + o] = z;
+    if (mask) mask[(long)b * plane + o] = z > mask_thr ? 1.f : 0.f;
+    if (bgr) {
+      float* q = bgr + ((long)b * plane + o) * 3;
+      q[0] = bl; q[1] = g; q[2] = r;
+    }
+  }
+  if (bbox) {
+    bool on = in_img && z > mask_thr;
+    unsigned long long ball = __ballot(on);
+    // per-wave min/max x via ballot (lanes are consecutive x), one atomic set per wave with coverage
+    if (ball) {
+      const int lane = threadIdx.x & 63;
+      if (lane == 0) {
+        int wave_x0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+        int lo = __ffsll((long long)ball) - 1;
+        int hi = 63 - __clzll((long long)ball);
+        atomicMin(&bbox[4 * b + 0], wave_x0 + lo);
+        atomicMax(&bbox[4 * b + 1], wave_x0 + hi);
+        atomicMin(&bbox[4 * b + 2], y);
+        atomicMax(&bbox[4 * b + 3], y);
+      }
+    }
+  }
+}
+
+// mask[b] = filled rectangle [y0:y1, x0:x1] (END-EXCLUSIVE: lib/pair_matching/data_pair.py:103-114)
+// of bbox[b]; empty bbox -> all zeros (the reference would raise in np.min; status reports it).
+__global__ __launch_bounds__(256) void box_mask_kernel(const int* __restrict__ bbox, float* __restrict__ mask, int H, int W) {
+  const int b = blockIdx.z, y = blockIdx.y;
+  const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (x4 >= W) return;
+  const int* bb = bbox + 4 * b;
+  const int xs = bb[0], xe = bb[1], ys = bb[2], ye = bb[3];
+  bool row = (bb[1] >= 0) && y >= ys && y < ye;
+  float4 v;
+  v.x = (row && x4 + 0 >= xs && x4 + 0 < xe) ? 1.f : 0.f;
+  v.y = (row && x4 + 1 >= xs && x4 + 1 < xe) ? 1.f : 0.f;
+  v.z = (row && x4 + 2 >= xs && x4 + 2 < xe) ? 1.f : 0.f;
+  v.w = (row && x4 + 3 >= xs && x4 + 3 < xe) ? 1.f : 0.f;
+  *reinterpret_cast<float4*>(mask + ((long)b * H + y) * W + x4) = v;
+}
+
+__global__ void bbox_init2_kernel(int* bbox, int n, int H, int W) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    bbox[4 * i + 0] = W; bbox[4 * i + 1] = -1; bbox[4 * i + 2] = H; bbox[4 * i + 3] = -1;
+  }
+}
+
+}  // namespace dim
+
+using namespace dim;
+
+extern "C" {
+
+long dim_raster_workspace_bytes(int B, int vmax, int H, int W) {
+  // z-buffer (u64 per pixel) followed by projected vertices (3 floats each)
+  return (long)B * H * W * 8 + (long)B * vmax * 3 * 4;
+}
+
+int dim_raster_render(const float* verts, const float* uvs, const int* faces, const int* mesh_table, int vmax, int fmax,
+                      const unsigned char* textures, const int* tex_table, const int* class_index, const float* poses,
+                      const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear, const float* plane_means3,
+                      float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox,
+                      void* stream) {
+  DIM_REQUIRE(verts && uvs && faces && mesh_table && textures && tex_table && class_index && poses && K9 && workspace, "null pointer");
+  DIM_REQUIRE(vmax > 0 && fmax > 0 && H > 0 && W > 0, "bad sizes");
+  DIM_REQUIRE(!image || plane_means3, "image output needs plane_means3");
+  if (B == 0) return DIM_OK;
+  hipStream_t st = as_stream(stream);
+  unsigned long long* zbuf = reinterpret_cast<unsigned long long*>(workspace);
+  float* scr = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (long)B * H * W * 8);
+  hipError_t e = hipMemsetAsync(zbuf, 0xFF, (size_t)B * H * W * 8, st);
+  if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "zbuf memset: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(raster_vertex_kernel, dim3(ceil_div(vmax, 256), B), dim3(256), 0, st, verts, mesh_table, class_index, poses,
+                     K9[0], K9[4], K9[2], K9[5], vmax, scr);
+  hipLaunchKernelGGL(raster_tri_kernel, dim3(ceil_div(fmax, 256), B), dim3(256), 0, st, faces, mesh_table, class_index, scr, vmax, H,
+                     W, znear, zfar, zbuf);
+  if (bbox) hipLaunchKernelGGL(bbox_init2_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, bbox, B, H, W);
+  float p0 = plane_means3 ? plane_means3[0] : 0.f, p1 = plane_means3 ? plane_means3[1] : 0.f, p2 = plane_means3 ? plane_means3[2] : 0.f;
+  hipLaunchKernelGGL(raster_resolve_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, st, uvs, faces, mesh_table, textures,
+                     tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, mask_thr, image, depth, mask, bgr,
+                     bbox);
+  return check_launch("raster_render");
+}
+
+int dim_box_mask(const int* bbox, float* mask, int B, int H, int W, void* stream) {
+  DIM_REQUIRE(bbox && mask, "null pointer");
+  DIM_REQUIRE(W % 4 == 0, "W must be a multiple of 4");
+  if (B == 0) return DIM_OK;
+  hipLaunchKernelGGL(box_mask_kernel, dim3(ceil_div(W / 4, 256), H, B), dim3(256), 0, as_stream(stream), bbox, mask, H, W);
+  return check_launch("box_mask");
+}
+
+}  // extern "C"

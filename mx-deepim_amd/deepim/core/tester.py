@@ -1,0 +1,122 @@
+"""Test-time iterative refinement, device resident.
+
+Mirror of /root/reference/deepim/core/tester.py: `Predictor` (:27-56) and the refinement loop of
+`pred_eval` (:418-642).  The reference runs batch 1 per GPU and, per iteration, syncs the 7 floats to
+the host, composes the pose in numpy (:525-532), renders with OpenGL + glReadPixels (:563-568),
+rebuilds the blobs on the host (data_pair.update_data_batch) and uploads them (:590).  Here a batch of
+pairs stays in HBM for all iterations:
+
+    forward (zoom -> encoder -> heads)  ->  se3_compose  ->  rasterise (image_rendered, mask_rendered,
+    bbox)  ->  box mask (mask_observed, UPDATE_MASK == "box_rendered")  ->  forward ...
+
+and the whole loop can be captured into one hipGraph (`Refiner(capture_graph=True)`).
+"""
+from __future__ import print_function, division
+
+import numpy as np
+import torch
+
+from lib.hip import ops
+from deepim.symbols.deepIM_flownet import FlowNetHip
+
+
+class Predictor(object):
+    """Reference: binds a MutableModule and calls forward (tester.py:27-56).  Here: owns a FlowNetHip."""
+
+    def __init__(self, config, arg_params, batch_size, device="cuda:0", conv_plan=None):
+        self.net = FlowNetHip(config, arg_params, batch_size, device=device, conv_plan=conv_plan)
+        self.data_names = ["image_observed", "image_rendered", "src_pose", "class_index", "mask_observed", "mask_rendered"]
+
+    def predict(self, data_batch):
+        """data_batch: dict blob-name -> CUDA tensor (names/shapes as deepim/core/loader.py:35-41).
+        Returns [dict(se3_output, zoom_factor)] -- one entry, since one process drives one GPU."""
+        return [self.net.forward_test(data_batch)]
+
+
+class Refiner(object):
+    def __init__(self, config, predictor, render_machine, batch_size, capture_graph=False):
+        cfg = config
+        if cfg.network.INPUT_MASK and cfg.network.PRED_MASK and cfg.TEST.UPDATE_MASK not in ("box_rendered", "init"):
+            # same restriction as the released loop (tester.py:579-587)
+            raise Exception("Unknown UPDATE_MASK type: {}".format(cfg.TEST.UPDATE_MASK))
+        self.cfg = cfg
+        self.predictor = predictor
+        self.net = predictor.net
+        self.render_machine = render_machine
+        self.B = batch_size
+        self.test_iter = int(cfg.TEST.test_iter)
+        d = self.net.device
+        B, H, W = batch_size, 480, 640
+        self.batch = {
+            "image_observed": torch.zeros((B, 3, H, W), dtype=torch.float32, device=d),
+            "image_rendered": torch.zeros((B, 3, H, W), dtype=torch.float32, device=d),
+            "mask_observed": torch.zeros((B, 1, H, W), dtype=torch.float32, device=d),
+            "mask_rendered": torch.zeros((B, 1, H, W), dtype=torch.float32, device=d),
+            "src_pose": torch.zeros((B, 3, 4), dtype=torch.float32, device=d),
+            "class_index": torch.zeros((B,), dtype=torch.int32, device=d),
+        }
+        # pristine copies of the blobs the loop overwrites, so refine() can be replayed on the same batch
+        self.init = {k: torch.zeros_like(self.batch[k]) for k in ("image_rendered", "mask_observed", "mask_rendered")}
+        self.pose_init = torch.zeros((B, 3, 4), dtype=torch.float32, device=d)
+        self.poses_iter = torch.zeros((self.test_iter, B, 3, 4), dtype=torch.float32, device=d)
+        self.se3_iter = torch.zeros((self.test_iter, B, 7), dtype=torch.float32, device=d)
+        self.bbox = torch.zeros((B, 4), dtype=torch.int32, device=d)
+        self.depth = torch.zeros((B, 1, H, W), dtype=torch.float32, device=d)
+        self.status_iter = torch.zeros((self.test_iter, B), dtype=torch.int32, device=d)
+        self.T_means = np.asarray(cfg.dataset.trans_means, dtype=np.float32)
+        self.T_stds = np.asarray(cfg.dataset.trans_stds, dtype=np.float32)
+        render_machine.reserve(B)
+        self.graph = None
+        self._want_graph = capture_graph
+
+    # ------------------------------------------------------------------------------------------
+    def load(self, image_observed, image_rendered, mask_observed, mask_rendered, src_pose, class_index):
+        """copy one batch of blobs (any device) into the resident buffers"""
+        b = self.batch
+        b["image_observed"].copy_(torch.as_tensor(image_observed))
+        self.init["image_rendered"].copy_(torch.as_tensor(image_rendered))
+        self.init["mask_observed"].copy_(torch.as_tensor(mask_observed))
+        self.init["mask_rendered"].copy_(torch.as_tensor(mask_rendered))
+        self.pose_init.copy_(torch.as_tensor(src_pose))
+        b["class_index"].copy_(torch.as_tensor(class_index).to(torch.int32))
+
+    def _loop(self):
+        """tester.py:476-598 for a whole batch; everything enqueued on the current stream, no host sync."""
+        cfg, net, b = self.cfg, self.net, self.batch
+        b["src_pose"].copy_(self.pose_init)
+        for k, v in self.init.items():
+            b[k].copy_(v)
+        bbox = None
+        for it in range(self.test_iter):
+            net.forward_test(b, bbox_ren=bbox)
+            self.se3_iter[it].copy_(net.se3)
+            self.status_iter[it].copy_(net.status)
+            # pose_rendered_update = RT_transform(pose_rendered, se3[:-3], se3[-3:], ...)   (:525-532)
+            ops.se3_compose(b["src_pose"], net.se3, cfg.network.ROT_COORD, self.T_means, self.T_stds, out=self.poses_iter[it])
+            if it < self.test_iter - 1:
+                # render(render_machine, pose_rendered_update, cls_idx) + update_data_batch  (:563-590)
+                self.render_machine.render_batch(b["class_index"], self.poses_iter[it], image=b["image_rendered"], depth=self.depth,
+                                                 mask=b["mask_rendered"], bbox=self.bbox, plane_means=net.plane_means, mask_thr=0.2)
+                if cfg.network.INPUT_MASK and cfg.network.PRED_MASK and cfg.TEST.UPDATE_MASK == "box_rendered":
+                    ops.box_mask(self.bbox, b["mask_observed"])  # data_pair.py:103-114
+                b["src_pose"].copy_(self.poses_iter[it])
+                bbox = self.bbox
+
+    def refine(self):
+        """run test_iter iterations on the loaded batch; returns poses_iter (test_iter,B,3,4) (device)."""
+        if self._want_graph and self.graph is None:
+            s = torch.cuda.Stream(device=self.net.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._loop()  # warm-up outside capture (lazy module loads, attribute sets)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._loop()
+            self.graph = g
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._loop()
+        return self.poses_iter

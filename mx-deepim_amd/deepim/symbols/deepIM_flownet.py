@@ -1,0 +1,234 @@
+"""DeepIM FlowNetSimple network on the HIP kernels.
+
+Mirror of /root/reference/deepim/symbols/deepIM_flownet.py (class deepIM_flownet): the same layer
+names, parameter names/shapes (MXNet layouts) and test-graph outputs (`se3`, `zoom_factor`), but the
+"symbol" is executed directly: zoom (csrc/zoom.hip) -> 10 direct convolutions + fc6 (csrc/conv.hip,
+f32 MFMA, NHWC) -> pose head -> se3.  Weights are packed once into the kernels' layout.
+
+  get_convs            :32-301   -> FlowNetHip.encoder()
+  get_test_symbol_share:764-980  -> FlowNetHip.forward_test()
+  init_weights         :998-1124 -> deepIM_flownet.init_weights() (random init; the FlowNet
+                                    checkpoint is an external download and is not available offline)
+"""
+import numpy as np
+import torch
+
+from lib.hip import ops
+
+# name, cout, kernel, stride, pad      (deepIM_flownet.py:67-191)
+ENCODER = [
+    ("flow_conv1", 64, 7, 2, 3),
+    ("conv2", 128, 5, 2, 2),
+    ("conv3", 256, 5, 2, 2),
+    ("conv3_1", 256, 3, 1, 1),
+    ("conv4", 512, 3, 2, 1),
+    ("conv4_1", 512, 3, 1, 1),
+    ("conv5", 512, 3, 2, 1),
+    ("conv5_1", 512, 3, 1, 1),
+    ("conv6", 1024, 3, 2, 1),
+    ("conv6_1", 1024, 3, 1, 1),
+]
+
+
+def input_channels(cfg):
+    """Concat arity of get_convs (reference :33-66): 6 RGB (+2 depth) (+2 masks iff INPUT_MASK and PRED_MASK)."""
+    c = 6
+    if cfg.network.INPUT_DEPTH:
+        c += 2
+    if cfg.network.INPUT_MASK and cfg.network.PRED_MASK:
+        c += 2
+    return c
+
+
+class deepIM_flownet(object):
+    def __init__(self):
+        self.eps = 1e-5
+        self.workspace = 4096
+        self.arg_shape_dict = {}
+        self.sym = None
+
+    def infer_param_shapes(self, cfg):
+        cin = input_channels(cfg)
+        shp = {}
+        c = cin
+        for name, cout, k, s, p in ENCODER:
+            shp[name + "_weight"] = (cout, c, k, k)
+            shp[name + "_bias"] = (cout,)
+            c = cout
+        shp["fc6_weight"] = (256, 1024 * 8 * 10)
+        shp["fc6_bias"] = (256,)
+        shp["fc7_weight"] = (256, 256)
+        shp["fc7_bias"] = (256,)
+        shp["rot_weight"] = (4 if cfg.network.ROT_TYPE == "QUAT" else 3, 256)
+        shp["rot_bias"] = (shp["rot_weight"][0],)
+        shp["trans_weight"] = (3, 256)
+        shp["trans_bias"] = (3,)
+        if cfg.network.PRED_FLOW or cfg.network.PRED_MASK:
+            shp["Convolution1_weight"] = (2, 1024, 3, 3)
+            shp["Convolution1_bias"] = (2,)
+            shp["deconv5_weight"] = (1024, 512, 4, 4)
+            shp["deconv5_bias"] = (512,)
+            shp["upsample_flow6to5_weight"] = (2, 2, 4, 4)
+            shp["upsample_flow6to5_bias"] = (2,)
+            shp["Convolution2_weight"] = (2, 1026, 3, 3)
+            shp["Convolution2_bias"] = (2,)
+            shp["deconv4_weight"] = (1026, 256, 4, 4)
+            shp["deconv4_bias"] = (256,)
+            shp["upsample_flow5to4_weight"] = (2, 2, 4, 4)
+            shp["upsample_flow5to4_bias"] = (2,)
+        if cfg.network.PRED_FLOW:
+            shp["Convolution3_weight"] = (2, 770, 3, 3)
+            shp["Convolution3_bias"] = (2,)
+            shp["upsampling_weight"] = (2, 1, 32, 32)
+        if cfg.network.PRED_MASK:
+            shp["mask_conv3_weight"] = (1, 770, 3, 3)
+            shp["mask_conv3_bias"] = (1,)
+            shp["mask_upsampling_weight"] = (1, 1, 32, 32)
+        self.arg_shape_dict = shp
+        return shp
+
+    def get_symbol(self, cfg, is_train=True):
+        """The reference returns an mx Symbol; here the 'symbol' is the shape table + the executor class."""
+        self.infer_param_shapes(cfg)
+        self.sym = ("train" if is_train else "test", cfg)
+        return self.sym
+
+    @staticmethod
+    def bilinear_kernel(shape):
+        """mx.init.Initializer._init_bilinear (reference :1077-1099)."""
+        w = np.zeros(int(np.prod(shape)), dtype=np.float32)
+        f = np.ceil(shape[3] / 2.0)
+        c = (2 * f - 1 - f % 2) / (2.0 * f)
+        for i in range(w.size):
+            x = i % shape[3]
+            y = (i // shape[3]) % shape[2]
+            w[i] = (1 - abs(x / f - c)) * (1 - abs(y / f - c))
+        return w.reshape(shape)
+
+    def init_weights(self, cfg, arg_params, aux_params, seed=0):
+        """Fill every missing parameter.  Encoder/decoder convs: seeded He-normal stand-in for the FlowNet
+        checkpoint (with the mask channels of flow_conv1 zero-padded as :1009-1025 does); heads as
+        :1033-1099 (xavier fc6/fc7, rot row 0 ~U(.01,1.01), rest ~U(0,.01), trans zeros, bilinear upsampling)."""
+        if not self.arg_shape_dict:
+            self.infer_param_shapes(cfg)
+        rng = np.random.RandomState(seed)
+        for k, shp in self.arg_shape_dict.items():
+            if k in arg_params:
+                continue
+            if k.endswith("bias"):
+                arg_params[k] = np.zeros(shp, dtype=np.float32) if k.startswith(("fc", "rot", "trans", "mask_conv3")) else \
+                    rng.normal(0, 0.01, size=shp).astype(np.float32)
+            elif k in ("upsampling_weight", "mask_upsampling_weight"):
+                arg_params[k] = self.bilinear_kernel(shp)
+            elif k == "rot_weight":
+                w = rng.rand(*shp) * 0.01
+                w[0, :] = rng.rand(shp[1]) + 0.01
+                arg_params[k] = w.astype(np.float32)
+            elif k == "trans_weight":
+                arg_params[k] = np.zeros(shp, dtype=np.float32)
+            elif k in ("fc6_weight", "fc7_weight"):
+                scale = np.sqrt(3.0 / ((shp[0] + shp[1]) / 2.0))  # mx.init.Xavier(uniform, avg, 3)
+                arg_params[k] = rng.uniform(-scale, scale, size=shp).astype(np.float32)
+            elif k == "mask_conv3_weight":
+                arg_params[k] = rng.normal(0, 0.01, size=shp).astype(np.float32)
+            else:
+                fan_in = int(np.prod(shp[1:])) if not k.startswith(("deconv", "upsample_flow")) else shp[0] * shp[2] * shp[3] // 4
+                w = rng.normal(0, np.sqrt(2.0 / (1.01 * fan_in)), size=shp).astype(np.float32)
+                if k == "flow_conv1_weight" and shp[1] > 6:
+                    w[:, 6:] = 0.0
+                arg_params[k] = w
+        return arg_params
+
+
+class FlowNetHip(object):
+    """Device executor of the test graph for a fixed per-GPU batch size B (all buffers pre-allocated)."""
+
+    H, W = 480, 640
+
+    def __init__(self, cfg, arg_params, batch_size, device="cuda:0", conv_plan=None):
+        self.cfg = cfg
+        self.B = batch_size
+        self.device = torch.device(device)
+        self.cin = input_channels(cfg)
+        if self.cin != 8:
+            raise NotImplementedError("HIP encoder is built for the shipped 8-channel input (INPUT_MASK & PRED_MASK, no depth)")
+        d = self.device
+        self.params = {k: torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float32).to(d) for k, v in arg_params.items()}
+        self.packed = {}
+        for name, cout, k, s, p in ENCODER:
+            self.packed[name] = ops.conv2d_pack_weight(self.params[name + "_weight"])
+        self.packed["fc6"] = ops.fc_pack_weight(self.params["fc6_weight"], 1024, 8, 10)
+        self.K = np.asarray(cfg.dataset.INTRINSIC_MATRIX, dtype=np.float32).reshape(3, 3)
+        self.plane_means = np.asarray(cfg.network.PIXEL_MEANS, dtype=np.float32).reshape(3)[::-1].copy()
+        # tile / split-K plan per layer: (tile, splits); 0 = library heuristic
+        self.conv_plan = {"fc6": (3, 160)}
+        if conv_plan:
+            self.conv_plan.update(conv_plan)
+        B, H, W = batch_size, self.H, self.W
+        self.X = torch.empty((B, H, W, 8), dtype=torch.float32, device=d)
+        self.acts = {}
+        h, w, c = H, W, 8
+        max_ws = 0
+        for name, cout, k, s, p in ENCODER:
+            ho, wo = ops.conv_out_hw(h, w, k, k, s, p)
+            self.acts[name] = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=d)
+            tile, splits = self.conv_plan.get(name, (0, 1))
+            if splits > 1:
+                max_ws = max(max_ws, ops.lib().dim_conv2d_workspace_floats(B, h, w, c, cout, k, k, s, p, splits))
+            h, w, c = ho, wo, cout
+        assert (h, w, c) == (8, 10, 1024)
+        tile, splits = self.conv_plan["fc6"]
+        max_ws = max(max_ws, ops.lib().dim_conv2d_workspace_floats(B, 8, 10, 1024, 256, 8, 10, 1, 0, splits))
+        self.workspace = torch.empty((max(max_ws, 4),), dtype=torch.float32, device=d)
+        self.fc6 = torch.empty((B, 1, 1, 256), dtype=torch.float32, device=d)
+        self.fc7 = torch.empty((B, 256), dtype=torch.float32, device=d)
+        self.se3 = torch.empty((B, 7), dtype=torch.float32, device=d)
+        self.zoom_factor = torch.empty((B, 4), dtype=torch.float32, device=d)
+        self.bbox_obs = torch.empty((B, 4), dtype=torch.int32, device=d)
+        self.bbox_ren = torch.empty((B, 4), dtype=torch.int32, device=d)
+        self.status = torch.zeros((B,), dtype=torch.int32, device=d)
+        torch.cuda.synchronize(d)
+
+    # ---- pieces -------------------------------------------------------------------------------
+    def zoom(self, batch, bbox_ren=None, nchw_out=None):
+        """ZoomMask + ZoomImageWithFactor + Concat (reference :783-806, :53-60).  At test time
+        mask_gt_observed IS mask_observed (:779).  bbox_ren may come pre-computed from the rasteriser."""
+        ops.mask_bbox(batch["mask_observed"], 0.3, out=self.bbox_obs)
+        if bbox_ren is None:
+            bbox_ren = ops.mask_bbox(batch["mask_rendered"], 0.2, out=self.bbox_ren)
+        ops.zoom_factor(self.bbox_obs, bbox_ren, batch["src_pose"], self.K, self.H, self.W, out=self.zoom_factor, status=self.status)
+        ops.zoom_net_input(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"],
+                           self.zoom_factor, self.plane_means, X=self.X, nchw_out=nchw_out)
+        return self.X
+
+    def encoder(self, X=None):
+        x = self.X if X is None else X
+        for name, cout, k, s, p in ENCODER:
+            tile, splits = self.conv_plan.get(name, (0, 1))
+            x = ops.conv2d_fwd(x, self.packed[name], self.params[name + "_bias"], cout, k, k, s, p, slope=0.1, splits=splits,
+                               tile=tile, out=self.acts[name], workspace=self.workspace)
+        tile, splits = self.conv_plan["fc6"]
+        ops.conv2d_fwd(x, self.packed["fc6"], self.params["fc6_bias"], 256, 8, 10, 1, 0, slope=0.1, splits=splits, tile=tile,
+                       out=self.fc6, workspace=self.workspace)
+        return self.fc6
+
+    def head(self):
+        return ops.pose_head_fwd(self.fc6.view(self.B, 256), self.params, self.zoom_factor, se3=self.se3, fc7_out=self.fc7)
+
+    def forward_test(self, batch, bbox_ren=None):
+        """One test-graph forward (FAST_TEST graph: zoom + encoder + FC heads).  Returns the output dict the
+        refinement loop reads (tester.py:483): se3_output (B,7), zoom_factor (B,4)."""
+        self.zoom(batch, bbox_ren=bbox_ren)
+        self.encoder()
+        self.head()
+        return {"se3_output": self.se3, "zoom_factor": self.zoom_factor}
+
+    def flops_per_forward(self):
+        """algorithmic MACs*2 of encoder + head for this batch (SURVEY.md 8a layer table)."""
+        h, w, c, total = self.H, self.W, 8, 0
+        for name, cout, k, s, p in ENCODER:
+            h, w = ops.conv_out_hw(h, w, k, k, s, p)
+            total += h * w * cout * c * k * k
+            c = cout
+        total += 81920 * 256 + 256 * 256 + 256 * 7
+        return 2 * total * self.B

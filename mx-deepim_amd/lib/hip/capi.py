@@ -1,0 +1,110 @@
+"""ctypes binding of libdeepim_hip.so (the C ABI declared in include/deepim_hip.h).
+
+The product path has NO CPU fallback: importing this module without the built library, or calling
+an op with non-CUDA tensors, raises.  Build with `make -C mx-deepim_amd/csrc` (or
+`python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "libdeepim_hip.so"))
+
+P = ctypes.c_void_p  # device pointer / host array / stream
+I = ctypes.c_int
+F = ctypes.c_float
+L = ctypes.c_long
+
+# name -> (restype, argtypes); mirrors include/deepim_hip.h one to one
+SIGNATURES = {
+    "dim_last_error": (ctypes.c_char_p, []),
+    "dim_device_info": (I, [ctypes.c_char_p, I]),
+    "dim_mask_bbox": (I, [P, I, I, I, I, I, F, P, P, P]),
+    "dim_zoom_factor": (I, [P, P, P, P, I, I, I, P, P, P]),
+    "dim_zoom_planes": (I, [P, P, P, I, I, I, I, I, I, I, P, I, P]),
+    "dim_zoom_net_input": (I, [P, P, P, P, P, P, I, I, I, P, P, P, P, P, P]),
+    "dim_zoom_trans": (I, [P, P, P, I, I, P]),
+    "dim_se3_compose": (I, [P, P, P, P, I, I, P, P, P]),
+    "dim_se3_delta": (I, [P, P, P, P, I, I, P, P, P]),
+    "dim_transform3d_fwd": (I, [P, P, P, P, P, I, I, I, P, P, P]),
+    "dim_transform3d_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P, P]),
+    "dim_depth_to_flow": (I, [P, P, P, P, I, I, I, P, P, P]),
+    "dim_raster_workspace_bytes": (L, [I, I, I, I]),
+    "dim_raster_render": (I, [P, P, P, P, I, I, P, P, P, P, P, I, I, I, F, F, I, P, F, P, P, P, P, P, P, P]),
+    "dim_box_mask": (I, [P, P, I, I, I, P]),
+    "dim_conv2d_packed_weight_floats": (L, [I, I, I, I]),
+    "dim_conv2d_pack_weight": (I, [P, P, I, I, I, I, P]),
+    "dim_conv2d_workspace_floats": (L, [I, I, I, I, I, I, I, I, I, I]),
+    "dim_conv2d_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, P]),
+    "dim_fc_pack_weight": (I, [P, P, I, I, I, I, P]),
+    "dim_pose_head_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, P]),
+}
+
+_lib = None
+
+
+class DeepIMHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DeepIMHipError(
+                "libdeepim_hip.so not found at {} -- build it with `make -C mx-deepim_amd/csrc`; "
+                "there is no CPU fallback for the refinement path".format(LIB_PATH))
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise DeepIMHipError("libdeepim_hip error {}: {}".format(rc, lib().dim_last_error().decode()))
+
+
+def host_f32(values, n=None):
+    """small HOST float array argument (K9, means3, ...) -> (keepalive ndarray, pointer)."""
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
+    if n is not None and a.size != n:
+        raise ValueError("expected {} floats, got {}".format(n, a.size))
+    return a, a.ctypes.data
+
+
+def dptr(t, dtype=None):
+    """device pointer of a contiguous CUDA torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    import torch
+
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise DeepIMHipError("expected a CUDA tensor (the HIP path has no CPU fallback), got {}".format(type(t)))
+    if not t.is_contiguous():
+        raise DeepIMHipError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise DeepIMHipError("expected dtype {}, got {}".format(dtype, t.dtype))
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+ROT_COORD = {"model": 0, "camera": 1, "camera_new": 2, "naive": 3}
+
+
+def rot_coord_id(name):
+    try:
+        return ROT_COORD[name.lower()]
+    except KeyError:
+        raise Exception("Unknown rot_coord: {}".format(name))

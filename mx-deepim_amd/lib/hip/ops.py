@@ -1,0 +1,164 @@
+"""Thin torch-tensor front-ends of the C ABI (one function per entry point of include/deepim_hip.h).
+
+Every function only enqueues HIP kernels on torch's current stream; outputs are written into
+caller-provided tensors when given, so the refinement loop can run allocation-free inside a
+hipGraph capture.  No CPU fallback: non-CUDA tensors raise DeepIMHipError.
+"""
+import torch
+
+from . import capi
+from .capi import check, current_stream, dptr, host_f32, lib
+
+f32 = torch.float32
+i32 = torch.int32
+
+
+def _new(shape, like, dtype=f32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def mask_bbox(x, thr, mode=0, means3=None, out=None):
+    """bbox (B,4) int32 = {min_x,max_x,min_y,max_y} of the predicate; empty = {W,-1,H,-1}."""
+    B, C, H, W = x.shape
+    out = out if out is not None else _new((B, 4), x, i32)
+    keep, mp = host_f32(means3, 3) if means3 is not None else (None, None)
+    check(lib().dim_mask_bbox(dptr(x, f32), B, C, H, W, mode, float(thr), mp, dptr(out, i32), current_stream()))
+    return out
+
+
+def zoom_factor(bbox_obs, bbox_ren, src_pose, K, H, W, out=None, status=None):
+    B = src_pose.shape[0]
+    out = out if out is not None else _new((B, 4), src_pose)
+    keep, kp = host_f32(K, 9)
+    check(lib().dim_zoom_factor(dptr(bbox_obs, i32), dptr(bbox_ren, i32), dptr(src_pose, f32), kp, B, H, W, dptr(out, f32),
+                                dptr(status, i32), current_stream()))
+    return out
+
+
+def zoom_planes(x, zf, inverse=False, pre=0, post=0, add3=None, scale_mode=0, out=None):
+    B, C, H, W = x.shape
+    out = out if out is not None else torch.empty_like(x)
+    keep, ap = host_f32(add3, 3) if add3 is not None else (None, None)
+    check(lib().dim_zoom_planes(dptr(x, f32), dptr(zf, f32), dptr(out, f32), B, C, H, W, int(inverse), pre, post, ap, scale_mode,
+                                current_stream()))
+    return out
+
+
+def zoom_net_input(img_obs, img_ren, mask_obs, mask_ren, zf, plane_means3, X=None, nchw_out=None):
+    """X (B,H,W,8) NHWC network input.  nchw_out: optional (z_img_obs, z_img_ren, z_mask_obs, z_mask_ren)."""
+    B, _, H, W = img_obs.shape
+    X = X if X is not None else _new((B, H, W, 8), img_obs)
+    keep, mp = host_f32(plane_means3, 3)
+    z = nchw_out if nchw_out is not None else (None, None, None, None)
+    check(lib().dim_zoom_net_input(dptr(img_obs, f32), dptr(img_ren, f32), dptr(mask_obs, f32), dptr(mask_ren, f32), dptr(zf, f32),
+                                   dptr(X, f32), B, H, W, mp, dptr(z[0], f32), dptr(z[1], f32), dptr(z[2], f32), dptr(z[3], f32),
+                                   current_stream()))
+    return X
+
+
+def zoom_trans(zf, t, mode, out=None):
+    B = t.shape[0]
+    out = out if out is not None else torch.empty_like(t)
+    check(lib().dim_zoom_trans(dptr(zf, f32), dptr(t, f32), dptr(out, f32), B, mode, current_stream()))
+    return out
+
+
+def se3_compose(pose_src, se3, rot_coord, T_means, T_stds, out=None, out_f64=None):
+    B = pose_src.shape[0]
+    out = out if out is not None else torch.empty_like(pose_src)
+    k1, mp = host_f32(T_means, 3)
+    k2, sp = host_f32(T_stds, 3)
+    check(lib().dim_se3_compose(dptr(pose_src, f32), dptr(se3, f32), dptr(out, f32), dptr(out_f64, torch.float64), B,
+                                capi.rot_coord_id(rot_coord), mp, sp, current_stream()))
+    return out
+
+
+def se3_delta(pose_src, pose_tgt, rot_coord, T_means, T_stds):
+    B = pose_src.shape[0]
+    rot = _new((B, 4), pose_src)
+    trans = _new((B, 3), pose_src)
+    k1, mp = host_f32(T_means, 3)
+    k2, sp = host_f32(T_stds, 3)
+    check(lib().dim_se3_delta(dptr(pose_src, f32), dptr(pose_tgt, f32), dptr(rot, f32), dptr(trans, f32), B,
+                              capi.rot_coord_id(rot_coord), mp, sp, current_stream()))
+    return rot, trans
+
+
+def transform3d_fwd(points, rot, trans, pose_src, rot_coord, T_means, T_stds, out=None):
+    B = points.shape[0]
+    npts = points.numel() // (B * 3) if B else 0
+    out = out if out is not None else torch.empty_like(points)
+    k1, mp = host_f32(T_means, 3)
+    k2, sp = host_f32(T_stds, 3)
+    check(lib().dim_transform3d_fwd(dptr(points, f32), dptr(rot, f32), dptr(trans, f32), dptr(pose_src, f32), dptr(out, f32), B, npts,
+                                    capi.rot_coord_id(rot_coord), mp, sp, current_stream()))
+    return out
+
+
+def transform3d_bwd(out_grad, points, rot, trans, pose_src, rot_coord, T_means, T_stds):
+    B = points.shape[0]
+    npts = points.numel() // (B * 3) if B else 0
+    d_rot = torch.empty_like(rot)
+    d_trans = torch.empty_like(trans)
+    k1, mp = host_f32(T_means, 3)
+    k2, sp = host_f32(T_stds, 3)
+    check(lib().dim_transform3d_bwd(dptr(out_grad, f32), dptr(points, f32), dptr(rot, f32), dptr(trans, f32), dptr(pose_src, f32),
+                                    dptr(d_rot, f32), dptr(d_trans, f32), B, npts, capi.rot_coord_id(rot_coord), mp, sp,
+                                    current_stream()))
+    return d_rot, d_trans
+
+
+def depth_to_flow(depth_src, depth_tgt, KT, Kinv, flow=None, valid=None):
+    B, _, H, W = depth_src.shape
+    flow = flow if flow is not None else _new((B, 2, H, W), depth_src)
+    valid = valid if valid is not None else _new((B, 1, H, W), depth_src)
+    keep, kp = host_f32(Kinv, 9)
+    check(lib().dim_depth_to_flow(dptr(depth_src, f32), dptr(depth_tgt, f32), dptr(KT, f32), kp, B, H, W, dptr(flow, f32),
+                                  dptr(valid, f32), current_stream()))
+    return flow, valid
+
+
+def box_mask(bbox, mask):
+    B, _, H, W = mask.shape
+    check(lib().dim_box_mask(dptr(bbox, i32), dptr(mask, f32), B, H, W, current_stream()))
+    return mask
+
+
+def conv2d_pack_weight(w_oihw):
+    Cout, Cin, KH, KW = w_oihw.shape
+    n = lib().dim_conv2d_packed_weight_floats(Cout, Cin, KH, KW)
+    wp = _new((n,), w_oihw)
+    check(lib().dim_conv2d_pack_weight(dptr(w_oihw.contiguous(), f32), dptr(wp, f32), Cout, Cin, KH, KW, current_stream()))
+    return wp
+
+
+def fc_pack_weight(w_out_in, C, H, W):
+    Out = w_out_in.shape[0]
+    wp = _new((Out * C * H * W,), w_out_in)
+    check(lib().dim_fc_pack_weight(dptr(w_out_in.contiguous(), f32), dptr(wp, f32), Out, C, H, W, current_stream()))
+    return wp
+
+
+def conv_out_hw(H, W, KH, KW, stride, pad):
+    return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+
+
+def conv2d_fwd(x_nhwc, w_packed, bias, Cout, KH, KW, stride, pad, slope=0.1, splits=1, tile=0, out=None, workspace=None):
+    N, H, W, Cin = x_nhwc.shape
+    Ho, Wo = conv_out_hw(H, W, KH, KW, stride, pad)
+    out = out if out is not None else _new((N, Ho, Wo, Cout), x_nhwc)
+    if splits > 1 and workspace is None:
+        workspace = _new((lib().dim_conv2d_workspace_floats(N, H, W, Cin, Cout, KH, KW, stride, pad, splits),), x_nhwc)
+    check(lib().dim_conv2d_fwd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), dptr(workspace, f32), N, H, W,
+                               Cin, Cout, KH, KW, stride, pad, float(slope), splits, tile, current_stream()))
+    return out
+
+
+def pose_head_fwd(fc6, p, zf, se3=None, fc7_out=None):
+    """p: dict with fc7_weight/bias, rot_weight/bias, trans_weight/bias (reference (out,in) layout)."""
+    B = fc6.shape[0]
+    se3 = se3 if se3 is not None else _new((B, 7), fc6)
+    check(lib().dim_pose_head_fwd(dptr(fc6, f32), dptr(p["fc7_weight"], f32), dptr(p["fc7_bias"], f32), dptr(p["rot_weight"], f32),
+                                  dptr(p["rot_bias"], f32), dptr(p["trans_weight"], f32), dptr(p["trans_bias"], f32), dptr(zf, f32),
+                                  dptr(se3, f32), dptr(fc7_out, f32), B, current_stream()))
+    return se3

@@ -1,0 +1,197 @@
+/* Software rasteriser -- CPU oracle for lib/render_glumpy/render_py_multi.py (test-only).
+ *
+ * Restates what Render_Py.render (render_py_multi.py:112-147) asks OpenGL to do:
+ *   - view = diag(1,-1,-1)*[R|t] (:171-178) and the pinhole projection of
+ *     my_compute_calib_proj (:152-169).  Deriving window coordinates from that matrix
+ *     gives  x_win = fx*X/Z + cx + 0.5,  y_win(top-down after flipud) = fy*Y/Z + cy + 0.5,
+ *     i.e. the centre of pixel (i,j) samples the projection at (u,v) = (i,j).
+ *   - GL depth buffer -> metric depth (:139-146) is exactly camera-frame Z; background 0.
+ *   - unlit texture lookup (fragment shader :36-46) of texture_map.png uploaded flipped
+ *     vertically (:76-78); colour returned as BGR * 255 (:135-137).
+ * OpenGL's fill rule / sub-pixel snapping / texture filter are implementation-defined
+ * (glumpy + driver absent here): this oracle fixes them as 8-bit sub-pixel snapping,
+ * top-left fill rule, nearest (default) or bilinear clamp-to-edge filtering.
+ * "parity unpinned" w.r.t. a real GL context; the HIP rasteriser is checked against THIS.
+ *
+ * Geometric near-plane clipping is not implemented: triangles with a vertex at Z<=1e-6 are
+ * dropped; fragments outside [znear,zfar] are discarded per pixel.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SUBPIX 256.0f
+#define COORD_LIM 1.0e6f
+
+typedef struct {
+  int64_t A[3], B[3], C[3];
+  int64_t area;
+  int tl[3];
+} edges_t;
+
+static inline int32_t snap(float u) { return (int32_t)floorf(u * SUBPIX + 0.5f); }
+
+/* returns 0 when degenerate */
+static int setup_edges(const int32_t X[3], const int32_t Y[3], edges_t *e) {
+  /* edge i is opposite vertex i: from v[(i+1)%3] to v[(i+2)%3] */
+  for (int i = 0; i < 3; ++i) {
+    int a = (i + 1) % 3, b = (i + 2) % 3;
+    e->A[i] = (int64_t)Y[a] - (int64_t)Y[b];
+    e->B[i] = (int64_t)X[b] - (int64_t)X[a];
+    e->C[i] = (int64_t)X[a] * (int64_t)Y[b] - (int64_t)X[b] * (int64_t)Y[a];
+  }
+  e->area = e->A[0] * X[0] + e->B[0] * Y[0] + e->C[0];
+  if (e->area == 0) return 0;
+  if (e->area < 0) {
+    for (int i = 0; i < 3; ++i) { e->A[i] = -e->A[i]; e->B[i] = -e->B[i]; e->C[i] = -e->C[i]; }
+    e->area = -e->area;
+  }
+  for (int i = 0; i < 3; ++i) e->tl[i] = (e->A[i] > 0) || (e->A[i] == 0 && e->B[i] > 0);
+  return 1;
+}
+
+static inline int inside(const edges_t *e, int64_t px, int64_t py, int64_t E[3]) {
+  for (int i = 0; i < 3; ++i) {
+    E[i] = e->A[i] * px + e->B[i] * py + e->C[i];
+    if (E[i] < 0 || (E[i] == 0 && !e->tl[i])) return 0;
+  }
+  return 1;
+}
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* One view. verts (V,3), uvs (V,2), faces (F,3) int32; tex (Ht,Wt,3) uint8 RGB, row 0 = top of the
+ * image file; R (9) row-major, t (3), K (9); outputs bgr (H,W,3) float 0..255, depth (H,W) float.
+ * shade: NULL, or per-vertex intensity (V) multiplied into the colour then rounded (ModelNet variant).
+ * scratch: caller-provided H*W uint64 z-buffer + V*3 floats (cam u,v,z). */
+void dim_oracle_render(const float *verts, const float *uvs, const int32_t *faces, int V, int F,
+                       const uint8_t *tex, int Ht, int Wt, const float *R, const float *t, const float *K,
+                       int H, int W, float znear, float zfar, int tex_bilinear, float *bgr, float *depth) {
+  uint64_t *zbuf = (uint64_t *)malloc((size_t)H * W * sizeof(uint64_t));
+  float *scr = (float *)malloc((size_t)V * 3 * sizeof(float));
+  memset(zbuf, 0xFF, (size_t)H * W * sizeof(uint64_t));
+  const float fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+  for (int i = 0; i < V; ++i) {
+    const float *p = verts + 3 * i;
+    float xc = fmaf(R[0], p[0], fmaf(R[1], p[1], fmaf(R[2], p[2], t[0])));
+    float yc = fmaf(R[3], p[0], fmaf(R[4], p[1], fmaf(R[5], p[2], t[1])));
+    float zc = fmaf(R[6], p[0], fmaf(R[7], p[1], fmaf(R[8], p[2], t[2])));
+    scr[3 * i + 0] = fmaf(fx, xc / zc, cx);
+    scr[3 * i + 1] = fmaf(fy, yc / zc, cy);
+    scr[3 * i + 2] = zc;
+  }
+  for (int f = 0; f < F; ++f) {
+    int32_t X[3], Y[3];
+    float iz[3];
+    int ok = 1;
+    for (int k = 0; k < 3; ++k) {
+      const float *s = scr + 3 * faces[3 * f + k];
+      if (!(s[2] > 1e-6f) || !(fabsf(s[0]) < COORD_LIM) || !(fabsf(s[1]) < COORD_LIM)) { ok = 0; break; }
+      X[k] = snap(s[0]); Y[k] = snap(s[1]); iz[k] = 1.0f / s[2];
+    }
+    if (!ok) continue;
+    edges_t e;
+    if (!setup_edges(X, Y, &e)) continue;
+    int32_t minX = X[0] < X[1] ? X[0] : X[1]; if (X[2] < minX) minX = X[2];
+    int32_t maxX = X[0] > X[1] ? X[0] : X[1]; if (X[2] > maxX) maxX = X[2];
+    int32_t minY = Y[0] < Y[1] ? Y[0] : Y[1]; if (Y[2] < minY) minY = Y[2];
+    int32_t maxY = Y[0] > Y[1] ? Y[0] : Y[1]; if (Y[2] > maxY) maxY = Y[2];
+    int x0 = (minX + 255) >> 8, x1 = maxX >> 8, y0 = (minY + 255) >> 8, y1 = maxY >> 8; /* arithmetic shifts = floor */
+    if (x0 < 0) x0 = 0; if (y0 < 0) y0 = 0; if (x1 > W - 1) x1 = W - 1; if (y1 > H - 1) y1 = H - 1;
+    const float inv_area = 1.0f / (float)e.area;
+    for (int y = y0; y <= y1; ++y)
+      for (int x = x0; x <= x1; ++x) {
+        int64_t E[3];
+        if (!inside(&e, (int64_t)x * 256, (int64_t)y * 256, E)) continue;
+        float b0 = (float)E[0] * inv_area, b1 = (float)E[1] * inv_area, b2 = (float)E[2] * inv_area;
+        float invz = fmaf(b2, iz[2], fmaf(b1, iz[1], b0 * iz[0]));
+        float z = 1.0f / invz;
+        if (!(z >= znear && z <= zfar)) continue;
+        uint64_t key = ((uint64_t)f2u(z) << 32) | (uint32_t)f;
+        uint64_t *zp = zbuf + (size_t)y * W + x;
+        if (key < *zp) *zp = key;
+      }
+  }
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      uint64_t key = zbuf[(size_t)y * W + x];
+      float *o = bgr + ((size_t)y * W + x) * 3;
+      if (key == UINT64_MAX) { o[0] = o[1] = o[2] = 0.f; depth[(size_t)y * W + x] = 0.f; continue; }
+      int f = (int)(uint32_t)(key & 0xFFFFFFFFu);
+      float z = u2f((uint32_t)(key >> 32));
+      int32_t X[3], Y[3];
+      float iz[3], tu[3], tv[3];
+      for (int k = 0; k < 3; ++k) {
+        int vi = faces[3 * f + k];
+        const float *s = scr + 3 * vi;
+        X[k] = snap(s[0]); Y[k] = snap(s[1]); iz[k] = 1.0f / s[2];
+        tu[k] = uvs[2 * vi]; tv[k] = uvs[2 * vi + 1];
+      }
+      edges_t e; int64_t E[3];
+      setup_edges(X, Y, &e);
+      inside(&e, (int64_t)x * 256, (int64_t)y * 256, E);
+      const float inv_area = 1.0f / (float)e.area;
+      float b0 = (float)E[0] * inv_area, b1 = (float)E[1] * inv_area, b2 = (float)E[2] * inv_area;
+      float w0 = b0 * iz[0], w1 = b1 * iz[1], w2 = b2 * iz[2];
+      float u = fmaf(w2, tu[2], fmaf(w1, tu[1], w0 * tu[0])) * z;
+      float v = fmaf(w2, tv[2], fmaf(w1, tv[1], w0 * tv[0])) * z;
+      float rgb[3];
+      if (!tex_bilinear) {
+        int tx = clampi((int)floorf(u * (float)Wt), 0, Wt - 1);
+        int ty = clampi((int)floorf(v * (float)Ht), 0, Ht - 1);
+        const uint8_t *px = tex + ((size_t)(Ht - 1 - ty) * Wt + tx) * 3;
+        rgb[0] = px[0]; rgb[1] = px[1]; rgb[2] = px[2];
+      } else {
+        float xf = u * (float)Wt - 0.5f, yf = v * (float)Ht - 0.5f;
+        float x0f = floorf(xf), y0f = floorf(yf);
+        float ax = xf - x0f, ay = yf - y0f;
+        int xa = clampi((int)x0f, 0, Wt - 1), xb = clampi((int)x0f + 1, 0, Wt - 1);
+        int ya = clampi((int)y0f, 0, Ht - 1), yb = clampi((int)y0f + 1, 0, Ht - 1);
+        const uint8_t *p00 = tex + ((size_t)(Ht - 1 - ya) * Wt + xa) * 3, *p01 = tex + ((size_t)(Ht - 1 - ya) * Wt + xb) * 3;
+        const uint8_t *p10 = tex + ((size_t)(Ht - 1 - yb) * Wt + xa) * 3, *p11 = tex + ((size_t)(Ht - 1 - yb) * Wt + xb) * 3;
+        for (int c = 0; c < 3; ++c) {
+          float top = fmaf(ax, (float)p01[c] - (float)p00[c], (float)p00[c]);
+          float bot = fmaf(ax, (float)p11[c] - (float)p10[c], (float)p10[c]);
+          rgb[c] = floorf(fmaf(ay, bot - top, top)); /* tester.py:244 astype('uint8') truncation */
+        }
+      }
+      o[0] = rgb[2]; o[1] = rgb[1]; o[2] = rgb[0];
+      depth[(size_t)y * W + x] = z;
+    }
+  free(zbuf);
+  free(scr);
+}
+
+/* gpu_flow_kernel.cu:32-69 restated on the CPU (float arithmetic, same operation order). */
+void dim_oracle_flow(const float *depth_src, const float *depth_tgt, const float *KT, const float *Kinv,
+                     int B, int H, int W, float *flow, float *valid) {
+  for (int b = 0; b < B; ++b)
+    for (int h = 0; h < H; ++h)
+      for (int w = 0; w < W; ++w) {
+        size_t index = ((size_t)b * H + h) * W + w;
+        const float *kt = KT + 12 * b;
+        float d = depth_src[index];
+        float x = (w * Kinv[0] + h * Kinv[1] + Kinv[2]) * d;
+        float y = (w * Kinv[3] + h * Kinv[4] + Kinv[5]) * d;
+        float z = d;
+        float fh = 0.f, fw = 0.f, va = 0.f;
+        if (d > 1E-3) {
+          float xp = x * kt[0] + y * kt[1] + z * kt[2] + kt[3];
+          float yp = x * kt[4] + y * kt[5] + z * kt[6] + kt[7];
+          float zp = (float)((double)(x * kt[8] + y * kt[9] + z * kt[10] + kt[11]) + 1E-15);
+          float wp = xp / zp, hp = yp / zp;
+          int wi = (int)round((double)wp), hi = (int)round((double)hp);
+          if (wp >= 0 && wp <= W - 1 && hp >= 0 && hp <= H - 1) {
+            float dt = depth_tgt[((size_t)b * H + hi) * W + wi];
+            if (fabsf(zp - dt) < 3E-3) { fh = hp - h; fw = wp - w; va = 1.f; }
+          }
+        }
+        flow[(((size_t)b * 2 + 0) * H + h) * W + w] = fh;
+        flow[(((size_t)b * 2 + 1) * H + h) * W + w] = fw;
+        valid[index] = va;
+      }
+}

@@ -1,0 +1,59 @@
+"""Test-time refinement loop, CPU restatement (oracle; test-only).
+
+Restates /root/reference/deepim/core/tester.py:476-598 (pred_eval inner loop) with
+lib/pair_matching/data_pair.py:75-138 (update_data_batch) per pair, using the other oracle
+pieces: zoom ops + FlowNet forward (oracle.flownet.forward_test), RT_transform (oracle.se3),
+the software rasteriser (oracle.native.render) in place of Render_Py.
+"""
+import numpy as np
+
+from . import flownet, native, se3 as ose3
+
+
+def image_transform(im_bgr, pixel_means):
+    """lib/utils/image.py:709-720 transform()."""
+    out = np.zeros((1, 3, im_bgr.shape[0], im_bgr.shape[1]))
+    for i in range(3):
+        out[0, i] = im_bgr[:, :, 2 - i] - pixel_means[2 - i]
+    return out
+
+
+def update_mask_observed_box_rendered(mask_rendered):
+    """data_pair.py:103-114 (UPDATE_MASK == 'box_rendered').  Reference raises on an empty mask (np.min of empty)."""
+    m = np.zeros(mask_rendered.shape)
+    nz_x = np.nonzero(np.max(mask_rendered, 0))[0]
+    nz_y = np.nonzero(np.max(mask_rendered, 1))[0]
+    if len(nz_x) == 0 or len(nz_y) == 0:
+        raise ValueError("empty rendered mask (reference: np.min of an empty array)")
+    m[np.min(nz_y):np.max(nz_y), np.min(nz_x):np.max(nz_x)] = 1.0
+    return m
+
+
+def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord="CAMERA", test_iter=4, znear=0.25, zfar=6.0,
+                tex_bilinear=False, fast_test=True):
+    """One (observed, rendered) pair, batch 1 like the reference.
+    blobs: image_observed (1,3,H,W), image_rendered, mask_observed (1,1,H,W), mask_rendered, src_pose (1,3,4).
+    mesh: (verts, uvs, faces, tex).  Returns list of poses (test_iter x (3,4) float64) and the per-iteration se3."""
+    verts, uvs, faces, tex = mesh
+    batch = {k: np.array(v, dtype=np.float32) for k, v in blobs.items()}
+    pose_rendered = np.array(batch["src_pose"][0], dtype=np.float64)
+    out = flownet.forward_test(params, batch, K, pixel_means, fast_test=fast_test)
+    poses, se3s = [], []
+    for it in range(test_iter):
+        se3 = np.squeeze(out["se3"]).astype("float32")
+        se3s.append(se3)
+        pose_new = ose3.RT_transform(pose_rendered, se3[:-3], se3[-3:], T_means, T_stds, rot_coord)
+        poses.append(pose_new)
+        if it < test_iter - 1:
+            bgr, depth = native.render(verts, uvs, faces, tex, pose_new[:3, :3], pose_new[:, 3], K, znear=znear, zfar=zfar,
+                                       tex_bilinear=tex_bilinear)
+            image_refined = bgr.astype("uint8")  # tester.py:246
+            mask_r = np.zeros(depth.shape)
+            mask_r[depth > 0.2] = 1  # tester.py:575-577
+            batch["image_rendered"] = image_transform(image_refined.astype(np.float64), pixel_means).astype(np.float32)
+            batch["mask_rendered"] = mask_r[np.newaxis, np.newaxis].astype(np.float32)
+            batch["mask_observed"] = update_mask_observed_box_rendered(mask_r)[np.newaxis, np.newaxis].astype(np.float32)
+            batch["src_pose"] = pose_new[np.newaxis].astype(np.float32)  # nd.array -> float32
+            pose_rendered = pose_new
+            out = flownet.forward_test(params, batch, K, pixel_means, fast_test=fast_test)
+    return poses, se3s

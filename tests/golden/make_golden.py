@@ -1,0 +1,163 @@
+"""Generate golden vectors by IMPORTING the reference's own numpy modules (build container only).
+
+Run:  python tests/golden/make_golden.py        (needs /root/reference; never runs on the GPU box)
+Writes small .npz fixtures next to this file.  The reference's source never leaves the container;
+only inputs and expected outputs are stored.
+
+Modules imported from /root/reference:
+  lib/pair_matching/RT_transform.py  (numpy-2 alias shim for its module-level np.float uses, :246-247)
+  lib/pair_matching/flow.py (calc_flow), lib/utils/pose_error.py (add, adi),
+  lib/utils/get_min_rect.py, lib/utils/projection.py (se3_mul, se3_inverse)
+"""
+import os
+import sys
+
+import numpy as np
+
+np.float = float  # noqa: shim for RT_transform.py:246-247 under numpy 2
+np.int = int
+np.maximum_sctype = lambda t: np.longdouble
+sys.path.insert(0, "/root/reference")
+
+from lib.pair_matching import RT_transform as RT  # noqa: E402
+from lib.pair_matching.flow import calc_flow  # noqa: E402
+from lib.utils.pose_error import add, adi  # noqa: E402
+from lib.utils.get_min_rect import get_min_rect  # noqa: E402
+from lib.utils.projection import se3_inverse, se3_mul  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+K = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1]])
+
+
+def rand_pose(rng):
+    q = rng.normal(size=4)
+    R = RT.quat2mat(q / np.linalg.norm(q))
+    t = np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.15, 0.15), rng.uniform(0.5, 1.3)])
+    return np.concatenate([R, t[:, None]], axis=1)
+
+
+def se3_vectors():
+    rng = np.random.default_rng(2333)
+    n = 64
+    out = {k: [] for k in ("pose_src", "pose_tgt", "quat_raw", "trans_delta")}
+    coords = ["MODEL", "CAMERA", "CAMERA_NEW", "NAIVE"]
+    res = {c: {"compose": [], "delta_q": [], "delta_t": [], "delta_R": []} for c in coords}
+    T_means = np.array([0.0, 0.0, 0.0])
+    T_stds = np.array([1.0, 1.0, 1.0])
+    T_means2 = np.array([0.01, -0.02, 0.03])
+    T_stds2 = np.array([0.5, 2.0, 1.5])
+    res2 = {"compose": [], "delta_q": [], "delta_t": []}
+    dist = []
+    for i in range(n):
+        ps, pt = rand_pose(rng), rand_pose(rng)
+        q = rng.normal(size=4) * rng.uniform(0.2, 3.0)  # un-normalised, as the test graph emits it
+        td = rng.normal(size=3) * np.array([0.05, 0.05, 0.2])
+        out["pose_src"].append(ps); out["pose_tgt"].append(pt); out["quat_raw"].append(q); out["trans_delta"].append(td)
+        for c in coords:
+            res[c]["compose"].append(RT.RT_transform(ps, q, td, T_means, T_stds, c))
+            r, t = RT.calc_RT_delta(ps, pt, T_means, T_stds, c, "QUAT")
+            res[c]["delta_q"].append(r); res[c]["delta_t"].append(t)
+            rm, _ = RT.calc_RT_delta(ps, pt, T_means, T_stds, c, "MATRIX")
+            res[c]["delta_R"].append(rm)
+        res2["compose"].append(RT.RT_transform(ps, q, td, T_means2, T_stds2, "CAMERA"))
+        r, t = RT.calc_RT_delta(ps, pt, T_means2, T_stds2, "CAMERA", "QUAT")
+        res2["delta_q"].append(r); res2["delta_t"].append(t)
+        dist.append(RT.calc_rt_dist_m(ps, pt))
+    save = {k: np.array(v) for k, v in out.items()}
+    for c in coords:
+        for k, v in res[c].items():
+            save["{}_{}".format(c, k)] = np.array(v)
+    for k, v in res2.items():
+        save["ms_CAMERA_{}".format(k)] = np.array(v)
+    save["T_means2"], save["T_stds2"] = T_means2, T_stds2
+    save["rt_dist"] = np.array(dist)
+    # analytic constants from the docstrings (RT_transform.py:413-418, :545-547)
+    save["quat2mat_id"] = RT.quat2mat([1, 0, 0, 0])
+    save["quat2mat_x180"] = RT.quat2mat([0, 1, 0, 0])
+    save["euler2quat_123_ryxz"] = RT.euler2quat(1, 2, 3, "ryxz")
+    # mat2quat on exact and slightly noisy rotations (sign rule w >= 0)
+    Rs = np.array([rand_pose(rng)[:, :3] for _ in range(32)])
+    save["m2q_R"] = Rs
+    save["m2q_q"] = np.array([RT.mat2quat(R) for R in Rs])
+    # se3_mul / se3_inverse (float32 outputs)
+    save["se3_mul"] = np.array([se3_mul(a, b) for a, b in zip(save["pose_src"], save["pose_tgt"])])
+    save["se3_inv"] = np.array([se3_inverse(a) for a in save["pose_src"]])
+    np.savez_compressed(os.path.join(HERE, "se3_golden.npz"), **save)
+
+
+def synth_depth(rng, pose, H=120, W=160, Ks=None):
+    """depth of a sphere of radius .08 m at pose translation (analytic ray cast), small image for fixture size"""
+    c = pose[:, 3]
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    d = np.stack([(xs - Ks[0, 2]) / Ks[0, 0], (ys - Ks[1, 2]) / Ks[1, 1], np.ones_like(xs, dtype=np.float64)], axis=-1)
+    a = (d * d).sum(-1)
+    b = -2 * (d @ c)
+    cc = c @ c - 0.08 ** 2
+    disc = b * b - 4 * a * cc
+    t = np.where(disc > 0, (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a), 0.0)
+    return (t * (disc > 0)).astype(np.float32)  # z-depth since d_z = 1
+
+
+def flow_vectors():
+    rng = np.random.default_rng(7)
+    H, W = 120, 160
+    Ks = K.copy()
+    Ks[:2] *= 0.25
+    save = {"K": Ks}
+    ds, dt, ps, pt, fl, vis = [], [], [], [], [], []
+    for i in range(6):
+        p0 = rand_pose(rng)
+        p0[:, 3] = [rng.uniform(-0.05, 0.05), rng.uniform(-0.04, 0.04), rng.uniform(0.5, 0.9)]
+        p1 = p0.copy()
+        dq = np.array([1.0, 0, 0, 0]) + rng.normal(size=4) * 0.05
+        p1[:, :3] = RT.quat2mat(dq / np.linalg.norm(dq)) @ p0[:, :3]
+        p1[:, 3] += rng.normal(size=3) * np.array([0.01, 0.01, 0.03])
+        d0, d1 = synth_depth(rng, p0, H, W, Ks), synth_depth(rng, p1, H, W, Ks)
+        f, v, _ = calc_flow(d0, p0, p1, Ks, d1, thresh=3e-3, standard_rep=False)
+        ds.append(d0); dt.append(d1); ps.append(p0); pt.append(p1); fl.append(f); vis.append(v)
+    save.update(depth_src=np.array(ds), depth_tgt=np.array(dt), pose_src=np.array(ps), pose_tgt=np.array(pt),
+                flow=np.array(fl, dtype=np.float32), visible=np.array(vis, dtype=np.float32))
+    np.savez_compressed(os.path.join(HERE, "flow_golden.npz"), **save)
+
+
+def pose_error_vectors():
+    rng = np.random.default_rng(11)
+    pts = rng.normal(size=(500, 3)) * 0.05
+    pe, pg, a, s = [], [], [], []
+    for i in range(16):
+        g = rand_pose(rng)
+        e = g.copy()
+        dq = np.array([1.0, 0, 0, 0]) + rng.normal(size=4) * 0.03
+        e[:, :3] = RT.quat2mat(dq / np.linalg.norm(dq)) @ g[:, :3]
+        e[:, 3] += rng.normal(size=3) * 0.01
+        pe.append(e); pg.append(g)
+        a.append(add(e[:, :3], e[:, 3], g[:, :3], g[:, 3], pts))
+        s.append(adi(e[:, :3], e[:, 3], g[:, :3], g[:, 3], pts))
+    np.savez_compressed(os.path.join(HERE, "pose_error_golden.npz"), pts=pts, pose_est=np.array(pe), pose_gt=np.array(pg),
+                        add=np.array(a), adi=np.array(s))
+
+
+def min_rect_vectors():
+    rng = np.random.default_rng(5)
+    masks, rects = [], []
+    for i in range(12):
+        m = np.zeros((48, 64), dtype=np.float32)
+        y0, x0 = rng.integers(0, 40), rng.integers(0, 56)
+        h, w = rng.integers(1, 48 - y0 + 1), rng.integers(1, 64 - x0 + 1)
+        blob = (rng.uniform(size=(h, w)) > 0.6).astype(np.float32)
+        if blob.sum() == 0:
+            blob[0, 0] = 1
+        m[y0:y0 + h, x0:x0 + w] = blob
+        masks.append(m)
+        rects.append(get_min_rect(m))
+    np.savez_compressed(os.path.join(HERE, "min_rect_golden.npz"), masks=np.array(masks), rects=np.array(rects))
+
+
+if __name__ == "__main__":
+    se3_vectors()
+    flow_vectors()
+    pose_error_vectors()
+    min_rect_vectors()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))

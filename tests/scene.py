@@ -1,0 +1,56 @@
+"""Seeded synthetic scene shared by CPU and GPU tests (inputs only; rendering by the CPU oracle)."""
+import numpy as np
+
+from lib.utils import synthetic as syn
+from oracle import native
+
+
+def make_scene(B=2, seed=2333, subdiv=3, n_models=1):
+    """-> dict with models, K, blobs (numpy, reference blob names/shapes), pose_gt."""
+    models = syn.make_models(seed=seed, n_models=n_models, subdiv=subdiv)
+    cls, gt, init = syn.sample_pairs(seed + 1, B, n_classes=n_models)
+    rng = np.random.default_rng(seed + 2)
+    K = syn.LINEMOD_K
+    H, W = 480, 640
+    io, ir, mo, mr = [], [], [], []
+    for b in range(B):
+        v, t, f, tex = models[cls[b]]
+        bgr_gt, d_gt = native.render(v, t, f, tex, gt[b][:, :3], gt[b][:, 3], K)
+        obs = syn.compose_observed(bgr_gt, d_gt, rng)
+        bgr_r, d_r = native.render(v, t, f, tex, init[b][:, :3], init[b][:, 3], K)
+        io.append(syn.bgr_to_blob(obs))
+        ir.append(syn.bgr_to_blob(bgr_r.astype(np.uint8)))
+        m_r = (d_r > 0.2).astype(np.float32)
+        mr.append(m_r[None, None])
+        mo.append(syn.box_from_mask(m_r)[None, None])  # TEST.INIT_MASK == 'box_rendered' (image.py:437-460)
+    blobs = {
+        "image_observed": np.concatenate(io).astype(np.float32),
+        "image_rendered": np.concatenate(ir).astype(np.float32),
+        "mask_observed": np.concatenate(mo).astype(np.float32),
+        "mask_rendered": np.concatenate(mr).astype(np.float32),
+        "src_pose": init.astype(np.float32),
+        "class_index": cls,
+    }
+    return {"models": models, "K": K, "blobs": blobs, "pose_gt": gt, "pose_init": init}
+
+
+def make_test_config(test_iter=4):
+    """the shipped ape test config, built from defaults + the YAML-level overrides (no file I/O)."""
+    from deepim.config.config import config, reset_config
+
+    reset_config()
+    config.network.PIXEL_MEANS = np.array([123.68, 116.779, 103.939])
+    config.network.INPUT_MASK = True
+    config.network.PRED_MASK = True
+    config.network.PRED_FLOW = True
+    config.network.ROT_COORD = "CAMERA"
+    config.dataset.NORMALIZE_FLOW = 20.0
+    config.dataset.INTRINSIC_MATRIX = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1]], dtype=np.float32)
+    config.dataset.trans_means = np.zeros(3, dtype=np.float32)
+    config.dataset.trans_stds = np.ones(3, dtype=np.float32)
+    config.dataset.class_name = ["ape"]
+    config.TEST.test_iter = test_iter
+    config.TEST.FAST_TEST = True
+    config.TEST.UPDATE_MASK = "box_rendered"
+    config.TEST.INIT_MASK = "box_rendered"
+    return config

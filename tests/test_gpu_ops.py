@@ -1,0 +1,385 @@
+"""GPU parity: every C-ABI entry point vs the CPU oracle / the reference-generated golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import native, se3 as ose3, transform3d as ot3d, zoom as ozoom  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def cu(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from lib.hip import ops as _ops
+
+    return _ops
+
+
+# ------------------------------------------------------------------ SE(3): against the REFERENCE's outputs
+@pytest.mark.parametrize("coord", ["MODEL", "CAMERA", "CAMERA_NEW", "NAIVE"])
+def test_se3_compose_and_delta_vs_reference_golden(ops, golden_dir, coord):
+    g = np.load(os.path.join(golden_dir, "se3_golden.npz"))
+    ps, pt = cu(g["pose_src"]), cu(g["pose_tgt"])
+    se3 = cu(np.concatenate([g["quat_raw"], g["trans_delta"]], axis=1))
+    z3, o3 = np.zeros(3), np.ones(3)
+    out64 = torch.empty(ps.shape, dtype=torch.float64, device=DEV)
+    out = ops.se3_compose(ps, se3, coord, z3, o3, out_f64=out64)
+    # inputs were rounded to f32 on upload: compare with the oracle on the same rounded inputs at 1e-12 ...
+    for i in range(ps.shape[0]):
+        ref = ose3.RT_transform(g["pose_src"][i].astype(np.float32).astype(np.float64), se3[i, :4].cpu().numpy().astype(np.float64),
+                                se3[i, 4:].cpu().numpy().astype(np.float64), z3, o3, coord)
+        np.testing.assert_allclose(out64[i].cpu().numpy(), ref, atol=1e-6 if coord == "NAIVE" else 1e-12)
+    # ... and with the reference's own float64 result at f32 resolution
+    np.testing.assert_allclose(out.cpu().numpy(), g[coord + "_compose"], atol=2e-6)
+    rot, trans = ops.se3_delta(ps, pt, coord, z3, o3)
+    np.testing.assert_allclose(rot.cpu().numpy(), g[coord + "_delta_q"], atol=2e-6)
+    np.testing.assert_allclose(trans.cpu().numpy(), g[coord + "_delta_t"], atol=2e-6)
+    assert (rot[:, 0] >= 0).all()
+
+
+def test_se3_means_stds(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "se3_golden.npz"))
+    se3 = cu(np.concatenate([g["quat_raw"], g["trans_delta"]], axis=1))
+    out = ops.se3_compose(cu(g["pose_src"]), se3, "CAMERA", g["T_means2"], g["T_stds2"])
+    np.testing.assert_allclose(out.cpu().numpy(), g["ms_CAMERA_compose"], atol=2e-6)
+    rot, trans = ops.se3_delta(cu(g["pose_src"]), cu(g["pose_tgt"]), "CAMERA", g["T_means2"], g["T_stds2"])
+    np.testing.assert_allclose(trans.cpu().numpy(), g["ms_CAMERA_delta_t"], atol=2e-6)
+
+
+def test_zoom_trans_roundtrip(ops):
+    """reference check zoom_trans.py:126-168: zoom = divide by wx, inverse round-trips."""
+    rng = np.random.RandomState(0)
+    zf = rng.rand(8, 4).astype(np.float32) + 0.2
+    zf[:, 1] = zf[:, 0]
+    t = rng.randn(8, 3).astype(np.float32)
+    z = ops.zoom_trans(cu(zf), cu(t), 1)
+    np.testing.assert_allclose(z.cpu().numpy(), ozoom.zoom_trans(zf, t, False), rtol=1e-6)
+    back = ops.zoom_trans(cu(zf), z, 2)
+    np.testing.assert_allclose(back.cpu().numpy(), t, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(ops.zoom_trans(cu(zf), cu(t), 2).cpu().numpy(), ozoom.zoom_trans(zf, t, True), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ Transform3D
+@pytest.mark.parametrize("coord", ["MODEL", "CAMERA", "CAMERA_NEW", "NAIVE"])
+def test_transform3d(ops, coord):
+    from test_oracle_transform3d import _inputs
+
+    pts, rot, trans, pose_src = _inputs()
+    z3, o3 = np.zeros(3, np.float32), np.ones(3, np.float32)
+    out = ops.transform3d_fwd(cu(pts), cu(rot), cu(trans), cu(pose_src), coord, z3, o3)
+    ref = ot3d.forward(pts, rot, trans, pose_src, z3, o3, coord)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-5)
+    # reference self-check (transform3d.py:473-493): |fwd - RT_transform| < 1e-4
+    for b in range(pts.shape[0]):
+        pose = ose3.RT_transform(pose_src[b], rot[b], trans[b], z3, o3, coord)
+        assert np.abs(out[b].cpu().numpy() - (pose[:, :3] @ pts[b] + pose[:, 3:4])).max() < 1e-4
+    g = np.random.RandomState(3).randn(*pts.shape).astype(np.float32) / pts.shape[2]
+    d_rot, d_trans = ops.transform3d_bwd(cu(g), cu(pts), cu(rot), cu(trans), cu(pose_src), coord, z3, o3)
+    r_rot, r_trans = ot3d.backward(g, pts, rot, trans, pose_src, z3, o3, coord)
+    np.testing.assert_allclose(d_trans.cpu().numpy(), r_trans, atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(d_rot.cpu().numpy(), r_rot, atol=2e-5, rtol=1e-4)
+
+
+def test_transform3d_bad_quaternion_branches(ops):
+    """quat2mat_forward returns identity when |q|^2 is off by > 1e-2; backward returns 0 when off by > 1e-4."""
+    from test_oracle_transform3d import _inputs
+
+    pts, rot, trans, pose_src = _inputs()
+    rot = rot * np.float32(1.2)
+    z3, o3 = np.zeros(3, np.float32), np.ones(3, np.float32)
+    out = ops.transform3d_fwd(cu(pts), cu(rot), cu(trans), cu(pose_src), "CAMERA", z3, o3)
+    np.testing.assert_allclose(out.cpu().numpy(), ot3d.forward(pts, rot, trans, pose_src, z3, o3, "CAMERA"), atol=1e-5)
+    g = np.ones_like(pts)
+    d_rot, _ = ops.transform3d_bwd(cu(g), cu(pts), cu(rot), cu(trans), cu(pose_src), "CAMERA", z3, o3)
+    assert (d_rot == 0).all()
+
+
+# ------------------------------------------------------------------ depth -> flow
+def test_depth_to_flow_vs_oracle_and_reference(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "flow_golden.npz"))
+    K = g["K"]
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    n = len(g["depth_src"])
+    KT = np.zeros((n, 3, 4), dtype=np.float32)
+    for i in range(n):
+        R, t = ose3.calc_se3(g["pose_src"][i], g["pose_tgt"][i])
+        KT[i] = np.dot(K, np.concatenate([R, t.reshape(3, 1)], axis=1)).astype(np.float32)
+    ds, dt = g["depth_src"][:, None], g["depth_tgt"][:, None]
+    flow, valid = ops.depth_to_flow(cu(ds), cu(dt), cu(KT), Kinv)
+    rflow, rvalid = native.gpu_flow(ds, dt, KT, Kinv)
+    flow, valid = flow.cpu().numpy(), valid.cpu().numpy()
+    # FMA contraction may move a value by an ulp across a predicate: allow a handful of flips
+    flips = (valid != rvalid).sum()
+    assert flips <= 20, flips
+    same = valid == rvalid
+    np.testing.assert_allclose(flow[np.repeat(same, 2, axis=1)], rflow[np.repeat(same, 2, axis=1)], atol=1e-3)
+    # against the reference's numpy calc_flow where both say visible
+    for i in range(n):
+        both = (valid[i, 0] == 1) & (g["visible"][i] == 1)
+        f = np.stack([flow[i, 0], flow[i, 1]], axis=-1)
+        np.testing.assert_allclose(f[both], g["flow"][i][both], atol=2e-3)
+        assert both.sum() > 100
+
+
+def test_depth_to_flow_empty_and_zero_depth(ops):
+    z = torch.zeros((2, 1, 48, 64), device=DEV)
+    KT = cu(np.tile(np.eye(3, 4, dtype=np.float32), (2, 1, 1)))
+    flow, valid = ops.depth_to_flow(z, z, KT, np.eye(3, dtype=np.float32))
+    assert flow.abs().sum() == 0 and valid.sum() == 0
+    flow, valid = ops.depth_to_flow(z[:0], z[:0], KT[:0], np.eye(3, dtype=np.float32))
+    assert flow.shape[0] == 0
+
+
+# ------------------------------------------------------------------ zoom ops
+def _rand_masks(rng, B, H, W, empty_rendered=()):
+    mo = np.zeros((B, 1, H, W), np.float32)
+    mr = np.zeros((B, 1, H, W), np.float32)
+    pose = np.zeros((B, 3, 4), np.float32)
+    for b in range(B):
+        y0, x0 = rng.randint(60, 200), rng.randint(80, 300)
+        h, w = rng.randint(40, 200), rng.randint(40, 250)
+        mo[b, 0, y0:y0 + h, x0:x0 + w] = 1
+        if b not in empty_rendered:
+            yy, xx = np.mgrid[0:H, 0:W]
+            cy, cx = y0 + h / 2 + rng.randint(-15, 15), x0 + w / 2 + rng.randint(-15, 15)
+            mr[b, 0] = (((yy - cy) / (h / 2.2)) ** 2 + ((xx - cx) / (w / 2.2)) ** 2 < 1) * rng.uniform(0.3, 1.5)  # depth-like values
+        z = rng.uniform(0.5, 1.2)
+        pose[b] = np.concatenate([np.eye(3), [[(x0 + w / 2 - 325.26) * z / 572.4], [(y0 + h / 2 - 242.05) * z / 573.6], [z]]], axis=1)
+    return mo, mr, pose
+
+
+def test_zoom_mask_and_image_vs_oracle(ops):
+    from lib.utils.synthetic import LINEMOD_K, PIXEL_MEANS
+
+    rng = np.random.RandomState(5)
+    B, H, W = 4, 480, 640
+    mo, mr, pose = _rand_masks(rng, B, H, W, empty_rendered=(3,))
+    io = (rng.randint(0, 256, size=(B, 3, H, W)) - PIXEL_MEANS[::-1].reshape(1, 3, 1, 1)).astype(np.float32)
+    ir = (rng.randint(0, 256, size=(B, 3, H, W)) - PIXEL_MEANS[::-1].reshape(1, 3, 1, 1)).astype(np.float32)
+    zmo, zmg, zmr, zf = ozoom.zoom_mask(mo, mo, mr, pose, LINEMOD_K, H, W)
+    zio, zir = ozoom.zoom_image_with_factor(zf, io, ir, PIXEL_MEANS, H, W)
+    bo = ops.mask_bbox(cu(mo), 0.3)
+    br = ops.mask_bbox(cu(mr), 0.2)
+    assert br[3].tolist() == [W, -1, H, -1]  # empty rendered mask
+    status = torch.zeros(B, dtype=torch.int32, device=DEV)
+    gzf = ops.zoom_factor(bo, br, cu(pose), LINEMOD_K, H, W, status=status)
+    np.testing.assert_allclose(gzf.cpu().numpy(), zf, rtol=2e-6, atol=2e-6)
+    assert status.tolist() == [0, 0, 0, 2]
+    # use the oracle's factor so sampling differences are not confounded with factor rounding
+    zft = cu(zf)
+    pm = PIXEL_MEANS[::-1].copy()
+    nchw = tuple(torch.empty_like(t) for t in (cu(io), cu(ir), cu(mo), cu(mr)))
+    X = ops.zoom_net_input(cu(io), cu(ir), cu(mo), cu(mr), zft, pm, nchw_out=nchw)
+    np.testing.assert_allclose(nchw[0].cpu().numpy(), zio, atol=2e-3)
+    np.testing.assert_allclose(nchw[1].cpu().numpy(), zir, atol=2e-3)
+    assert (nchw[2].cpu().numpy() != zmo).sum() <= 8
+    assert (nchw[3].cpu().numpy() != zmr).sum() <= 8
+    Xr = np.concatenate([zio / 255.0, zir / 255.0, zmo, zmr], axis=1).transpose(0, 2, 3, 1)
+    Xg = X.cpu().numpy()
+    np.testing.assert_allclose(Xg[..., :6], Xr[..., :6], atol=1e-5)
+    assert (Xg[..., 6:] != Xr[..., 6:]).sum() <= 16
+    # generic plane sampler: ZoomMaskWithFactor fwd / inverse, ZoomDepth, ZoomFlow fwd / inverse
+    m = ops.zoom_planes(cu(mr), zft, pre=1, post=1)
+    assert (m.cpu().numpy() != ozoom.zoom_mask_with_factor(zf, mr, False)).sum() <= 8
+    mi = ops.zoom_planes(cu(zmr), zft, inverse=True, pre=1, post=1)
+    assert (mi.cpu().numpy() != ozoom.zoom_mask_with_factor(zf, zmr, True)).sum() <= 8
+    d = ops.zoom_planes(cu(mr), zft)
+    np.testing.assert_allclose(d.cpu().numpy(), ozoom.zoom_depth(zf, mr, mr)[0], atol=1e-5)
+    flow = rng.randn(B, 2, H, W).astype(np.float32) * 5
+    fw = (rng.rand(B, 2, H, W) > 0.5).astype(np.float32)
+    rf, rw = ozoom.zoom_flow(zf, flow, fw, b_inv_zoom=False)
+    gf = ops.zoom_planes(cu(flow), zft, scale_mode=1)
+    gw = ops.zoom_planes(cu(fw), zft, post=2)
+    np.testing.assert_allclose(gf.cpu().numpy(), rf, atol=1e-3, rtol=1e-5)
+    assert (gw.cpu().numpy() != rw).sum() <= 16
+    gfi = ops.zoom_planes(cu(rf), zft, inverse=True, scale_mode=2)
+    np.testing.assert_allclose(gfi.cpu().numpy(), ozoom.zoom_flow(zf, rf, b_inv_zoom=True), atol=1e-3, rtol=1e-5)
+
+
+def test_zoom_image_mode_bbox(ops):
+    """ZoomImage validity rule (zoom_image.py:31-37): sum_c(image + mean) > 0.01."""
+    from lib.utils.synthetic import LINEMOD_K, PIXEL_MEANS
+
+    rng = np.random.RandomState(9)
+    B, H, W = 2, 480, 640
+    pm = PIXEL_MEANS[::-1].reshape(1, 3, 1, 1)
+    raw_o = np.zeros((B, 3, H, W), np.float32)
+    raw_r = np.zeros((B, 3, H, W), np.float32)
+    raw_o[:, :, 100:300, 200:420] = rng.randint(1, 255, size=(B, 3, 200, 220))
+    raw_r[:, :, 120:310, 180:400] = rng.randint(1, 255, size=(B, 3, 190, 220))
+    io, ir = (raw_o - pm).astype(np.float32), (raw_r - pm).astype(np.float32)
+    pose = np.tile(np.array([[1, 0, 0, -0.03], [0, 1, 0, -0.04], [0, 0, 1, 0.9]], np.float32), (B, 1, 1))
+    zio, zir, zf = ozoom.zoom_image(io, ir, pose, LINEMOD_K, PIXEL_MEANS, H, W)
+    bo = ops.mask_bbox(cu(io), 0.01, mode=1, means3=pm.reshape(3))
+    br = ops.mask_bbox(cu(ir), 0.01, mode=1, means3=pm.reshape(3))
+    gzf = ops.zoom_factor(bo, br, cu(pose), LINEMOD_K, H, W)
+    np.testing.assert_allclose(gzf.cpu().numpy(), zf, rtol=2e-6, atol=2e-6)
+    out = ops.zoom_planes(cu(io), cu(zf), add3=pm.reshape(3))
+    np.testing.assert_allclose(out.cpu().numpy(), zio, atol=2e-3)
+
+
+def test_zoom_observed_empty_sets_status(ops):
+    from lib.utils.synthetic import LINEMOD_K
+
+    B, H, W = 2, 480, 640
+    mo = torch.zeros((B, 1, H, W), device=DEV)
+    mr = torch.zeros((B, 1, H, W), device=DEV)
+    mr[1, 0, 100:200, 100:200] = 1
+    pose = cu(np.tile(np.eye(3, 4, dtype=np.float32), (B, 1, 1)) + np.array([0, 0, 0, 1], np.float32))
+    status = torch.zeros(B, dtype=torch.int32, device=DEV)
+    zf = ops.zoom_factor(ops.mask_bbox(mo, 0.3), ops.mask_bbox(mr, 0.2), pose, LINEMOD_K, H, W, status=status)
+    assert status.tolist() == [3, 1]  # reference raises ValueError here (np.min of empty)
+    assert torch.isfinite(zf).all()
+
+
+# ------------------------------------------------------------------ rasteriser
+def test_rasteriser_vs_oracle(ops):
+    from lib.render_hip.render_py_multi import Render_Py
+    from lib.utils import synthetic as syn
+
+    models = syn.make_models(seed=3, n_models=2, subdiv=3)
+    cls, gt, init = syn.sample_pairs(4, 4, n_classes=2)
+    K = syn.LINEMOD_K
+    for bil in (False, True):
+        rm = Render_Py(None, ["a", "b"], K, meshes=models, tex_bilinear=bil)
+        B = 4
+        image = torch.empty((B, 3, 480, 640), device=DEV)
+        depth = torch.empty((B, 1, 480, 640), device=DEV)
+        mask = torch.empty((B, 1, 480, 640), device=DEV)
+        bgr = torch.empty((B, 480, 640, 3), device=DEV)
+        bbox = torch.empty((B, 4), dtype=torch.int32, device=DEV)
+        pm = syn.plane_means()
+        rm.render_batch(cu(cls, torch.int32), cu(init), image=image, depth=depth, mask=mask, bgr=bgr, bbox=bbox, plane_means=pm)
+        for b in range(B):
+            v, t, f, tex = models[cls[b]]
+            rb, rd = native.render(v, t, f, tex, init[b][:, :3], init[b][:, 3], K, tex_bilinear=bil)
+            gd = depth[b, 0].cpu().numpy()
+            cov_diff = ((gd > 0) != (rd > 0)).sum()
+            assert cov_diff <= 4, cov_diff
+            both = (gd > 0) & (rd > 0)
+            assert both.sum() > 500
+            np.testing.assert_allclose(gd[both], rd[both], rtol=2e-6)
+            gb = bgr[b].cpu().numpy()
+            bad = (np.abs(gb - rb).max(axis=-1) > (1.0 if bil else 0.0)) & both
+            assert bad.sum() <= (20 if bil else 8), bad.sum()  # texel flips on cell borders
+            np.testing.assert_array_equal(mask[b, 0].cpu().numpy(), (gd > 0.2).astype(np.float32))
+            ys, xs = np.nonzero(gd > 0.2)
+            assert bbox[b].tolist() == [xs.min(), xs.max(), ys.min(), ys.max()]
+            ref_img = syn.bgr_to_blob(gb)[0]
+            np.testing.assert_allclose(image[b].cpu().numpy(), ref_img, atol=1e-4)
+        # reference object API: render(cls_idx, r, t, r_type='mat')
+        b0, d0 = rm.render(int(cls[0]), init[0][:, :3], init[0][:, 3], r_type="mat")
+        np.testing.assert_array_equal(d0, depth[0, 0].cpu().numpy())
+        np.testing.assert_array_equal(b0, bgr[0].cpu().numpy())
+
+
+def test_rasteriser_offscreen_and_clipping(ops):
+    from lib.render_hip.render_py_multi import Render_Py
+    from lib.utils import synthetic as syn
+
+    models = syn.make_models(seed=3, n_models=1, subdiv=2)
+    rm = Render_Py(None, ["a"], syn.LINEMOD_K, meshes=models)
+    poses = np.tile(np.eye(3, 4, dtype=np.float32), (3, 1, 1))
+    poses[0, :, 3] = [5.0, 0, 1.0]    # far off-screen
+    poses[1, :, 3] = [0, 0, 0.1]      # closer than znear: every fragment clipped
+    poses[2, :, 3] = [0, 0, -1.0]     # behind the camera
+    depth = torch.empty((3, 1, 480, 640), device=DEV)
+    bbox = torch.empty((3, 4), dtype=torch.int32, device=DEV)
+    mask = torch.empty((3, 1, 480, 640), device=DEV)
+    rm.render_batch(cu(np.zeros(3), torch.int32), cu(poses), depth=depth, mask=mask, bbox=bbox)
+    assert depth.abs().sum() == 0
+    assert bbox.tolist() == [[640, -1, 480, -1]] * 3
+    m = torch.ones((3, 1, 480, 640), device=DEV)
+    ops.box_mask(bbox, m)
+    assert m.sum() == 0
+
+
+def test_box_mask_end_exclusive(ops):
+    bbox = torch.tensor([[10, 20, 30, 50], [5, 5, 7, 9]], dtype=torch.int32, device=DEV)
+    m = torch.empty((2, 1, 480, 640), device=DEV)
+    ops.box_mask(bbox, m)
+    ref = np.zeros((2, 1, 480, 640), np.float32)
+    ref[0, 0, 30:50, 10:20] = 1  # data_pair.py:114 mask[y_start:y_end, x_start:x_end]
+    np.testing.assert_array_equal(m.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------ convolution
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, s, p, tile, splits
+    (2, 60, 80, 8, 64, 7, 2, 3, 0, 1),
+    (1, 37, 53, 8, 64, 7, 2, 3, 2, 1),
+    (1, 37, 53, 8, 64, 7, 2, 3, 3, 1),
+    (2, 30, 40, 64, 128, 5, 2, 2, 1, 1),
+    (1, 23, 31, 64, 128, 5, 2, 2, 3, 1),
+    (2, 15, 20, 256, 256, 3, 1, 1, 0, 1),
+    (2, 15, 20, 256, 512, 3, 2, 1, 1, 1),
+    (2, 15, 20, 512, 512, 3, 1, 1, 3, 3),
+    (2, 8, 10, 512, 1024, 3, 2, 1, 0, 4),
+    (1, 9, 11, 32, 64, 3, 1, 0, 2, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_vs_torch_cpu(ops, case):
+    import torch.nn.functional as F
+
+    N, H, W, Cin, Cout, k, s, p, tile, splits = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn((Cout,), generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p), 0.1).float()
+    wp = ops.conv2d_pack_weight(w.to(DEV))
+    y = ops.conv2d_fwd(x.permute(0, 2, 3, 1).contiguous().to(DEV), wp, b.to(DEV), Cout, k, k, s, p, slope=0.1, splits=splits, tile=tile)
+    got = y.permute(0, 3, 1, 2).cpu()
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)
+
+
+def test_conv2d_linear_no_bias_and_arg_errors(ops):
+    import torch.nn.functional as F
+    from lib.hip.capi import DeepIMHipError
+
+    x = torch.randn((1, 32, 9, 9))
+    w = torch.randn((64, 32, 3, 3)) / 17
+    wp = ops.conv2d_pack_weight(w.to(DEV))
+    y = ops.conv2d_fwd(x.permute(0, 2, 3, 1).contiguous().to(DEV), wp, None, 64, 3, 3, 1, 1, slope=1.0)
+    np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), F.conv2d(x, w, padding=1).numpy(), atol=2e-5, rtol=1e-4)
+    with pytest.raises(DeepIMHipError):
+        ops.conv2d_fwd(torch.zeros((1, 9, 9, 12), device=DEV), wp, None, 64, 3, 3, 1, 1)
+    with pytest.raises(DeepIMHipError):
+        ops.conv2d_fwd(torch.zeros((1, 9, 9, 32)), wp, None, 64, 3, 3, 1, 1)  # CPU tensor: no fallback
+
+
+def test_fc6_and_pose_head(ops):
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(1)
+    B = 3
+    feat = torch.randn((B, 1024, 8, 10), generator=g)
+    w6 = torch.randn((256, 81920), generator=g) / 286
+    b6 = torch.randn((256,), generator=g)
+    p = {"fc7_weight": torch.randn((256, 256), generator=g) / 16, "fc7_bias": torch.randn((256,), generator=g),
+         "rot_weight": torch.randn((4, 256), generator=g) / 16, "rot_bias": torch.randn((4,), generator=g),
+         "trans_weight": torch.randn((3, 256), generator=g) / 16, "trans_bias": torch.randn((3,), generator=g)}
+    zf = torch.rand((B, 4), generator=g) + 0.3
+    fc6 = F.leaky_relu(F.linear(feat.reshape(B, -1).double(), w6.double(), b6.double()), 0.1)
+    fc7 = F.leaky_relu(F.linear(fc6, p["fc7_weight"].double(), p["fc7_bias"].double()), 0.1)
+    rot = F.linear(fc7, p["rot_weight"].double(), p["rot_bias"].double())
+    tr = F.linear(fc7, p["trans_weight"].double(), p["trans_bias"].double())
+    tr[:, :2] *= zf[:, :1].double()
+    ref = torch.cat([rot, tr], dim=1).float().numpy()
+    wp = ops.fc_pack_weight(w6.to(DEV), 1024, 8, 10)
+    y6 = ops.conv2d_fwd(feat.permute(0, 2, 3, 1).contiguous().to(DEV), wp, b6.to(DEV), 256, 8, 10, 1, 0, slope=0.1, splits=160, tile=3)
+    np.testing.assert_allclose(y6.view(B, 256).cpu().numpy(), fc6.float().numpy(), atol=5e-5, rtol=1e-4)
+    se3 = ops.pose_head_fwd(y6.view(B, 256), {k: v.to(DEV) for k, v in p.items()}, zf.to(DEV))
+    np.testing.assert_allclose(se3.cpu().numpy(), ref, atol=5e-5, rtol=1e-4)

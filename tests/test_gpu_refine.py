@@ -1,0 +1,83 @@
+"""GPU parity of the network forward and of the whole 4-iteration refinement loop vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import flownet as oflow, pose_error, refine as orefine  # noqa: E402
+from scene import make_scene, make_test_config  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def setup(hip_lib):
+    assert torch.cuda.is_available()
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+
+    cfg = make_test_config(test_iter=4)
+    sym = deepIM_flownet()
+    sym.get_symbol(cfg, is_train=False)
+    params = sym.init_weights(cfg, {}, {}, seed=0)
+    # make the pose head non-trivial (the reference init has trans = 0): parity must cover it
+    rng = np.random.RandomState(1)
+    params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
+    params["rot_weight"][1:] = (rng.randn(3, 256) * 0.01).astype(np.float32)
+    scene = make_scene(B=2, seed=2333, subdiv=3)
+    return cfg, params, scene
+
+
+def test_forward_test_vs_oracle(setup):
+    from deepim.core.tester import Predictor
+
+    cfg, params, scene = setup
+    B = 2
+    pred = Predictor(cfg, params, B)
+    batch = {k: torch.as_tensor(v).to(DEV) for k, v in scene["blobs"].items()}
+    out = pred.predict(batch)[0]
+    ref = oflow.forward_test(params, scene["blobs"], scene["K"], cfg.network.PIXEL_MEANS, fast_test=True)
+    np.testing.assert_allclose(out["zoom_factor"].cpu().numpy(), ref["zoom_factor"], rtol=2e-6, atol=2e-6)
+    X = pred.net.X.cpu().numpy().transpose(0, 3, 1, 2)
+    np.testing.assert_allclose(X[:, :6], ref["data"][:, :6], atol=2e-5)
+    assert (X[:, 6:] != ref["data"][:, 6:]).sum() <= 16
+    for name in ["flow_conv1", "conv3_1", "conv6_1"]:
+        got = pred.net.acts[name].cpu().numpy().transpose(0, 3, 1, 2)
+        want = ref["feats"][name].numpy()
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 1e-4 * scale + 1e-5, name
+    # north_star tolerance: outputs within 1e-3 fp32
+    np.testing.assert_allclose(out["se3_output"].cpu().numpy(), ref["se3"], atol=1e-3)
+    np.testing.assert_allclose(out["se3_output"].cpu().numpy(), ref["se3"], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_refine_4iter_vs_oracle(setup, graph):
+    from deepim.core.tester import Predictor, Refiner
+    from lib.render_hip.render_py_multi import Render_Py
+
+    cfg, params, scene = setup
+    B = 2
+    pred = Predictor(cfg, params, B)
+    rm = Render_Py(None, cfg.dataset.class_name, scene["K"], meshes=scene["models"])
+    ref = Refiner(cfg, pred, rm, B, capture_graph=graph)
+    bl = scene["blobs"]
+    ref.load(bl["image_observed"], bl["image_rendered"], bl["mask_observed"], bl["mask_rendered"], bl["src_pose"], bl["class_index"])
+    poses = ref.refine().cpu().numpy().copy()
+    poses2 = ref.refine().cpu().numpy()  # replay on the same batch must be idempotent
+    np.testing.assert_array_equal(poses, poses2)
+    assert int(ref.status_iter.abs().sum()) == 0
+    z3, o3 = np.zeros(3), np.ones(3)
+    pts = scene["models"][0][0].astype(np.float64)
+    diam = np.linalg.norm(pts.max(0) - pts.min(0))
+    for b in range(B):
+        blobs_b = {k: bl[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
+        o_poses, o_se3 = orefine.refine_pair(params, scene["models"][int(bl["class_index"][b])], blobs_b, scene["K"],
+                                             cfg.network.PIXEL_MEANS, z3, o3, "CAMERA", test_iter=4)
+        for it in range(4):
+            np.testing.assert_allclose(ref.se3_iter[it, b].cpu().numpy(), o_se3[it], atol=1e-3)
+            np.testing.assert_allclose(poses[it, b], o_poses[it], atol=1e-3)
+            # ADD of our final pose vs the oracle's final pose ("ADD(-S) vs reference" clause): far below 0.02*d
+            e = pose_error.add(poses[it, b][:, :3].astype(np.float64), poses[it, b][:, 3].astype(np.float64), o_poses[it][:, :3],
+                               o_poses[it][:, 3], pts)
+            assert e < 1e-3 * diam, (b, it, e)
