@@ -2,7 +2,7 @@
  *
  * Drop-in boundary: these are the entry points a maintainer of wangg12/mx-DeepIM would bind
  * (ctypes) in place of
- *   - the numpy/MXNet bodies of the Python custom ops in deepim/operator_py/*.py,
+ *   - the numpy/MXNet bodies of the Python custom ops in deepim/operator_py/ (every .py there),
  *   - the one native function the reference has today,
  *       void _flow(float* flow, float* valid, float* depth_src, float* depth_tgt, float* KT,
  *                  float* Kinv, int batch_size, int height, int width, int device_id)

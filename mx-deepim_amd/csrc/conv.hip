@@ -372,6 +372,7 @@ long dim_conv2d_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH,
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64
 int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
                    int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile, void* stream) {
+  if (N == 0) return DIM_OK;  // empty batch
   DIM_REQUIRE(x && w_packed && y, "null pointer");
   DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
   DIM_REQUIRE(Cout % 64 == 0, "Cout must be a multiple of 64 (got %d)", Cout);
@@ -426,7 +427,7 @@ int dim_pose_head_fwd(const float* fc6, const float* fc7_w, const float* fc7_b, 
                       const float* trans_w, const float* trans_b, const float* zoom_factor, float* se3, float* fc7_out, int B,
                       void* stream) {
   DIM_REQUIRE(fc6 && fc7_w && fc7_b && rot_w && rot_b && trans_w && trans_b && zoom_factor && se3, "null pointer");
-  DIM_REQUIRE(B > 0, "empty batch");
+  if (B == 0) return DIM_OK;
   hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(256), 0, as_stream(stream), fc6, fc7_w, fc7_b, rot_w, rot_b, trans_w,
                      trans_b, zoom_factor, se3, fc7_out);
   return check_launch("pose_head");

@@ -51,8 +51,8 @@ using namespace dim;
 
 extern "C" int dim_depth_to_flow(const float* depth_src, const float* depth_tgt, const float* KT, const float* Kinv9, int B, int H,
                                  int W, float* flow, float* valid, void* stream) {
+  if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(depth_src && depth_tgt && KT && Kinv9 && flow && valid, "null pointer");
-  if (B == 0) return DIM_OK;
   hipLaunchKernelGGL(depth_flow_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, as_stream(stream), depth_src, depth_tgt, KT,
                      Kinv9[0], Kinv9[1], Kinv9[2], Kinv9[3], Kinv9[4], Kinv9[5], H, W, flow, valid);
   return check_launch("depth_to_flow");

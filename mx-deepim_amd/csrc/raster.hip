@@ -283,10 +283,10 @@ int dim_raster_render(const float* verts, const float* uvs, const int* faces, co
                       const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear, const float* plane_means3,
                       float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox,
                       void* stream) {
+  if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(verts && uvs && faces && mesh_table && textures && tex_table && class_index && poses && K9 && workspace, "null pointer");
   DIM_REQUIRE(vmax > 0 && fmax > 0 && H > 0 && W > 0, "bad sizes");
   DIM_REQUIRE(!image || plane_means3, "image output needs plane_means3");
-  if (B == 0) return DIM_OK;
   hipStream_t st = as_stream(stream);
   unsigned long long* zbuf = reinterpret_cast<unsigned long long*>(workspace);
   float* scr = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (long)B * H * W * 8);
@@ -305,9 +305,9 @@ int dim_raster_render(const float* verts, const float* uvs, const int* faces, co
 }
 
 int dim_box_mask(const int* bbox, float* mask, int B, int H, int W, void* stream) {
+  if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(bbox && mask, "null pointer");
   DIM_REQUIRE(W % 4 == 0, "W must be a multiple of 4");
-  if (B == 0) return DIM_OK;
   hipLaunchKernelGGL(box_mask_kernel, dim3(ceil_div(W / 4, 256), H, B), dim3(256), 0, as_stream(stream), bbox, mask, H, W);
   return check_launch("box_mask");
 }

@@ -326,9 +326,9 @@ extern "C" {
 
 int dim_se3_compose(const float* pose_src, const float* se3, float* pose_out, double* pose_out_f64, int B, int rot_coord,
                     const float* T_means3, const float* T_stds3, void* stream) {
+  if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(pose_src && se3 && pose_out && T_means3 && T_stds3, "null pointer");
   DIM_REQUIRE(parse_rot(rot_coord) >= 0, "unknown rot_coord %d", rot_coord);
-  if (B == 0) return DIM_OK;
   hipLaunchKernelGGL(se3_compose_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, se3, pose_out,
                      pose_out_f64, B, rot_coord, (double)T_means3[0], (double)T_means3[1], (double)T_means3[2], (double)T_stds3[0],
                      (double)T_stds3[1], (double)T_stds3[2]);
@@ -337,9 +337,9 @@ int dim_se3_compose(const float* pose_src, const float* se3, float* pose_out, do
 
 int dim_se3_delta(const float* pose_src, const float* pose_tgt, float* rot_quat, float* trans, int B, int rot_coord,
                   const float* T_means3, const float* T_stds3, void* stream) {
+  if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(pose_src && pose_tgt && rot_quat && trans && T_means3 && T_stds3, "null pointer");
   DIM_REQUIRE(parse_rot(rot_coord) >= 0, "unknown rot_coord %d", rot_coord);
-  if (B == 0) return DIM_OK;
   hipLaunchKernelGGL(se3_delta_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, pose_tgt, rot_quat, trans, B,
                      rot_coord, (double)T_means3[0], (double)T_means3[1], (double)T_means3[2], (double)T_stds3[0],
                      (double)T_stds3[1], (double)T_stds3[2]);
@@ -347,9 +347,9 @@ int dim_se3_delta(const float* pose_src, const float* pose_tgt, float* rot_quat,
 }
 
 int dim_zoom_trans(const float* zoom_factor, const float* in, float* out, int B, int mode, void* stream) {
+  if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(zoom_factor && in && out, "null pointer");
   DIM_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (copy), 1 (divide) or 2 (multiply)");
-  if (B == 0) return DIM_OK;
   hipLaunchKernelGGL(zoom_trans_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), zoom_factor, in, out, B, mode);
   return check_launch("zoom_trans");
 }
@@ -363,9 +363,9 @@ static T3DConst make_t3d(int rot_coord, const float* m, const float* s) {
 
 int dim_transform3d_fwd(const float* points, const float* rot, const float* trans, const float* pose_src, float* out, int B,
                         int Npts, int rot_coord, const float* T_means3, const float* T_stds3, void* stream) {
+  if (B == 0 || Npts == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(points && rot && trans && pose_src && out && T_means3 && T_stds3, "null pointer");
   DIM_REQUIRE(parse_rot(rot_coord) >= 0, "unknown rot_coord %d", rot_coord);
-  if (B == 0 || Npts == 0) return DIM_OK;
   hipLaunchKernelGGL(transform3d_fwd_kernel, dim3(ceil_div(Npts, 256), B), dim3(256), 0, as_stream(stream), points, rot, trans,
                      pose_src, out, Npts, make_t3d(rot_coord, T_means3, T_stds3));
   return check_launch("transform3d_fwd");
@@ -374,9 +374,9 @@ int dim_transform3d_fwd(const float* points, const float* rot, const float* tran
 int dim_transform3d_bwd(const float* out_grad, const float* points, const float* rot, const float* trans, const float* pose_src,
                         float* d_rot, float* d_trans, int B, int Npts, int rot_coord, const float* T_means3, const float* T_stds3,
                         void* stream) {
+  if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(out_grad && points && rot && trans && pose_src && d_rot && d_trans && T_means3 && T_stds3, "null pointer");
   DIM_REQUIRE(parse_rot(rot_coord) >= 0, "unknown rot_coord %d", rot_coord);
-  if (B == 0) return DIM_OK;
   hipLaunchKernelGGL(transform3d_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), out_grad, points, rot, trans, pose_src,
                      d_rot, d_trans, Npts, make_t3d(rot_coord, T_means3, T_stds3));
   return check_launch("transform3d_bwd");

@@ -163,21 +163,28 @@ __device__ inline Affine load_affine(const float* zf, bool inverse, int H, int W
 }
 
 struct Tap {
-  int o00, o01, o10, o11;      // offsets inside a plane
-  float w00, w01, w10, w11;    // weights already multiplied by corner validity
+  int o00, o01, o10, o11;      // offsets inside a plane (clamped)
+  bool v00, v01, v10, v11;     // corner validity (BilinearSampler zero padding)
+  float wx0, wy0;              // top_left_x_w, top_left_y_w
 };
 
 // GridGenerator(affine) + BilinearSampler coordinate rule (MXNet 1.2 semantics, float32):
 //   x_t = -1 + j*2/(W-1);  x_s = wx*x_t + tx;  x_real = (x_s + 1)*(W-1)/2;  zero outside.
+// Every operation is individually rounded (__f*_rn: no FMA contraction) so coordinates and weights are
+// bit-identical to a plain float32 evaluation: with 8-bit image data a 1-ulp coordinate change at x~600
+// already moves a sample by ~1e-2, which would otherwise dominate the parity budget.
 __device__ inline Tap make_tap(const Affine& a, int y, int x, int H, int W) {
-  float xt = -1.f + (float)x * (2.f / (float)(W - 1));
-  float yt = -1.f + (float)y * (2.f / (float)(H - 1));
-  float xs = a.wx * xt + a.tx;
-  float ys = a.wy * yt + a.ty;
-  float xr = (xs + 1.f) * (float)(W - 1) / 2.f;
-  float yr = (ys + 1.f) * (float)(H - 1) / 2.f;
+  const float sx = (float)(2.0 / (double)(W - 1)), sy = (float)(2.0 / (double)(H - 1));
+  float xt = __fadd_rn(-1.f, __fmul_rn((float)x, sx));
+  float yt = __fadd_rn(-1.f, __fmul_rn((float)y, sy));
+  float xs = __fadd_rn(__fmul_rn(a.wx, xt), a.tx);
+  float ys = __fadd_rn(__fmul_rn(a.wy, yt), a.ty);
+  float xr = __fdiv_rn(__fmul_rn(__fadd_rn(xs, 1.f), (float)(W - 1)), 2.f);
+  float yr = __fdiv_rn(__fmul_rn(__fadd_rn(ys, 1.f), (float)(H - 1)), 2.f);
   float x0f = floorf(xr), y0f = floorf(yr);
-  float wx0 = 1.f - (xr - x0f), wy0 = 1.f - (yr - y0f);
+  Tap t;
+  t.wx0 = __fsub_rn(1.f, __fsub_rn(xr, x0f));
+  t.wy0 = __fsub_rn(1.f, __fsub_rn(yr, y0f));
   // clamp before the int cast so absurd coordinates cannot overflow; those corners are invalid anyway
   int x0 = (int)fminf(fmaxf(x0f, -2.f), (float)(W + 1));
   int y0 = (int)fminf(fmaxf(y0f, -2.f), (float)(H + 1));
@@ -185,12 +192,8 @@ __device__ inline Tap make_tap(const Affine& a, int y, int x, int H, int W) {
   bool vy0 = y0 >= 0 && y0 <= H - 1, vy1 = y0 + 1 >= 0 && y0 + 1 <= H - 1;
   int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
   int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
-  Tap t;
   t.o00 = yc0 * W + xc0; t.o01 = yc0 * W + xc1; t.o10 = yc1 * W + xc0; t.o11 = yc1 * W + xc1;
-  t.w00 = (vy0 && vx0) ? wy0 * wx0 : 0.f;
-  t.w01 = (vy0 && vx1) ? wy0 * (1.f - wx0) : 0.f;
-  t.w10 = (vy1 && vx0) ? (1.f - wy0) * wx0 : 0.f;
-  t.w11 = (vy1 && vx1) ? (1.f - wy0) * (1.f - wx0) : 0.f;
+  t.v00 = vy0 && vx0; t.v01 = vy0 && vx1; t.v10 = vy1 && vx0; t.v11 = vy1 && vx1;
   return t;
 }
 
@@ -206,14 +209,21 @@ __device__ inline float fetch(const float* p, int o) {
   return v;
 }
 
-// out = tl*w00 + tr*w01 + bl*w10 + br*w11, evaluated left to right like BilinearSampler.
+// out = tl*wy0*wx0 + tr*wy0*(1-wx0) + bl*(1-wy0)*wx0 + br*(1-wy0)*(1-wx0), evaluated left to right with
+// one rounding per operation, exactly as BilinearSampler's expression reads.
 // `add` is the per-plane constant added before sampling and removed afterwards (pixel mean).
 template <int PRE>
 __device__ inline float sample(const float* plane, const Tap& t, float add) {
-  float tl = fetch<PRE>(plane, t.o00) + add, tr = fetch<PRE>(plane, t.o01) + add;
-  float bl = fetch<PRE>(plane, t.o10) + add, br = fetch<PRE>(plane, t.o11) + add;
-  // invalid corners contribute exactly 0 (weights carry validity)
-  return ((tl * t.w00 + tr * t.w01) + bl * t.w10) + br * t.w11;
+  float tl = t.v00 ? __fadd_rn(fetch<PRE>(plane, t.o00), add) : 0.f;
+  float tr = t.v01 ? __fadd_rn(fetch<PRE>(plane, t.o01), add) : 0.f;
+  float bl = t.v10 ? __fadd_rn(fetch<PRE>(plane, t.o10), add) : 0.f;
+  float br = t.v11 ? __fadd_rn(fetch<PRE>(plane, t.o11), add) : 0.f;
+  const float wx1 = __fsub_rn(1.f, t.wx0), wy1 = __fsub_rn(1.f, t.wy0);
+  float r = __fmul_rn(__fmul_rn(tl, t.wy0), t.wx0);
+  r = __fadd_rn(r, __fmul_rn(__fmul_rn(tr, t.wy0), wx1));
+  r = __fadd_rn(r, __fmul_rn(__fmul_rn(bl, wy1), t.wx0));
+  r = __fadd_rn(r, __fmul_rn(__fmul_rn(br, wy1), wx1));
+  return r;
 }
 
 // Generic NCHW plane sampler: y[b,c] = post( sample(pre(x[b,c] + add[c])) - add[c] ) * scale(b)
@@ -234,11 +244,11 @@ __global__ __launch_bounds__(256) void zoom_planes_kernel(const float* __restric
     float add = c == 0 ? add0 : (c == 1 ? add1 : add2);
     if (C > 3) add = 0.f;
     float v = sample<PRE>(x + ((long)b * C + c) * plane, t, add);
-    v -= add;
+    v = __fsub_rn(v, add);
     if (POST == POST_ROUND) v = mx_round(v);
-    if (POST == POST_ROUND_M045) v = mx_round(v - 0.45f);
-    if (scale_mode == 1) v = v / zwx;
-    if (scale_mode == 2) v = v * zwx;
+    if (POST == POST_ROUND_M045) v = mx_round(__fsub_rn(v, 0.45f));
+    if (scale_mode == 1) v = __fdiv_rn(v, zwx);
+    if (scale_mode == 2) v = __fmul_rn(v, zwx);
     y[((long)b * C + c) * plane + (long)py * W + px] = v;
   }
 }
@@ -263,12 +273,12 @@ __global__ __launch_bounds__(256) void zoom_net_input_kernel(const float* __rest
   const float* io = img_obs + (long)b * 3 * plane;
   const float* ir = img_ren + (long)b * 3 * plane;
   float v[8];
-  v[0] = sample<PRE_NONE>(io, t, m0) - m0;
-  v[1] = sample<PRE_NONE>(io + plane, t, m1) - m1;
-  v[2] = sample<PRE_NONE>(io + 2 * plane, t, m2) - m2;
-  v[3] = sample<PRE_NONE>(ir, t, m0) - m0;
-  v[4] = sample<PRE_NONE>(ir + plane, t, m1) - m1;
-  v[5] = sample<PRE_NONE>(ir + 2 * plane, t, m2) - m2;
+  v[0] = __fsub_rn(sample<PRE_NONE>(io, t, m0), m0);
+  v[1] = __fsub_rn(sample<PRE_NONE>(io + plane, t, m1), m1);
+  v[2] = __fsub_rn(sample<PRE_NONE>(io + 2 * plane, t, m2), m2);
+  v[3] = __fsub_rn(sample<PRE_NONE>(ir, t, m0), m0);
+  v[4] = __fsub_rn(sample<PRE_NONE>(ir + plane, t, m1), m1);
+  v[5] = __fsub_rn(sample<PRE_NONE>(ir + 2 * plane, t, m2), m2);
   v[6] = mx_round(sample<PRE_NONE>(mask_obs + (long)b * plane, t, 0.f));
   v[7] = mx_round(sample<PRE_BIN02>(mask_ren + (long)b * plane, t, 0.f));
   const long o = (long)py * W + px;
@@ -280,8 +290,8 @@ __global__ __launch_bounds__(256) void zoom_net_input_kernel(const float* __rest
     z_mask_obs[(long)b * plane + o] = v[6];
     z_mask_ren[(long)b * plane + o] = v[7];
   }
-  float4 lo = make_float4(v[0] / 255.f, v[1] / 255.f, v[2] / 255.f, v[3] / 255.f);
-  float4 hi = make_float4(v[4] / 255.f, v[5] / 255.f, v[6], v[7]);
+  float4 lo = make_float4(__fdiv_rn(v[0], 255.f), __fdiv_rn(v[1], 255.f), __fdiv_rn(v[2], 255.f), __fdiv_rn(v[3], 255.f));
+  float4 hi = make_float4(__fdiv_rn(v[4], 255.f), __fdiv_rn(v[5], 255.f), v[6], v[7]);
   float4* dst = reinterpret_cast<float4*>(X + ((long)b * plane + o) * 8);
   dst[0] = lo;
   dst[1] = hi;
@@ -294,11 +304,11 @@ using namespace dim;
 extern "C" {
 
 int dim_mask_bbox(const float* x, int B, int C, int H, int W, int mode, float thr, const float* means3, int* bbox, void* stream) {
+  if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(x && bbox, "null pointer");
   DIM_REQUIRE(W % 4 == 0, "W must be a multiple of 4 (got %d)", W);
   DIM_REQUIRE(mode == 0 || (mode == 1 && C == 3 && means3), "mode 0 (plane>thr, C=1) or mode 1 (sum of 3 planes + means)");
   DIM_REQUIRE(mode == 1 || C == 1, "mode 0 expects C == 1");
-  if (B == 0) return DIM_OK;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(bbox_init_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, bbox, B, H, W);
   const int rows = 8;
@@ -312,8 +322,8 @@ int dim_mask_bbox(const float* x, int B, int C, int H, int W, int mode, float th
 
 int dim_zoom_factor(const int* bbox_observed, const int* bbox_rendered, const float* src_pose, const float* K9, int B, int H, int W,
                     float* zoom_factor, int* status, void* stream) {
+  if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(bbox_observed && bbox_rendered && src_pose && K9 && zoom_factor, "null pointer");
-  if (B == 0) return DIM_OK;
   hipLaunchKernelGGL(zoom_factor_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), bbox_observed, bbox_rendered,
                      src_pose, K9[0], K9[1], K9[2], K9[3], K9[4], K9[5], K9[6], K9[7], K9[8], H, W, B, zoom_factor, status);
   return check_launch("zoom_factor");
@@ -321,11 +331,11 @@ int dim_zoom_factor(const int* bbox_observed, const int* bbox_rendered, const fl
 
 int dim_zoom_planes(const float* x, const float* zoom_factor, float* y, int B, int C, int H, int W, int inverse, int pre, int post,
                     const float* add3, int scale_mode, void* stream) {
+  if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(x && zoom_factor && y, "null pointer");
   DIM_REQUIRE(pre == PRE_NONE || pre == PRE_BIN02, "pre must be 0 or 1");
   DIM_REQUIRE(post >= 0 && post <= 2, "post must be 0..2");
   DIM_REQUIRE(!add3 || C <= 3, "per-plane add constants only for C <= 3");
-  if (B == 0) return DIM_OK;
   float a0 = add3 ? add3[0] : 0.f, a1 = add3 && C > 1 ? add3[1] : 0.f, a2 = add3 && C > 2 ? add3[2] : 0.f;
   dim3 grid(ceil_div(W, 256), H, B), block(256);
   hipStream_t st = as_stream(stream);
@@ -345,11 +355,11 @@ int dim_zoom_net_input(const float* image_observed, const float* image_rendered,
                        const float* mask_rendered, const float* zoom_factor, float* X_nhwc8, int B, int H, int W,
                        const float* means3, float* z_image_observed, float* z_image_rendered, float* z_mask_observed,
                        float* z_mask_rendered, void* stream) {
+  if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(image_observed && image_rendered && mask_observed && mask_rendered && zoom_factor && X_nhwc8 && means3, "null pointer");
   bool any = z_image_observed || z_image_rendered || z_mask_observed || z_mask_rendered;
   bool all = z_image_observed && z_image_rendered && z_mask_observed && z_mask_rendered;
   DIM_REQUIRE(!any || all, "pass all four NCHW outputs or none");
-  if (B == 0) return DIM_OK;
   dim3 grid(ceil_div(W, 256), H, B), block(256);
   hipLaunchKernelGGL(zoom_net_input_kernel, grid, block, 0, as_stream(stream), image_observed, image_rendered, mask_observed,
                      mask_rendered, zoom_factor, X_nhwc8, H, W, means3[0], means3[1], means3[2], z_image_observed,

@@ -39,7 +39,10 @@ def test_forward_test_vs_oracle(setup):
     ref = oflow.forward_test(params, scene["blobs"], scene["K"], cfg.network.PIXEL_MEANS, fast_test=True)
     np.testing.assert_allclose(out["zoom_factor"].cpu().numpy(), ref["zoom_factor"], rtol=2e-6, atol=2e-6)
     X = pred.net.X.cpu().numpy().transpose(0, 3, 1, 2)
-    np.testing.assert_allclose(X[:, :6], ref["data"][:, :6], atol=2e-5)
+    # zoom_factor may differ in its last bit (np.dot(K, t) in float32 BLAS vs the kernel's left-to-right sum); at
+    # x ~ 600 that moves a bilinear sample by up to ~1e-2 grey levels = 5e-5 after /255 (sampling itself is
+    # pinned bit-tight with identical factors in test_gpu_ops.test_zoom_mask_and_image_vs_oracle)
+    np.testing.assert_allclose(X[:, :6], ref["data"][:, :6], atol=1.5e-4)
     assert (X[:, 6:] != ref["data"][:, 6:]).sum() <= 16
     for name in ["flow_conv1", "conv3_1", "conv6_1"]:
         got = pred.net.acts[name].cpu().numpy().transpose(0, 3, 1, 2)
