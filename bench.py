@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py -- pose-refinements/sec (4 iterations, 480x640) of the HIP refinement path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one 4-iteration refinement of one batch of BATCH_PAIRS=16 synthetic LINEMOD-'ape' pairs per
+GPU (BASELINE.json configs[1]: FlowNetS-backbone forward x4 + SE(3) compose x4 + HIP rasteriser x3 +
+zoom x4), inputs resident in HBM, whole loop replayed as one hipGraph.  Pairs are independent, so ranks
+shard them with no data-path collective ("weak" scaling: 16 pairs per GPU).
+
+Prints ONE JSON line (rank 0) with the contract keys plus
+  "roofline":     dominant kernel's algorithmic TFLOP/s vs the dense f32 MFMA peak (HIP events on the
+                  launch stream, averaged over the timed launches of that kernel),
+  "cpu_baseline": the CPU oracle (torch-CPU convs + numpy zoom + C rasteriser, batch 1 like the reference
+                  loop) timed on this box's host cores on a bounded sample (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "mx-deepim_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_32x32x2_f32)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-pairs", type=int, default=None, help="pairs per GPU (default: TEST.BATCH_PAIRS of the cfg = 16)")
+    ap.add_argument("--cfg", default=os.path.join(PKG, "experiments", "deepim", "cfgs", "deepim_hip_LM_ape_test.yaml"))
+    ap.add_argument("--subdiv", type=int, default=5, help="icosphere subdivisions of the synthetic mesh (5 = 20480 triangles)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--autotune", action="store_true", help="time tile/split-K candidates per layer first (untimed); default: fixed plan")
+    ap.add_argument("--cpu-pairs", type=int, default=32, help="bounded CPU-baseline sample (pairs refined by the oracle)")
+    ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-layer HIP events for the roofline object")
+    return ap.parse_args()
+
+
+def host_cores():
+    """cores this process may actually use: cgroup quota if any (the GPU box gives 16 per GPU), else affinity"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16) if n > 64 else n  # no quota visible on a 256-thread host: stay within the per-GPU share
+
+
+def cpu_baseline(cfg, params, models, batch, n_pairs):
+    """oracle/refine.py on the first n_pairs pairs, batch 1 each (the reference loop is batch-1: tester.py:124)."""
+    from oracle import native, refine as orefine  # checker only -- never the measured product path
+
+    native.build()
+    torch.set_num_threads(host_cores())
+    idx = torch.arange(n_pairs, device=batch["src_pose"].device) % batch["src_pose"].shape[0]
+    blobs = {k: batch[k][idx].cpu().numpy() for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
+    cls = batch["class_index"][idx].cpu().numpy()
+    K = np.asarray(cfg.dataset.INTRINSIC_MATRIX, dtype=np.float32)
+    z3, o3 = np.zeros(3), np.ones(3)
+    one = {k: v[:1] for k, v in blobs.items()}
+    orefine.refine_pair(params, models[int(cls[0])], one, K, cfg.network.PIXEL_MEANS, z3, o3, cfg.network.ROT_COORD, test_iter=1)  # warm
+    t0 = time.time()
+    for i in range(n_pairs):
+        bi = {k: v[i:i + 1] for k, v in blobs.items()}
+        orefine.refine_pair(params, models[int(cls[i])], bi, K, cfg.network.PIXEL_MEANS, z3, o3, cfg.network.ROT_COORD,
+                            test_iter=int(cfg.TEST.test_iter))
+    dt = time.time() - t0
+    return {"value": n_pairs / dt, "unit": "pose-refinements/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "{} pairs x {} iters, batch 1 (torch-CPU f32 convs + numpy zoom + C rasteriser), {:.1f} s".format(
+                n_pairs, int(cfg.TEST.test_iter), dt)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus {} but WORLD_SIZE {}".format(args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the refinement path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:{}".format(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    from deepim.config.config import config as cfg, update_config
+    from deepim.core.tester import Predictor, Refiner
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+    from lib.hip import ops
+    from lib.render_hip.render_py_multi import Render_Py
+    from lib.utils import synthetic as syn
+
+    update_config(args.cfg)
+    B = args.batch_pairs or int(cfg.TEST.BATCH_PAIRS)
+    test_iter = int(cfg.TEST.test_iter)
+    sym = deepIM_flownet()
+    sym.get_symbol(cfg, is_train=False)
+    params = sym.init_weights(cfg, {}, {}, seed=0)
+    params["trans_weight"] = (np.random.RandomState(1).randn(3, 256) * 0.002).astype(np.float32)  # non-zero head: poses move
+    models = syn.make_models(seed=2333, n_models=len(cfg.dataset.class_name), subdiv=args.subdiv)
+    rm = Render_Py(None, cfg.dataset.class_name, cfg.dataset.INTRINSIC_MATRIX, zNear=cfg.dataset.ZNEAR, zFar=cfg.dataset.ZFAR,
+                   device=dev, meshes=models)
+    pred = Predictor(cfg, params, B, device=dev)
+    batch = syn.build_device_batch(rm, B, seed=1000 + rank, n_classes=len(models), pixel_means=cfg.network.PIXEL_MEANS, device=dev)
+    if args.autotune:  # untimed: choose tile / split-K per layer on this GPU before the graph is captured
+        pred.net.zoom({k: batch[k] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")})
+        pred.net.autotune()
+    refiner = Refiner(cfg, pred, rm, B, capture_graph=not args.no_graph)
+    refiner.load(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"], batch["src_pose"],
+                 batch["class_index"])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        refiner.refine()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        refiner.refine()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    status = int(refiner.status_iter.abs().sum().item())
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream around every conv launch (eager)
+    net = pred.net
+    events = {}
+    b = refiner.batch
+    for _ in range(args.profile_steps):
+        for it in range(test_iter):
+            net.zoom(b)
+            net.encoder(events=events)
+            net.head()
+    torch.cuda.synchronize()
+    per_kernel = {}
+    TILE_SYM = {1: "128, 128", 2: "128, 64", 3: "64, 64"}
+    for name, evs in events.items():
+        info = net.layer_info[name]
+        for tag, e0, e1 in evs:
+            if tag == "conv":  # the symbol rocprofv3 --kernel-trace reports for this launch
+                kname = "dim::conv_fwd_kernel<{}, 2, 2, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
+                flops = info["flops"]
+            else:
+                kname, flops = "dim::splitk_reduce_kernel", 0.0
+            k = per_kernel.setdefault(kname, {"ms": 0.0, "flops": 0.0, "launches": 0, "layers": []})
+            k["ms"] += e0.elapsed_time(e1)
+            k["flops"] += flops
+            k["launches"] += 1
+            if name not in k["layers"]:
+                k["layers"].append(name)
+    dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    nfwd = args.profile_steps * test_iter
+    roofline = {"bound": "mfma", "kernel": dom_name, "layers": dom["layers"], "achieved": round(achieved, 2),
+                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(dom["ms"] / dom["launches"], 4), "launches_timed": dom["launches"],
+                "gflop_per_launch_avg": round(dom["flops"] / dom["launches"] / 1e9, 3),
+                "all_kernels": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "avg_launch_ms": round(v["ms"] / v["launches"], 4),
+                                    "ms_per_forward": round(v["ms"] / nfwd, 4)} for k, v in per_kernel.items()},
+                "conv_stack_ms_per_forward": round(sum(v["ms"] for v in per_kernel.values()) / nfwd, 3)}
+
+    total_pairs = B * world * args.steps
+    value = total_pairs / elapsed
+    out = {
+        "metric": "pose-refinements/sec (4 iters, 480x640)", "value": round(value, 2), "unit": "pose-refinements/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LINEMOD 'ape' batch={} per GPU, {} iters, fp32, FAST_TEST graph (zoom + FlowNetS encoder + FC heads) "
+                               "+ SE3 compose + HIP rasteriser ({} triangles) + box_rendered mask update".format(
+                                   B, test_iter, models[0][2].shape[0]),
+                   "pairs_per_gpu": B, "global_pairs": B * world, "test_iter": test_iter, "hipgraph": not args.no_graph,
+                   "gflop_per_refinement": round(net.flops_per_forward() * test_iter / B / 1e9, 2), "status_flags": status,
+                   "conv_plan": {k: list(v) for k, v in net.conv_plan.items()}},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, params, models, batch, args.cpu_pairs)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,6 +113,11 @@ int dim_conv2d_pack_weight(const float* w_oihw, float* w_packed, int Cout, int C
 long dim_conv2d_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int splits);
 int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
                    int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile, void* stream);
+/* the two phases of a split-K dim_conv2d_fwd as separate calls (same kernels; lets a caller time / overlap them):
+ * partial: raw K-slice sums -> workspace[splits][M][Cout];  reduce: y = LeakyReLU(sum_k slabs + bias). */
+int dim_conv2d_fwd_partial(const float* x, const float* w_packed, float* workspace, int N, int H, int W, int Cin, int Cout, int KH,
+                           int KW, int stride, int pad, int splits, int tile, void* stream);
+int dim_splitk_reduce(const float* slabs, const float* bias, float* y, long M, int Cout, int splits, float slope, void* stream);
 /* FullyConnected weight (Out, C*H*W) [mx Flatten order c,h,w] -> [(h,w,c)][Out] so fc6 is dim_conv2d_fwd
  * with KH=H, KW=W on the NHWC feature map. */
 int dim_fc_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream);

@@ -60,27 +60,28 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const int kc_begin = split * a.chunks_per_split;
   const int kc_end = min(a.nchunks, kc_begin + a.chunks_per_split);
 
-  // ---- per-thread A-load descriptors (fixed pixels for the whole K loop)
+  // ---- per-thread A-load descriptors (fixed pixels for the whole K loop); element offsets fit int32
+  // (host checks N*H*W*Cin < 2^31)
   const int q = tid & 7;                  // float4 index inside the 32-float chunk
-  int a_hi0[A_PER_T], a_wi0[A_PER_T];
-  long a_base[A_PER_T];
-  bool a_ok[A_PER_T];
+  int a_hi0[A_PER_T], a_wi0[A_PER_T], a_base[A_PER_T];
 #pragma unroll
   for (int i = 0; i < A_PER_T; ++i) {
     int m = m0 + (tid >> 3) + 32 * i;
-    a_ok[i] = m < a.M;
-    int mm = a_ok[i] ? m : 0;
+    bool ok = m < a.M;
+    int mm = ok ? m : 0;
     int wo = mm % a.Wo;
     int t = mm / a.Wo;
     int ho = t % a.Ho;
     int n = t / a.Ho;
-    a_hi0[i] = ho * a.stride - a.pad;
+    a_hi0[i] = ok ? ho * a.stride - a.pad : -(1 << 28);  // rows past M: every tap fails the bounds test
     a_wi0[i] = wo * a.stride - a.pad;
-    a_base[i] = (long)n * a.H * a.W * a.Cin;
+    a_base[i] = n * a.H * a.W * a.Cin + (CIN8 ? (q & 1) * 4 : q * 4);
   }
   // ---- B-load mapping
   const int b_n4 = tid % (BN / 4);
   const int b_k = tid / (BN / 4);
+  const float* wbase = a.w + n0 + b_n4 * 4 + (long)b_k * a.Cout;
+  const int wrow_stride = B_ROWS_PER_PASS * a.Cout;
 
   // chunk -> (kh, kw, c0) counters
   int kh, kw, c0;
@@ -96,63 +97,49 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     kw = tap - kh * a.KW;
   }
 
-  float4 ra[A_PER_T], rb[B_PER_T];
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // named registers: arrays + lambdas ended up in scratch
 
-  auto load_chunk = [&](int kc) {
-#pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-      int hi = a_hi0[i] + kh;
-      int wi, coff;
-      if (CIN8) {
-        int tap = kw + (q >> 1);
-        wi = a_wi0[i] + tap;
-        coff = (q & 1) * 4;
-        bool ok = a_ok[i] && tap < a.KW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-        ra[i] = ok ? *reinterpret_cast<const float4*>(a.x + a_base[i] + ((long)hi * a.W + wi) * 8 + coff)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-        wi = a_wi0[i] + kw;
-        bool ok = a_ok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-        ra[i] = ok ? *reinterpret_cast<const float4*>(a.x + a_base[i] + ((long)hi * a.W + wi) * a.Cin + c0 + q * 4)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    const float* wsrc = a.w + ((long)kc * BK) * a.Cout + n0 + b_n4 * 4;
-#pragma unroll
-    for (int i = 0; i < B_PER_T; ++i) {
-      int k = b_k + B_ROWS_PER_PASS * i;
-      rb[i] = *reinterpret_cast<const float4*>(wsrc + (long)k * a.Cout);
-    }
-  };
-  auto advance = [&]() {
-    if (CIN8) {
-      kw += 4;
-      if (kw >= 8) { kw = 0; ++kh; }
-    } else {
-      c0 += 32;
-      if (c0 == a.Cin) {
-        c0 = 0;
-        if (++kw == a.KW) { kw = 0; ++kh; }
-      }
-    }
-  };
-  auto store_chunk = [&](int buf) {
-    float* dA = sA + buf * BK * LDA;
-    float* dB = sB + buf * BK * LDB;
-#pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-      int r = (tid >> 3) + 32 * i;
-      dA[(q * 4 + 0) * LDA + r] = ra[i].x;
-      dA[(q * 4 + 1) * LDA + r] = ra[i].y;
-      dA[(q * 4 + 2) * LDA + r] = ra[i].z;
-      dA[(q * 4 + 3) * LDA + r] = ra[i].w;
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER_T; ++i) {
-      int k = b_k + B_ROWS_PER_PASS * i;
-      *reinterpret_cast<float4*>(dB + k * LDB + b_n4 * 4) = rb[i];
-    }
-  };
+#define DIM_LOAD_A(REG, I)                                                                                   \
+  if (I < A_PER_T) {                                                                                          \
+    int hi = a_hi0[I] + kh;                                                                                   \
+    int wi = a_wi0[I] + kw + (CIN8 ? (q >> 1) : 0);                                                           \
+    bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && (!CIN8 || kw + (q >> 1) < a.KW); \
+    int off = a_base[I] + (hi * a.W + wi) * a.Cin + c0;                                                       \
+    REG = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);                 \
+  }
+#define DIM_LOAD_B(REG, I) \
+  if (I < B_PER_T) REG = *reinterpret_cast<const float4*>(wsrc + I * wrow_stride);
+#define DIM_LOAD_CHUNK(KC)                                       \
+  {                                                              \
+    DIM_LOAD_A(ra0, 0) DIM_LOAD_A(ra1, 1) DIM_LOAD_A(ra2, 2) DIM_LOAD_A(ra3, 3) \
+    const float* wsrc = wbase + (long)(KC) * BK * a.Cout;        \
+    DIM_LOAD_B(rb0, 0) DIM_LOAD_B(rb1, 1) DIM_LOAD_B(rb2, 2) DIM_LOAD_B(rb3, 3) \
+  }
+#define DIM_ADVANCE()                        \
+  if (CIN8) {                                \
+    kw += 4;                                 \
+    if (kw >= 8) { kw = 0; ++kh; }           \
+  } else {                                   \
+    c0 += 32;                                \
+    if (c0 == a.Cin) {                       \
+      c0 = 0;                                \
+      if (++kw == a.KW) { kw = 0; ++kh; }    \
+    }                                        \
+  }
+#define DIM_STORE_A(REG, I)                        \
+  if (I < A_PER_T) {                               \
+    float* d = dA + (q * 4) * LDA + (tid >> 3) + 32 * I; \
+    d[0] = REG.x; d[LDA] = REG.y; d[2 * LDA] = REG.z; d[3 * LDA] = REG.w; \
+  }
+#define DIM_STORE_B(REG, I) \
+  if (I < B_PER_T) *reinterpret_cast<float4*>(dB + (b_k + B_ROWS_PER_PASS * I) * LDB + b_n4 * 4) = REG;
+#define DIM_STORE_CHUNK(BUF)                          \
+  {                                                   \
+    float* dA = sA + (BUF) * BK * LDA;                \
+    float* dB = sB + (BUF) * BK * LDB;                \
+    DIM_STORE_A(ra0, 0) DIM_STORE_A(ra1, 1) DIM_STORE_A(ra2, 2) DIM_STORE_A(ra3, 3) \
+    DIM_STORE_B(rb0, 0) DIM_STORE_B(rb1, 1) DIM_STORE_B(rb2, 2) DIM_STORE_B(rb3, 3) \
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -163,9 +150,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (kc_begin < kc_end) {
-    load_chunk(kc_begin);
-    advance();
-    store_chunk(0);
+    DIM_LOAD_CHUNK(kc_begin)
+    DIM_ADVANCE()
+    DIM_STORE_CHUNK(0)
   }
   __syncthreads();
 
@@ -175,30 +162,47 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 
   int buf = 0;
   for (int kc = kc_begin; kc < kc_end; ++kc) {
-    const bool more = (kc + 1) < kc_end;
-    if (more) {
-      load_chunk(kc + 1);
-      advance();
-    }
-    const float* cA = sA + buf * BK * LDA;
-    const float* cB = sB + buf * BK * LDB;
+    // prefetch the next chunk into registers (the last iteration re-reads a clamped chunk: branch-free)
+    const int kn = min(kc + 1, a.nchunks - 1);
+    DIM_LOAD_CHUNK(kn)
+    DIM_ADVANCE()
+    __builtin_amdgcn_sched_barrier(0);  // keep the global prefetch AHEAD of the MFMA block (hipcc sinks it otherwise)
+    const float* cA = sA + buf * BK * LDA + khalf * LDA + a_row;
+    const float* cB = sB + buf * BK * LDB + khalf * LDB + b_col;
+    // fragment double buffer: LDS reads of k-step ks+1 are in flight under the MFMAs of k-step ks
+    float fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = cA[32 * i];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = cB[32 * j];
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      const int k = ks * 2 + khalf;
-      float fa[TM], fb[TN];
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = cA[k * LDA + a_row + 32 * i];
+        for (int i = 0; i < TM; ++i) fa[nxt][i] = cA[(ks + 1) * 2 * LDA + 32 * i];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = cB[k * LDB + b_col + 32 * j];
+        for (int j = 0; j < TN; ++j) fb[nxt][j] = cB[(ks + 1) * 2 * LDB + 32 * j];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // reads of step ks+1 issue BEFORE the MFMAs of step ks ...
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // ... and nothing is sunk below them
     }
-    if (more) store_chunk(buf ^ 1);
+    DIM_STORE_CHUNK(buf ^ 1)
     __syncthreads();
     buf ^= 1;
   }
+#undef DIM_LOAD_A
+#undef DIM_LOAD_B
+#undef DIM_LOAD_CHUNK
+#undef DIM_ADVANCE
+#undef DIM_STORE_A
+#undef DIM_STORE_B
+#undef DIM_STORE_CHUNK
 
   // ---- epilogue.  D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const bool final = gridDim.z == 1;
@@ -369,9 +373,20 @@ long dim_conv2d_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH,
   return (long)splits * N * Ho * Wo * Cout;
 }
 
+int dim_splitk_reduce(const float* slabs, const float* bias, float* y, long M, int Cout, int splits, float slope, void* stream) {
+  if (M == 0) return DIM_OK;
+  DIM_REQUIRE(slabs && y, "null pointer");
+  DIM_REQUIRE(Cout % 4 == 0 && splits >= 1, "bad geometry");
+  long MC = M * Cout;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MC / 4, 256)), dim3(256), 0, as_stream(stream), slabs, bias, y, MC, Cout,
+                     splits, slope, bias != nullptr);
+  return check_launch("splitk_reduce");
+}
+
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64
-int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
-                   int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile, void* stream) {
+static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
+                           int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile,
+                           int partial_only, void* stream) {
   if (N == 0) return DIM_OK;  // empty batch
   DIM_REQUIRE(x && w_packed && y, "null pointer");
   DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
@@ -384,6 +399,7 @@ int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, flo
   a.Ho = (H + 2 * pad - KH) / stride + 1;
   a.Wo = (W + 2 * pad - KW) / stride + 1;
   DIM_REQUIRE(a.Ho > 0 && a.Wo > 0, "empty output");
+  DIM_REQUIRE((long)N * H * W * Cin < (1L << 31), "input too large for 32-bit element offsets (%ld elements)", (long)N * H * W * Cin);
   a.M = N * a.Ho * a.Wo;
   a.nchunks = (Cin == 8) ? KH * 2 : KH * KW * (Cin / 32);
   if (splits < 1) splits = 1;
@@ -414,13 +430,20 @@ int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, flo
     else rc = launch_conv<64, 64, 2, 2, false>(a, splits, st);
   }
   if (rc != DIM_OK) return rc;
-  if (splits > 1) {
-    long MC = (long)a.M * Cout;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MC / 4, 256)), dim3(256), 0, st, workspace, bias, y, MC, Cout, splits,
-                       slope, a.has_bias);
-    return check_launch("splitk_reduce");
-  }
+  if (splits > 1 && !partial_only) return dim_splitk_reduce(workspace, bias, y, (long)a.M, Cout, splits, slope, stream);
   return DIM_OK;
+}
+
+int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
+                   int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile, void* stream) {
+  return conv2d_fwd_impl(x, w_packed, bias, y, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, slope, splits, tile, 0, stream);
+}
+
+int dim_conv2d_fwd_partial(const float* x, const float* w_packed, float* workspace, int N, int H, int W, int Cin, int Cout, int KH,
+                           int KW, int stride, int pad, int splits, int tile, void* stream) {
+  DIM_REQUIRE(splits > 1, "dim_conv2d_fwd_partial is the split-K first phase: splits must be > 1");
+  return conv2d_fwd_impl(x, w_packed, nullptr, workspace, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, 1.0f, splits, tile, 1,
+                         stream);
 }
 
 int dim_pose_head_fwd(const float* fc6, const float* fc7_w, const float* fc7_b, const float* rot_w, const float* rot_b,

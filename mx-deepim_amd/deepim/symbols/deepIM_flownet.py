@@ -161,7 +161,7 @@ class FlowNetHip(object):
         self.K = np.asarray(cfg.dataset.INTRINSIC_MATRIX, dtype=np.float32).reshape(3, 3)
         self.plane_means = np.asarray(cfg.network.PIXEL_MEANS, dtype=np.float32).reshape(3)[::-1].copy()
         # tile / split-K plan per layer: (tile, splits); 0 = library heuristic
-        self.conv_plan = {"fc6": (3, 160)}
+        self.conv_plan = {"fc6": (3, 40)}
         if conv_plan:
             self.conv_plan.update(conv_plan)
         B, H, W = batch_size, self.H, self.W
@@ -169,15 +169,21 @@ class FlowNetHip(object):
         self.acts = {}
         h, w, c = H, W, 8
         max_ws = 0
+        self.layer_info = {}  # name -> dict(M, K, N, flops, tile, splits) for profiling / roofline accounting
         for name, cout, k, s, p in ENCODER:
             ho, wo = ops.conv_out_hw(h, w, k, k, s, p)
             self.acts[name] = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=d)
-            tile, splits = self.conv_plan.get(name, (0, 1))
+            nchunks = k * 2 if c == 8 else k * k * (c // 32)
+            tile, splits = self.conv_plan.get(name, ops.conv_auto_plan(B * ho * wo, cout, nchunks))
+            self.conv_plan[name] = (tile, splits)
+            self.layer_info[name] = dict(M=B * ho * wo, K=c * k * k, N=cout, flops=2 * B * ho * wo * cout * c * k * k, tile=tile,
+                                         splits=splits, cin=c)
             if splits > 1:
                 max_ws = max(max_ws, ops.lib().dim_conv2d_workspace_floats(B, h, w, c, cout, k, k, s, p, splits))
             h, w, c = ho, wo, cout
         assert (h, w, c) == (8, 10, 1024)
         tile, splits = self.conv_plan["fc6"]
+        self.layer_info["fc6"] = dict(M=B, K=81920, N=256, flops=2 * B * 81920 * 256, tile=tile, splits=splits, cin=1024)
         max_ws = max(max_ws, ops.lib().dim_conv2d_workspace_floats(B, 8, 10, 1024, 256, 8, 10, 1, 0, splits))
         self.workspace = torch.empty((max(max_ws, 4),), dtype=torch.float32, device=d)
         self.fc6 = torch.empty((B, 1, 1, 256), dtype=torch.float32, device=d)
@@ -201,16 +207,51 @@ class FlowNetHip(object):
                            self.zoom_factor, self.plane_means, X=self.X, nchw_out=nchw_out)
         return self.X
 
-    def encoder(self, X=None):
+    def encoder(self, X=None, events=None):
+        """events: optional dict layer-name -> list of (tag, start, end) HIP-event triples (see ops.conv2d_fwd)."""
         x = self.X if X is None else X
         for name, cout, k, s, p in ENCODER:
-            tile, splits = self.conv_plan.get(name, (0, 1))
-            x = ops.conv2d_fwd(x, self.packed[name], self.params[name + "_bias"], cout, k, k, s, p, slope=0.1, splits=splits,
-                               tile=tile, out=self.acts[name], workspace=self.workspace)
+            tile, splits = self.conv_plan[name]
+            x = ops.conv2d_fwd(x, self.packed[name], self.params[name + "_bias"], cout, k, k, s, p, slope=0.1, splits=splits, tile=tile,
+                               out=self.acts[name], workspace=self.workspace,
+                               events=None if events is None else events.setdefault(name, []))
         tile, splits = self.conv_plan["fc6"]
         ops.conv2d_fwd(x, self.packed["fc6"], self.params["fc6_bias"], 256, 8, 10, 1, 0, slope=0.1, splits=splits, tile=tile,
-                       out=self.fc6, workspace=self.workspace)
+                       out=self.fc6, workspace=self.workspace, events=None if events is None else events.setdefault("fc6", []))
         return self.fc6
+
+    def autotune(self, tiles=(1, 2, 3), split_choices=(1, 2, 3, 4, 6, 8), reps=3):
+        """Pick (tile, splits) per layer by timing the candidates on this GPU (HIP events on the launch stream).
+        Only speed changes: split-K alters the f32 summation order (|delta| ~1e-6 relative), nothing else."""
+        x = self.X
+        layers = [(n, co, k, k, s, p, self.params[n + "_bias"], self.acts[n]) for n, co, k, s, p in ENCODER]
+        layers.append(("fc6", 256, 8, 10, 1, 0, self.params["fc6_bias"], self.fc6))
+        for name, cout, kh, kw, s, p, bias, out in layers:
+            N, H, W, C = x.shape
+            cands = [(t, sp) for t in tiles for sp in (split_choices if name != "fc6" else (20, 40, 80, 160)) if not (t == 1 and cout % 128)]
+            best = None
+            for t, sp in cands:
+                ws_need = ops.lib().dim_conv2d_workspace_floats(N, H, W, C, cout, kh, kw, s, p, sp)
+                if ws_need > self.workspace.numel():
+                    self.workspace = torch.empty((ws_need,), dtype=torch.float32, device=self.device)
+                run = lambda: ops.conv2d_fwd(x, self.packed[name], bias, cout, kh, kw, s, p, slope=0.1, splits=sp, tile=t, out=out,  # noqa: E731
+                                             workspace=self.workspace)
+                run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    run()
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                if best is None or ms < best[0]:
+                    best = (ms, t, sp)
+            self.conv_plan[name] = (best[1], best[2])
+            self.layer_info[name]["tile"], self.layer_info[name]["splits"] = best[1], best[2]
+            ops.conv2d_fwd(x, self.packed[name], bias, cout, kh, kw, s, p, slope=0.1, splits=best[2], tile=best[1], out=out,
+                           workspace=self.workspace)
+            x = out
+        return dict(self.conv_plan)
 
     def head(self):
         return ops.pose_head_fwd(self.fc6.view(self.B, 256), self.params, self.zoom_factor, se3=self.se3, fc7_out=self.fc7)

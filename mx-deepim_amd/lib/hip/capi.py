@@ -38,6 +38,8 @@ SIGNATURES = {
     "dim_conv2d_pack_weight": (I, [P, P, I, I, I, I, P]),
     "dim_conv2d_workspace_floats": (L, [I, I, I, I, I, I, I, I, I, I]),
     "dim_conv2d_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, P]),
+    "dim_conv2d_fwd_partial": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dim_splitk_reduce": (I, [P, P, P, L, I, I, F, P]),
     "dim_fc_pack_weight": (I, [P, P, I, I, I, I, P]),
     "dim_pose_head_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, P]),
 }

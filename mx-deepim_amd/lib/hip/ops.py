@@ -143,12 +143,45 @@ def conv_out_hw(H, W, KH, KW, stride, pad):
     return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
 
 
-def conv2d_fwd(x_nhwc, w_packed, bias, Cout, KH, KW, stride, pad, slope=0.1, splits=1, tile=0, out=None, workspace=None):
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64"}
+
+
+def conv_auto_plan(M, Cout, nchunks):
+    """default (tile, splits) when the caller does not autotune: 64x64 workgroup tiles (measured best or tied on every
+    encoder layer at batch 16 on MI355X), split-K until the grid has ~2048 workgroups (8 per CU)."""
+    blocks = -(-M // 64) * (Cout // 64)
+    splits = max(1, min(8, int(round(2048.0 / blocks)), nchunks))
+    return 3, splits
+
+
+def conv2d_fwd(x_nhwc, w_packed, bias, Cout, KH, KW, stride, pad, slope=0.1, splits=1, tile=0, out=None, workspace=None,
+               events=None):
+    """events: optional list; when given, (kernel_tag, start_event, end_event) tuples are appended with HIP events recorded on the
+    launch stream around the conv kernel and (split-K) around the reduce kernel separately."""
     N, H, W, Cin = x_nhwc.shape
     Ho, Wo = conv_out_hw(H, W, KH, KW, stride, pad)
     out = out if out is not None else _new((N, Ho, Wo, Cout), x_nhwc)
     if splits > 1 and workspace is None:
         workspace = _new((lib().dim_conv2d_workspace_floats(N, H, W, Cin, Cout, KH, KW, stride, pad, splits),), x_nhwc)
+    if events is not None:
+        def ev():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        e0 = ev()
+        if splits > 1:
+            check(lib().dim_conv2d_fwd_partial(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(workspace, f32), N, H, W, Cin, Cout, KH, KW,
+                                               stride, pad, splits, tile, current_stream()))
+            e1 = ev()
+            check(lib().dim_splitk_reduce(dptr(workspace, f32), dptr(bias, f32), dptr(out, f32), N * Ho * Wo, Cout, splits, float(slope),
+                                          current_stream()))
+            e2 = ev()
+            events += [("conv", e0, e1), ("reduce", e1, e2)]
+        else:
+            check(lib().dim_conv2d_fwd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), dptr(workspace, f32), N,
+                                       H, W, Cin, Cout, KH, KW, stride, pad, float(slope), splits, tile, current_stream()))
+            events.append(("conv", e0, ev()))
+        return out
     check(lib().dim_conv2d_fwd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), dptr(workspace, f32), N, H, W,
                                Cin, Cout, KH, KW, stride, pad, float(slope), splits, tile, current_stream()))
     return out

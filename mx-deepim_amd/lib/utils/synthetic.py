@@ -152,3 +152,36 @@ def compose_observed(bgr_render, depth_render, rng):
     bg = rng.integers(0, 256, size=bgr_render.shape).astype(np.float32)
     fg = (depth_render > 0)[..., None]
     return np.where(fg, bgr_render, bg).astype(np.uint8)
+
+
+def build_device_batch(render_machine, B, seed, n_classes=1, pixel_means=PIXEL_MEANS, device="cuda:0"):
+    """Synthetic test batch built ON the GPU with the HIP rasteriser (bench / smoke inputs):
+    observed = render at the GT pose over seeded uniform noise, uint8-quantised; rendered = render at the
+    perturbed pose; mask_rendered = depth > 0.2; mask_observed = bbox rectangle of it (TEST.INIT_MASK box_rendered).
+    Returns dict of CUDA tensors with the reference's blob names + pose_gt."""
+    import torch
+
+    from lib.hip import ops
+
+    d = torch.device(device)
+    cls, gt, init = sample_pairs(seed, B, n_classes)
+    H, W = render_machine.height, render_machine.width
+    pm = plane_means(pixel_means)
+    cls_t = torch.from_numpy(cls).to(d)
+    img = torch.empty((B, 3, H, W), device=d)
+    depth = torch.empty((B, 1, H, W), device=d)
+    render_machine.render_batch(cls_t, torch.from_numpy(gt).to(d), image=img, depth=depth, plane_means=pm)
+    g = torch.Generator(device=d)
+    g.manual_seed(seed)
+    noise = torch.randint(0, 256, (B, 3, H, W), generator=g, device=d).float() - torch.from_numpy(pm).to(d).view(1, 3, 1, 1)
+    image_observed = torch.where(depth > 0, img, noise).contiguous()
+    image_rendered = torch.empty((B, 3, H, W), device=d)
+    mask_rendered = torch.empty((B, 1, H, W), device=d)
+    mask_observed = torch.empty((B, 1, H, W), device=d)
+    bbox = torch.empty((B, 4), dtype=torch.int32, device=d)
+    render_machine.render_batch(cls_t, torch.from_numpy(init).to(d), image=image_rendered, depth=depth, mask=mask_rendered, bbox=bbox,
+                                plane_means=pm)
+    ops.box_mask(bbox, mask_observed)
+    return {"image_observed": image_observed, "image_rendered": image_rendered, "mask_observed": mask_observed,
+            "mask_rendered": mask_rendered, "src_pose": torch.from_numpy(init).to(d), "class_index": cls_t,
+            "pose_gt": torch.from_numpy(gt).to(d)}
