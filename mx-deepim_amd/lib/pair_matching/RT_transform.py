@@ -1,0 +1,42 @@
+"""SE(3) pose parameterisation of DeepIM on the HIP kernels.
+
+Same function names as /root/reference/lib/pair_matching/RT_transform.py (`RT_transform` :135-161, `calc_RT_delta` :16-48)
+for single 3x4 numpy poses, plus the batched device forms the refinement loop and the training updater use
+(`RT_transform_batch`, `calc_RT_delta_batch`).  Arithmetic is float64 inside the kernel (csrc/se3.hip), inputs/outputs float32.
+"""
+import numpy as np
+import torch
+
+from lib.hip import ops
+
+
+def RT_transform_batch(pose_src, se3, T_means, T_stds, rot_coord="MODEL", out=None, out_f64=None):
+    """pose_src (B,3,4), se3 (B,7) = [quat (raw), trans] CUDA f32 -> (B,3,4)."""
+    return ops.se3_compose(pose_src, se3, rot_coord, T_means, T_stds, out=out, out_f64=out_f64)
+
+
+def calc_RT_delta_batch(pose_src, pose_tgt, T_means, T_stds, rot_coord="MODEL"):
+    """-> (quat (B,4) with w >= 0, trans (B,3)); rot_type 'QUAT' of the reference."""
+    return ops.se3_delta(pose_src, pose_tgt, rot_coord, T_means, T_stds)
+
+
+def _dev(a, device):
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).to(device)
+
+
+def RT_transform(pose_src, r, t, T_means, T_stds, rot_coord="MODEL", device="cuda:0"):
+    r = np.squeeze(r)
+    if r.shape[0] != 4:
+        raise Exception("Unknown r shape: {}".format(r.shape)) if r.shape[0] != 3 else Exception("EULER deltas are not on the HIP path")
+    se3 = np.concatenate([r, np.squeeze(t)]).reshape(1, 7)
+    out64 = torch.empty((1, 3, 4), dtype=torch.float64, device=device)
+    RT_transform_batch(_dev(np.asarray(pose_src).reshape(1, 3, 4), device), _dev(se3, device), T_means, T_stds, rot_coord, out_f64=out64)
+    return out64[0].cpu().numpy()
+
+
+def calc_RT_delta(pose_src, pose_tgt, T_means, T_stds, rot_coord="MODEL", rot_type="MATRIX", device="cuda:0"):
+    if rot_type.lower() != "quat":
+        raise Exception("HIP path implements rot_type 'QUAT' (the only one the training labels use); got {}".format(rot_type))
+    q, t = calc_RT_delta_batch(_dev(np.asarray(pose_src).reshape(1, 3, 4), device), _dev(np.asarray(pose_tgt).reshape(1, 3, 4), device),
+                               T_means, T_stds, rot_coord)
+    return q[0].cpu().numpy(), t[0].cpu().numpy()
