@@ -2,14 +2,15 @@
 //
 // Replaces the cuDNN Convolution / FullyConnected calls of the reference's FlowNetS encoder
 // (/root/reference/deepim/symbols/deepIM_flownet.py:67-208).  Activations are NHWC fp32 in HBM,
-// weights are pre-packed once into [K = (kh,kw,cin)][Cout]; the kernel is an implicit GEMM
+// weights are pre-packed once into [K/32 chunks][Cout][32] with K = (kh,kw,cin); the kernel is an implicit GEMM
 //     Y[m = (n,ho,wo)][co] = sum_k X[n, ho*s-p+kh, wo*s-p+kw, c] * Wp[k][co]
 // with a 32-deep K chunk that is one tap x 32 channels (Cin % 32 == 0) or, for the 8-channel
 // first layer, four horizontally adjacent taps x 8 channels (= 32 contiguous floats in HBM).
 //
 // Block = 256 threads = 4 waves; wave tile = (BM/WM) x (BN/WN) in 32x32 MFMA tiles.
-// LDS: A chunk stored K-major [32][BM+1] (transposed while staging, conflict-free both ways),
-//      B chunk [32][BN+4]; two buffers, register prefetch of chunk k+1 under the MFMAs of chunk k.
+// LDS: A chunk [BM][32+4] and B chunk [BN][32+4], both k-contiguous: staged with one ds_write_b128 per float4 and read
+//      back as ds_read_b128 = four k-steps of MFMA operands per LDS instruction (the k order inside a chunk is permuted
+//      identically for A and B); two buffers, register prefetch of chunk k+1 under the MFMAs of chunk k.
 // Epilogue: bias + LeakyReLU fused; with gridDim.z > 1 (split-K) raw partials go to a slab
 // and dim_splitk_reduce finishes (deterministic, no atomics).
 #include "common.h"
@@ -36,18 +37,16 @@ struct ConvArgs {
 template <int BM, int BN, int WM, int WN, bool CIN8>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   constexpr int BK = 32;
-  constexpr int LDA = BM + 1;
-  constexpr int LDB = BN + 4;
+  constexpr int LDK = BK + 4;       // row stride (floats): 16 rows x 4 dwords hit 16 distinct 4-bank slots for ds_read_b128
   constexpr int TM = BM / WM / 32;  // MFMA tiles per wave along M
   constexpr int TN = BN / WN / 32;
   constexpr int A_PER_T = BM / 32;  // float4 loads per thread for the A chunk
   constexpr int B_PER_T = BN / 32;
-  constexpr int B_ROWS_PER_PASS = 256 / (BN / 4);
   static_assert(WM * WN == 4, "4 waves");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                       // [2][BK][LDA]
-  float* sB = smem + 2 * BK * LDA;        // [2][BK][LDB]  (2*BK*LDA*4 bytes is a multiple of 16)
+  float* sA = smem;                       // [2][BM][LDK]   pixel-major, k contiguous
+  float* sB = smem + 2 * BM * LDK;        // [2][BN][LDK]   channel-major, k contiguous
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -60,13 +59,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const int kc_begin = split * a.chunks_per_split;
   const int kc_end = min(a.nchunks, kc_begin + a.chunks_per_split);
 
-  // ---- per-thread A-load descriptors (fixed pixels for the whole K loop); element offsets fit int32
-  // (host checks N*H*W*Cin < 2^31)
-  const int q = tid & 7;                  // float4 index inside the 32-float chunk
+  // ---- per-thread staging descriptors: thread (q, srow) moves float4 #q of row srow (+32 per pass) for A and for B
+  const int q = tid & 7;
+  const int srow = tid >> 3;
   int a_hi0[A_PER_T], a_wi0[A_PER_T], a_base[A_PER_T];
 #pragma unroll
   for (int i = 0; i < A_PER_T; ++i) {
-    int m = m0 + (tid >> 3) + 32 * i;
+    int m = m0 + srow + 32 * i;
     bool ok = m < a.M;
     int mm = ok ? m : 0;
     int wo = mm % a.Wo;
@@ -75,13 +74,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     int n = t / a.Ho;
     a_hi0[i] = ok ? ho * a.stride - a.pad : -(1 << 28);  // rows past M: every tap fails the bounds test
     a_wi0[i] = wo * a.stride - a.pad;
-    a_base[i] = n * a.H * a.W * a.Cin + (CIN8 ? (q & 1) * 4 : q * 4);
+    a_base[i] = n * a.H * a.W * a.Cin + (CIN8 ? (q & 1) * 4 : q * 4);  // element offsets fit int32 (host-checked)
   }
-  // ---- B-load mapping
-  const int b_n4 = tid % (BN / 4);
-  const int b_k = tid / (BN / 4);
-  const float* wbase = a.w + n0 + b_n4 * 4 + (long)b_k * a.Cout;
-  const int wrow_stride = B_ROWS_PER_PASS * a.Cout;
+  const float* wbase = a.w + ((long)(n0 + srow) * BK + q * 4);  // packed [chunk][Cout][32]
+  const long wchunk = (long)a.Cout * BK;
 
   // chunk -> (kh, kw, c0) counters
   int kh, kw, c0;
@@ -97,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     kw = tap - kh * a.KW;
   }
 
-  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // named registers: arrays + lambdas ended up in scratch
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // named registers (arrays + lambdas ended up in scratch)
 
 #define DIM_LOAD_A(REG, I)                                                                                   \
   if (I < A_PER_T) {                                                                                          \
@@ -108,11 +104,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     REG = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);                 \
   }
 #define DIM_LOAD_B(REG, I) \
-  if (I < B_PER_T) REG = *reinterpret_cast<const float4*>(wsrc + I * wrow_stride);
+  if (I < B_PER_T) REG = *reinterpret_cast<const float4*>(wsrc + I * 32 * BK);
 #define DIM_LOAD_CHUNK(KC)                                       \
   {                                                              \
     DIM_LOAD_A(ra0, 0) DIM_LOAD_A(ra1, 1) DIM_LOAD_A(ra2, 2) DIM_LOAD_A(ra3, 3) \
-    const float* wsrc = wbase + (long)(KC) * BK * a.Cout;        \
+    const float* wsrc = wbase + (long)(KC) * wchunk;             \
     DIM_LOAD_B(rb0, 0) DIM_LOAD_B(rb1, 1) DIM_LOAD_B(rb2, 2) DIM_LOAD_B(rb3, 3) \
   }
 #define DIM_ADVANCE()                        \
@@ -126,17 +122,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       if (++kw == a.KW) { kw = 0; ++kh; }    \
     }                                        \
   }
-#define DIM_STORE_A(REG, I)                        \
-  if (I < A_PER_T) {                               \
-    float* d = dA + (q * 4) * LDA + (tid >> 3) + 32 * I; \
-    d[0] = REG.x; d[LDA] = REG.y; d[2 * LDA] = REG.z; d[3 * LDA] = REG.w; \
-  }
+#define DIM_STORE_A(REG, I) \
+  if (I < A_PER_T) *reinterpret_cast<float4*>(dA + (srow + 32 * I) * LDK + q * 4) = REG;
 #define DIM_STORE_B(REG, I) \
-  if (I < B_PER_T) *reinterpret_cast<float4*>(dB + (b_k + B_ROWS_PER_PASS * I) * LDB + b_n4 * 4) = REG;
+  if (I < B_PER_T) *reinterpret_cast<float4*>(dB + (srow + 32 * I) * LDK + q * 4) = REG;
 #define DIM_STORE_CHUNK(BUF)                          \
   {                                                   \
-    float* dA = sA + (BUF) * BK * LDA;                \
-    float* dB = sB + (BUF) * BK * LDB;                \
+    float* dA = sA + (BUF) * BM * LDK;                \
+    float* dB = sB + (BUF) * BN * LDK;                \
     DIM_STORE_A(ra0, 0) DIM_STORE_A(ra1, 1) DIM_STORE_A(ra2, 2) DIM_STORE_A(ra3, 3) \
     DIM_STORE_B(rb0, 0) DIM_STORE_B(rb1, 1) DIM_STORE_B(rb2, 2) DIM_STORE_B(rb3, 3) \
   }
@@ -156,40 +149,50 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   }
   __syncthreads();
 
-  const int a_row = wm * (BM / WM) + (lane & 31);
-  const int b_col = wn * (BN / WN) + (lane & 31);
+  // fragment addressing: lane (half h, row r) reads 4 consecutive k = 8s + 4h + {0..3} of its row with one ds_read_b128;
+  // MFMA #j of group s then contracts k = 8s + j (lanes 0-31) and k = 8s + 4 + j (lanes 32-63): every k of the chunk
+  // is used exactly once, identically for A and B.
+  const int frow = lane & 31;
   const int khalf = lane >> 5;
+  const int a_off = (wm * (BM / WM) + frow) * LDK + 4 * khalf;
+  const int b_off = (wn * (BN / WN) + frow) * LDK + 4 * khalf;
 
   int buf = 0;
   for (int kc = kc_begin; kc < kc_end; ++kc) {
+    const float* cA = sA + buf * BM * LDK + a_off;
+    const float* cB = sB + buf * BN * LDK + b_off;
+    float4 fa[2][TM], fb[2][TN];
+    // first fragments of this chunk go out before anything else: their LDS latency hides under the address arithmetic
+    // of the global prefetch below
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float4*>(cA + 32 * i * LDK);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float4*>(cB + 32 * j * LDK);
+    __builtin_amdgcn_sched_barrier(0);
     // prefetch the next chunk into registers (the last iteration re-reads a clamped chunk: branch-free)
     const int kn = min(kc + 1, a.nchunks - 1);
     DIM_LOAD_CHUNK(kn)
     DIM_ADVANCE()
     __builtin_amdgcn_sched_barrier(0);  // keep the global prefetch AHEAD of the MFMA block (hipcc sinks it otherwise)
-    const float* cA = sA + buf * BK * LDA + khalf * LDA + a_row;
-    const float* cB = sB + buf * BK * LDB + khalf * LDB + b_col;
-    // fragment double buffer: LDS reads of k-step ks+1 are in flight under the MFMAs of k-step ks
-    float fa[2][TM], fb[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = cA[32 * i];
+    for (int s = 0; s < BK / 8; ++s) {
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s + 1 < BK / 8) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = cB[32 * j];
+        for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const float4*>(cA + 32 * i * LDK + 8 * (s + 1));
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks + 1 < BK / 2) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[nxt][i] = cA[(ks + 1) * 2 * LDA + 32 * i];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nxt][j] = cB[(ks + 1) * 2 * LDB + 32 * j];
+        for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const float4*>(cB + 32 * j * LDK + 8 * (s + 1));
       }
-      __builtin_amdgcn_sched_barrier(0);  // reads of step ks+1 issue BEFORE the MFMAs of step ks ...
+      __builtin_amdgcn_sched_barrier(0);  // reads of group s+1 issue BEFORE the MFMAs of group s ...
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
+        }
       __builtin_amdgcn_sched_barrier(0);  // ... and nothing is sunk below them
     }
     DIM_STORE_CHUNK(buf ^ 1)
@@ -205,24 +208,42 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #undef DIM_STORE_CHUNK
 
   // ---- epilogue.  D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // Full tiles take a branch-free path: with a per-store `if (m < M)` hipcc put `s_waitcnt vmcnt(0)` in front of every
+  // predicated store (the bias load keeps the counter "unknown" across the branches), serialising 16 store round trips
+  // per wave.
   const bool final = gridDim.z == 1;
-  float* out = final ? a.y : a.y + (long)split * a.M * a.Cout;
+  float* out = (final ? a.y : a.y + (long)split * a.M * a.Cout) + (long)(m0 + wm * (BM / WM) + 4 * khalf) * a.Cout + n0 +
+               wn * (BN / WN) + frow;
+  float bv[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + b_col + 32 * j;
-    const float bv = (final && a.has_bias) ? a.bias[n] : 0.f;
+  for (int j = 0; j < TN; ++j) bv[j] = (final && a.has_bias) ? a.bias[n0 + wn * (BN / WN) + frow + 32 * j] : 0.f;
+  const float slope = final ? a.slope : 1.0f;
+  if (m0 + BM <= a.M) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (m < a.M) {
-          float v = acc[i][j][r] + bv;
-          if (final) v = v > 0.f ? v : v * a.slope;
-          out[(long)m * a.Cout + n] = v;
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv[j];
+          v = v > 0.f ? v : v * slope;
+          out[(long)(32 * i + (r & 3) + 8 * (r >> 2)) * a.Cout + 32 * j] = v;
         }
-      }
-    }
+  } else {
+    const int mrow = m0 + wm * (BM / WM) + 4 * khalf;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = 32 * i + (r & 3) + 8 * (r >> 2);
+          if (mrow + dm < a.M) {
+            float v = acc[i][j][r] + bv[j];
+            v = v > 0.f ? v : v * slope;
+            out[(long)dm * a.Cout + 32 * j] = v;
+          }
+        }
   }
 }
 
@@ -248,15 +269,16 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const floa
   *reinterpret_cast<float4*>(y + i) = s;
 }
 
-// OIHW (MXNet / reference layout) -> packed [chunk][32][Cout]
+// OIHW (MXNet / reference layout) -> packed [chunk][Cout][32]  (a workgroup's B chunk is one contiguous block)
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KH, int KW,
                                         int nchunks, int cin8) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)nchunks * 32 * Cout;
   if (idx >= total) return;
-  int co = (int)(idx % Cout);
-  long kk = idx / Cout;
-  int kc = (int)(kk / 32), kin = (int)(kk % 32);
+  int kin = (int)(idx % 32);
+  long t = idx / 32;
+  int co = (int)(t % Cout);
+  int kc = (int)(t / Cout);
   int kh, kw, c;
   if (cin8) {
     kh = kc >> 1;
@@ -275,13 +297,15 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
 }
 
 // FullyConnected weight (out, in) with `in` flattened (c,h,w) [mx Flatten of NCHW] -> packed
-// [k = (h,w,c)][out] so that fc6 runs through conv_fwd_kernel on the NHWC conv6_1 output.
+// [chunk][out][32] with k = (h,w,c) so that fc6 runs through conv_fwd_kernel on the NHWC conv6_1 output.
 __global__ void pack_fc_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Out, int C, int H, int W) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)Out * C * H * W;
   if (idx >= total) return;
-  int o = (int)(idx % Out);
-  long k = idx / Out;
+  int kin = (int)(idx % 32);
+  long t = idx / 32;
+  int o = (int)(t % Out);
+  long k = (t / Out) * 32 + kin;
   int c = (int)(k % C);
   long hw = k / C;
   wp[idx] = w[(long)o * C * H * W + (long)c * H * W + hw];
@@ -323,7 +347,7 @@ __global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict_
 
 template <int BM, int BN, int WM, int WN, bool CIN8>
 static int launch_conv(const ConvArgs& a, int splits, hipStream_t st) {
-  constexpr size_t lds = (2 * 32 * (BM + 1) + 2 * 32 * (BN + 4)) * sizeof(float);
+  constexpr size_t lds = (size_t)2 * (BM + BN) * (32 + 4) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<BM, BN, WM, WN, CIN8>),
