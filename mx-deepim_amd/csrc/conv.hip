@@ -2,7 +2,7 @@
 //
 // Replaces the cuDNN Convolution / FullyConnected calls of the reference's FlowNetS encoder
 // (/root/reference/deepim/symbols/deepIM_flownet.py:67-208).  Activations are NHWC fp32 in HBM,
-// weights are pre-packed once into [K/32 chunks][Cout][32] with K = (kh,kw,cin); the kernel is an implicit GEMM
+// weights are pre-packed once into [K/32 chunks][Cout][32] (chunk order: 32-channel slice outer, taps inner); implicit GEMM
 //     Y[m = (n,ho,wo)][co] = sum_k X[n, ho*s-p+kh, wo*s-p+kw, c] * Wp[k][co]
 // with a 32-deep K chunk that is one tap x 32 channels (Cin % 32 == 0) or, for the 8-channel
 // first layer, four horizontally adjacent taps x 8 channels (= 32 contiguous floats in HBM).
@@ -34,6 +34,8 @@ struct ConvArgs {
   int has_bias;
 };
 
+__device__ const float4 g_zero16 = {0.f, 0.f, 0.f, 0.f};  // source of padding taps
+
 template <int BM, int BN, int WM, int WN, bool CIN8>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   constexpr int BK = 32;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   // ---- per-thread staging descriptors: thread (q, srow) moves float4 #q of row srow (+32 per pass) for A and for B
   const int q = tid & 7;
   const int srow = tid >> 3;
-  int a_hi0[A_PER_T], a_wi0[A_PER_T], a_base[A_PER_T];
+  int a_hi0[A_PER_T], a_wi0[A_PER_T], a_pix[A_PER_T];
 #pragma unroll
   for (int i = 0; i < A_PER_T; ++i) {
     int m = m0 + srow + 32 * i;
@@ -73,8 +75,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     int ho = t % a.Ho;
     int n = t / a.Ho;
     a_hi0[i] = ok ? ho * a.stride - a.pad : -(1 << 28);  // rows past M: every tap fails the bounds test
-    a_wi0[i] = wo * a.stride - a.pad;
-    a_base[i] = n * a.H * a.W * a.Cin + (CIN8 ? (q & 1) * 4 : q * 4);  // element offsets fit int32 (host-checked)
+    a_wi0[i] = wo * a.stride - a.pad + (CIN8 ? (q >> 1) : 0);
+    // element offset of this thread's float4 at tap (0,0), channel 0 (may be negative in the padding; int32, host-checked).
+    // For the 8-channel layer the 4 taps of a chunk are contiguous in memory, so "+ q*4" covers tap and channel half.
+    a_pix[i] = (n * a.H + a_hi0[i]) * a.W * a.Cin + (wo * a.stride - a.pad) * a.Cin + q * 4;
   }
   const float* wbase = a.w + ((long)(n0 + srow) * BK + q * 4);  // packed [chunk][Cout][32]
   const long wchunk = (long)a.Cout * BK;
@@ -86,27 +90,34 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     kw = (kc_begin & 1) * 4;
     c0 = 0;
   } else {
-    int cpt = a.Cin >> 5;
-    int tap = kc_begin / cpt;
-    c0 = (kc_begin - tap * cpt) << 5;
+    // K order for Cin % 32 == 0: 32-channel slice OUTER, taps INNER -- consecutive chunks read the same channels at the
+    // (kh,kw)-shifted pixels, i.e. mostly the same cache lines (reuse distance 1 chunk instead of Cin/32 chunks).
+    // With taps outer the L2 hit rate of conv3_1 was 50 % (rocprofv3 TCC_HIT/TCC_MISS): every tap re-fetched its
+    // activations from beyond L2.
+    int taps = a.KH * a.KW;
+    int cc = kc_begin / taps;
+    int tap = kc_begin - cc * taps;
+    c0 = cc << 5;
     kh = tap / a.KW;
     kw = tap - kh * a.KW;
   }
 
   float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // named registers (arrays + lambdas ended up in scratch)
 
-#define DIM_LOAD_A(REG, I)                                                                                   \
-  if (I < A_PER_T) {                                                                                          \
-    int hi = a_hi0[I] + kh;                                                                                   \
-    int wi = a_wi0[I] + kw + (CIN8 ? (q >> 1) : 0);                                                           \
-    bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && (!CIN8 || kw + (q >> 1) < a.KW); \
-    int off = a_base[I] + (hi * a.W + wi) * a.Cin + c0;                                                       \
-    REG = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);                 \
+  // padding taps read a 16-byte zero block instead of branching around the load (address select, no exec juggling);
+  // tap_off is wave-uniform (scalar): one vector add per load
+#define DIM_LOAD_A(REG, I)                                                                                         \
+  if (I < A_PER_T) {                                                                                                \
+    bool ok = (unsigned)(a_hi0[I] + kh) < (unsigned)a.H && (unsigned)(a_wi0[I] + kw) < (unsigned)a.W &&             \
+              (!CIN8 || kw + (q >> 1) < a.KW);                                                                      \
+    const float* src = ok ? a.x + (a_pix[I] + tap_off) : reinterpret_cast<const float*>(&g_zero16);                 \
+    REG = *reinterpret_cast<const float4*>(src);                                                                    \
   }
 #define DIM_LOAD_B(REG, I) \
   if (I < B_PER_T) REG = *reinterpret_cast<const float4*>(wsrc + I * 32 * BK);
 #define DIM_LOAD_CHUNK(KC)                                       \
   {                                                              \
+    const int tap_off = (kh * a.W + kw) * a.Cin + c0;            \
     DIM_LOAD_A(ra0, 0) DIM_LOAD_A(ra1, 1) DIM_LOAD_A(ra2, 2) DIM_LOAD_A(ra3, 3) \
     const float* wsrc = wbase + (long)(KC) * wchunk;             \
     DIM_LOAD_B(rb0, 0) DIM_LOAD_B(rb1, 1) DIM_LOAD_B(rb2, 2) DIM_LOAD_B(rb3, 3) \
@@ -116,10 +127,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     kw += 4;                                 \
     if (kw >= 8) { kw = 0; ++kh; }           \
   } else {                                   \
-    c0 += 32;                                \
-    if (c0 == a.Cin) {                       \
-      c0 = 0;                                \
-      if (++kw == a.KW) { kw = 0; ++kh; }    \
+    if (++kw == a.KW) {                      \
+      kw = 0;                                \
+      if (++kh == a.KH) { kh = 0; c0 += 32; } \
     }                                        \
   }
 #define DIM_STORE_A(REG, I) \
@@ -285,9 +295,10 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
     kw = (kc & 1) * 4 + (kin >> 3);
     c = kin & 7;
   } else {
-    int cpt = Cin >> 5;
-    int tap = kc / cpt;
-    c = (kc - tap * cpt) * 32 + kin;
+    int taps = KH * KW;
+    int cc = kc / taps;
+    int tap = kc - cc * taps;
+    c = cc * 32 + kin;
     kh = tap / KW;
     kw = tap - kh * KW;
   }
@@ -297,7 +308,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
 }
 
 // FullyConnected weight (out, in) with `in` flattened (c,h,w) [mx Flatten of NCHW] -> packed
-// [chunk][out][32] with k = (h,w,c) so that fc6 runs through conv_fwd_kernel on the NHWC conv6_1 output.
+// [chunk][out][32] with chunk = (32-channel slice, h, w) so that fc6 runs through conv_fwd_kernel on the NHWC conv6_1 output.
 __global__ void pack_fc_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Out, int C, int H, int W) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)Out * C * H * W;
@@ -305,9 +316,9 @@ __global__ void pack_fc_weight_kernel(const float* __restrict__ w, float* __rest
   int kin = (int)(idx % 32);
   long t = idx / 32;
   int o = (int)(t % Out);
-  long k = (t / Out) * 32 + kin;
-  int c = (int)(k % C);
-  long hw = k / C;
+  long kc = t / Out;                       // chunk = (channel slice, tap) with the tap (h,w) fastest, as in the conv kernel
+  int c = (int)(kc / ((long)H * W)) * 32 + kin;
+  long hw = kc % ((long)H * W);
   wp[idx] = w[(long)o * C * H * W + (long)c * H * W + hw];
 }
 
