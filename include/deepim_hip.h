@@ -118,6 +118,31 @@ int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, flo
 int dim_conv2d_fwd_partial(const float* x, const float* w_packed, float* workspace, int N, int H, int W, int Cin, int Cout, int KH,
                            int KW, int stride, int pad, int splits, int tile, void* stream);
 int dim_splitk_reduce(const float* slabs, const float* bias, float* y, long M, int Cout, int splits, float slope, void* stream);
+/* generalised dim_conv2d_fwd (no split-K): input pixel stride `in_cstride` (>= Cin), output written at channel offset
+ * `out_coff` of rows `out_cstride` wide (concat buffers), and -- when osy > 0 -- scattered to
+ * (oy,ox) = (ho*osy + ooy, wo*osx + oox) inside an OH x OW map (used for the phases of a deconvolution + Crop). */
+int dim_conv2d_fwd_ex(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int in_cstride,
+                      int Cout, int KH, int KW, int stride, int pad, float slope, int tile, int out_cstride, int out_coff, int OH,
+                      int OW, int osy, int osx, int ooy, int oox, void* stream);
+/* Decoder (deepIM_flownet.py:213-299): y[..., out_coff:out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x, k=4, s=2, p=0) + bias,
+ * offset=(crop,crop))) as four 2x2 sub-pixel convolutions on the MFMA kernel.  Weight: MXNet layout (Cin, Cout, 4, 4). */
+long dim_deconv4x4s2_packed_weight_floats(int Cin, int Cout);
+int dim_deconv4x4s2_pack_weight(const float* w_iohw, float* w_packed, int Cin, int Cout, void* stream);
+int dim_deconv4x4s2_fwd(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin,
+                        int in_cstride, int Cout, int OH, int OW, int crop, float slope, int out_cstride, int out_coff, int tile,
+                        void* stream);
+/* same operator for a tiny channel count (upsample_flow6to5 / 5to4, 2 -> 2), direct; weight in MXNet layout, unpacked */
+int dim_deconv4x4s2_tiny_fwd(const float* x, const float* w_iohw, const float* bias, float* y, int N, int H, int W, int Cin,
+                             int in_cstride, int Cout, int OH, int OW, int crop, int out_cstride, int out_coff, void* stream);
+/* 3x3 (any KHxKW, stride 1) convolution to 1 or 2 channels (Convolution1/2/3, mask_conv3), no activation.
+ * Weight (Cout,Cin,KH,KW) packed to [Cout][KH][KW][CinPad], CinPad = Cin rounded up to 32 (floats: Cout*KH*KW*CinPad). */
+int dim_conv_small_cout_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
+int dim_conv_small_cout_fwd(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin,
+                            int in_cstride, int Cout, int KH, int KW, int pad, int out_cstride, int out_coff, void* stream);
+/* Deconvolution(k=32, s=16, num_group=C, no bias) + Crop(offset (crop,crop)) -> NCHW planes (N,C,OH,OW), times `scale`;
+ * mode 1 applies a sigmoid (mask probability).  deepIM_flownet.py:326-340, :513-529, :845-872. */
+int dim_upsample16_fwd(const float* x_nhwc, const float* w_c1_32_32, float* y_nchw, int N, int C, int h, int w, int OH, int OW,
+                       int crop, float scale, int mode, void* stream);
 /* FullyConnected weight (Out, C*H*W) [mx Flatten order c,h,w] -> [(h,w,c)][Out] so fc6 is dim_conv2d_fwd
  * with KH=H, KW=W on the NHWC feature map. */
 int dim_fc_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream);

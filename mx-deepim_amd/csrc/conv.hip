@@ -32,6 +32,10 @@ struct ConvArgs {
   int chunks_per_split;
   float slope;     // LeakyReLU slope (1 = linear)
   int has_bias;
+  // generalised addressing (decoder): input pixel stride, output row stride / channel offset (write into a concat buffer),
+  // and an output scatter (oy,ox) = (ho*osy + ooy, wo*osx + oox) clipped to OH x OW (sub-pixel phases of a deconvolution + Crop)
+  int in_cstride, out_cstride, out_coff;
+  int dense_out, OH, OW, osy, osx, ooy, oox;
 };
 
 __device__ const float4 g_zero16 = {0.f, 0.f, 0.f, 0.f};  // source of padding taps
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     a_wi0[i] = wo * a.stride - a.pad + (CIN8 ? (q >> 1) : 0);
     // element offset of this thread's float4 at tap (0,0), channel 0 (may be negative in the padding; int32, host-checked).
     // For the 8-channel layer the 4 taps of a chunk are contiguous in memory, so "+ q*4" covers tap and channel half.
-    a_pix[i] = (n * a.H + a_hi0[i]) * a.W * a.Cin + (wo * a.stride - a.pad) * a.Cin + q * 4;
+    a_pix[i] = (n * a.H + a_hi0[i]) * a.W * a.in_cstride + (wo * a.stride - a.pad) * a.in_cstride + q * 4;
   }
   const float* wbase = a.w + ((long)(n0 + srow) * BK + q * 4);  // packed [chunk][Cout][32]
   const long wchunk = (long)a.Cout * BK;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   if (I < B_PER_T) REG = *reinterpret_cast<const float4*>(wsrc + I * 32 * BK);
 #define DIM_LOAD_CHUNK(KC)                                       \
   {                                                              \
-    const int tap_off = (kh * a.W + kw) * a.Cin + c0;            \
+    const int tap_off = (kh * a.W + kw) * a.in_cstride + c0;     \
     DIM_LOAD_A(ra0, 0) DIM_LOAD_A(ra1, 1) DIM_LOAD_A(ra2, 2) DIM_LOAD_A(ra3, 3) \
     const float* wsrc = wbase + (long)(KC) * wchunk;             \
     DIM_LOAD_B(rb0, 0) DIM_LOAD_B(rb1, 1) DIM_LOAD_B(rb2, 2) DIM_LOAD_B(rb3, 3) \
@@ -222,38 +226,65 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   // predicated store (the bias load keeps the counter "unknown" across the branches), serialising 16 store round trips
   // per wave.
   const bool final = gridDim.z == 1;
-  float* out = (final ? a.y : a.y + (long)split * a.M * a.Cout) + (long)(m0 + wm * (BM / WM) + 4 * khalf) * a.Cout + n0 +
-               wn * (BN / WN) + frow;
+  const int ldc = final ? a.out_cstride : a.Cout;
+  const int ncol = n0 + wn * (BN / WN) + frow;
   float bv[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) bv[j] = (final && a.has_bias) ? a.bias[n0 + wn * (BN / WN) + frow + 32 * j] : 0.f;
+  for (int j = 0; j < TN; ++j) bv[j] = (final && a.has_bias) ? a.bias[ncol + 32 * j] : 0.f;
   const float slope = final ? a.slope : 1.0f;
-  if (m0 + BM <= a.M) {
+  const int mrow = m0 + wm * (BM / WM) + 4 * khalf;
+  if (!final || a.dense_out) {
+    float* out = (final ? a.y + a.out_coff : a.y + (long)split * a.M * a.Cout) + (long)mrow * ldc + ncol;
+    if (m0 + BM <= a.M) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] + bv[j];
-          v = v > 0.f ? v : v * slope;
-          out[(long)(32 * i + (r & 3) + 8 * (r >> 2)) * a.Cout + 32 * j] = v;
-        }
-  } else {
-    const int mrow = m0 + wm * (BM / WM) + 4 * khalf;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dm = 32 * i + (r & 3) + 8 * (r >> 2);
-          if (mrow + dm < a.M) {
+          for (int r = 0; r < 16; ++r) {
             float v = acc[i][j][r] + bv[j];
             v = v > 0.f ? v : v * slope;
-            out[(long)dm * a.Cout + 32 * j] = v;
+            out[(long)(32 * i + (r & 3) + 8 * (r >> 2)) * ldc + 32 * j] = v;
+          }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dm = 32 * i + (r & 3) + 8 * (r >> 2);
+            if (mrow + dm < a.M) {
+              float v = acc[i][j][r] + bv[j];
+              v = v > 0.f ? v : v * slope;
+              out[(long)dm * ldc + 32 * j] = v;
+            }
+          }
+    }
+  } else {
+    // scattered output (deconvolution phase + Crop): row m = (n, ho, wo) lands at (n, ho*osy+ooy, wo*osx+oox) if inside OH x OW
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow + 32 * i + (r & 3) + 8 * (r >> 2);
+        if (m < a.M) {
+          int wo = m % a.Wo;
+          int t = m / a.Wo;
+          int ho = t % a.Ho;
+          int n = t / a.Ho;
+          int oy = ho * a.osy + a.ooy, ox = wo * a.osx + a.oox;
+          if ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW) {
+            float* o = a.y + a.out_coff + ((long)(n * a.OH + oy) * a.OW + ox) * ldc + ncol;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              float v = acc[i][j][r] + bv[j];
+              v = v > 0.f ? v : v * slope;
+              o[32 * j] = v;
+            }
           }
         }
+      }
   }
 }
 
@@ -320,6 +351,140 @@ __global__ void pack_fc_weight_kernel(const float* __restrict__ w, float* __rest
   int c = (int)(kc / ((long)H * W)) * 32 + kin;
   long hw = kc % ((long)H * W);
   wp[idx] = w[(long)o * C * H * W + (long)c * H * W + hw];
+}
+
+// Deconvolution(k=4, s=2, p=0) weight (Cin, Cout, 4, 4) [MXNet layout] -> four packed 2x2 convolution weights, one per output
+// phase (py,px): out[2t+py, 2u+px] = sum_{dy,dx} in[t-1+dy, u-1+dx] * w[ci][co][py+2(1-dy)][px+2(1-dx)]   (pad 1, stride 1).
+// Cin is zero-padded to CinPad (multiple of 32).  Layout per phase: [chunk][Cout][32], chunk = (channel slice, dy, dx).
+__global__ void pack_deconv4x4s2_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int CinPad, int Cout) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per_phase = (long)CinPad * 4 * Cout;
+  if (idx >= 4 * per_phase) return;
+  int phase = (int)(idx / per_phase);
+  long r = idx % per_phase;
+  int kin = (int)(r % 32);
+  long t = r / 32;
+  int co = (int)(t % Cout);
+  int kc = (int)(t / Cout);
+  int cc = kc / 4, tap = kc % 4, dy = tap / 2, dx = tap % 2;
+  int ci = cc * 32 + kin;
+  int py = phase / 2, px = phase % 2;
+  float v = 0.f;
+  if (ci < Cin) v = w[(((long)ci * Cout + co) * 4 + (py + 2 * (1 - dy))) * 4 + (px + 2 * (1 - dx))];
+  wp[idx] = v;
+}
+
+// Convolution with a handful of output channels (flow / mask heads, Cout <= 2): one wave per output pixel, lanes stride the
+// (tap, channel) products with float4 loads, wave reduction.  HBM/L2-bound on the activations; weights (Cout,Cin,3,3 MXNet
+// layout) are re-packed to [Cout][kh][kw][CinPad].
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_small_cout_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                              const float* __restrict__ bias, float* __restrict__ y, int N, int H,
+                                                              int W, int CinPad, int in_cstride, int KH, int KW, int pad,
+                                                              int out_cstride, int out_coff) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * 4 + wave;
+  if (pix >= (long)N * H * W) return;
+  const int wo = (int)(pix % W);
+  const int ho = (int)((pix / W) % H);
+  const int n = (int)(pix / ((long)W * H));
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+  const int c4 = CinPad >> 2;
+  for (int kh = 0; kh < KH; ++kh) {
+    const int hi = ho - pad + kh;
+    if ((unsigned)hi >= (unsigned)H) continue;
+    for (int kw = 0; kw < KW; ++kw) {
+      const int wi = wo - pad + kw;
+      if ((unsigned)wi >= (unsigned)W) continue;
+      const float4* xs = reinterpret_cast<const float4*>(x + ((long)(n * H + hi) * W + wi) * in_cstride);
+      for (int i = lane; i < c4; i += 64) {
+        float4 v = xs[i];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+          float4 wv = reinterpret_cast<const float4*>(wp + ((long)(c * KH + kh) * KW + kw) * CinPad)[i];
+          acc[c] = fmaf(v.x, wv.x, fmaf(v.y, wv.y, fmaf(v.z, wv.z, fmaf(v.w, wv.w, acc[c]))));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) {
+    float v = acc[c];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) y[pix * out_cstride + out_coff + c] = v + (bias ? bias[c] : 0.f);
+  }
+}
+
+__global__ void pack_small_cout_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int CinPad,
+                                              int KH, int KW) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)Cout * KH * KW * CinPad;
+  if (idx >= total) return;
+  int ci = (int)(idx % CinPad);
+  long t = idx / CinPad;
+  int kw = (int)(t % KW); t /= KW;
+  int kh = (int)(t % KH);
+  int co = (int)(t / KH);
+  wp[idx] = ci < Cin ? w[(((long)co * Cin + ci) * KH + kh) * KW + kw] : 0.f;
+}
+
+// Deconvolution(k=4, s=2, p=0) on a tiny channel count (upsample_flow6to5 / 5to4: 2 -> 2) + Crop(offset) written into a
+// concat buffer.  x (N,H,W,xstride) NHWC; w (Cin,Cout,4,4) MXNet layout; out pixel (oy,ox) <- full-res (oy+crop, ox+crop).
+__global__ void deconv4x4s2_tiny_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                        float* __restrict__ y, int N, int H, int W, int Cin, int xstride, int Cout, int OH, int OW,
+                                        int crop, int out_cstride, int out_coff) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)N * OH * OW * Cout;
+  if (idx >= total) return;
+  int co = (int)(idx % Cout);
+  long t = idx / Cout;
+  int ox = (int)(t % OW); t /= OW;
+  int oy = (int)(t % OH);
+  int n = (int)(t / OH);
+  int fy = oy + crop, fx = ox + crop;
+  float acc = bias ? bias[co] : 0.f;
+  for (int ky = fy & 1; ky < 4; ky += 2) {
+    int iy = (fy - ky) >> 1;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    for (int kx = fx & 1; kx < 4; kx += 2) {
+      int ix = (fx - kx) >> 1;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const float* xs = x + ((long)(n * H + iy) * W + ix) * xstride;
+      for (int ci = 0; ci < Cin; ++ci) acc = fmaf(xs[ci], w[(((long)ci * Cout + co) * 4 + ky) * 4 + kx], acc);
+    }
+  }
+  y[((long)(n * OH + oy) * OW + ox) * out_cstride + out_coff + co] = acc;
+}
+
+// Deconvolution(k=32, s=16, group = C, no bias) + Crop(offset 8,8): the frozen bilinear x16 upsampling of the flow / mask heads
+// (deepIM_flownet.py:326-340, :513-529).  x (N,h,w,C) NHWC; wk (C,1,32,32); y (N,C,OH,OW) NCHW planes.
+// mode 0: plain * scale   mode 1: sigmoid (mask probability)
+__global__ __launch_bounds__(256) void upsample16_kernel(const float* __restrict__ x, const float* __restrict__ wk, float* __restrict__ y,
+                                                         int C, int h, int w, int OH, int OW, int crop, float scale, int mode) {
+  const int n = blockIdx.z / C, c = blockIdx.z % C;
+  const int oy = blockIdx.y;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ox >= OW) return;
+  const int fy = oy + crop, fx = ox + crop;
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    int iy = (fy >> 4) - a;
+    int ky = fy - 16 * iy;  // in [0,32)
+    if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      int ix = (fx >> 4) - b;
+      int kx = fx - 16 * ix;
+      if ((unsigned)ix >= (unsigned)w) continue;
+      acc = fmaf(x[((long)(n * h + iy) * w + ix) * C + c], wk[((long)c * 32 + ky) * 32 + kx], acc);
+    }
+  }
+  acc *= scale;
+  if (mode == 1) acc = 1.f / (1.f + expf(-acc));
+  y[(((long)n * C + c) * OH + oy) * OW + ox] = acc;
 }
 
 // Pose head: fc7 + LeakyReLU + rot (4) + trans (3) + inverse ZoomTrans -> se3 (B,7).
@@ -419,9 +584,13 @@ int dim_splitk_reduce(const float* slabs, const float* bias, float* y, long M, i
 }
 
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64
+struct ConvEx {
+  int in_cstride, out_cstride, out_coff, OH, OW, osy, osx, ooy, oox;  // 0 / 0 / 0 / 0.. = dense defaults
+};
+
 static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
                            int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile,
-                           int partial_only, void* stream) {
+                           int partial_only, void* stream, const ConvEx* ex = nullptr) {
   if (N == 0) return DIM_OK;  // empty batch
   DIM_REQUIRE(x && w_packed && y, "null pointer");
   DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
@@ -434,7 +603,17 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   a.Ho = (H + 2 * pad - KH) / stride + 1;
   a.Wo = (W + 2 * pad - KW) / stride + 1;
   DIM_REQUIRE(a.Ho > 0 && a.Wo > 0, "empty output");
-  DIM_REQUIRE((long)N * H * W * Cin < (1L << 31), "input too large for 32-bit element offsets (%ld elements)", (long)N * H * W * Cin);
+  a.in_cstride = (ex && ex->in_cstride) ? ex->in_cstride : Cin;
+  a.out_cstride = (ex && ex->out_cstride) ? ex->out_cstride : Cout;
+  a.out_coff = ex ? ex->out_coff : 0;
+  a.dense_out = !(ex && ex->osy);
+  a.OH = a.dense_out ? a.Ho : ex->OH; a.OW = a.dense_out ? a.Wo : ex->OW;
+  a.osy = a.dense_out ? 1 : ex->osy; a.osx = a.dense_out ? 1 : ex->osx;
+  a.ooy = a.dense_out ? 0 : ex->ooy; a.oox = a.dense_out ? 0 : ex->oox;
+  DIM_REQUIRE(a.in_cstride >= Cin && a.in_cstride % 4 == 0, "in_cstride must be >= Cin and a multiple of 4");
+  DIM_REQUIRE(a.out_cstride >= a.out_coff + Cout, "out_cstride < out_coff + Cout");
+  DIM_REQUIRE((long)N * H * W * a.in_cstride < (1L << 31), "input too large for 32-bit element offsets (%ld elements)",
+              (long)N * H * W * a.in_cstride);
   a.M = N * a.Ho * a.Wo;
   a.nchunks = (Cin == 8) ? KH * 2 : KH * KW * (Cin / 32);
   if (splits < 1) splits = 1;
@@ -442,6 +621,8 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   a.chunks_per_split = (a.nchunks + splits - 1) / splits;
   splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
   DIM_REQUIRE(splits == 1 || workspace, "split-K needs a workspace (dim_conv2d_workspace_floats)");
+  DIM_REQUIRE(splits == 1 || !ex || (a.dense_out && a.out_cstride == Cout && a.out_coff == 0),
+              "split-K writes a dense [M][Cout] result: not available with a strided / scattered output");
   a.y = splits > 1 ? workspace : y;
   a.slope = slope;
   a.has_bias = bias != nullptr;
@@ -474,11 +655,101 @@ int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, flo
   return conv2d_fwd_impl(x, w_packed, bias, y, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, slope, splits, tile, 0, stream);
 }
 
+int dim_conv2d_fwd_ex(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int in_cstride,
+                      int Cout, int KH, int KW, int stride, int pad, float slope, int tile, int out_cstride, int out_coff, int OH,
+                      int OW, int osy, int osx, int ooy, int oox, void* stream) {
+  ConvEx ex = {in_cstride, out_cstride, out_coff, OH, OW, osy, osx, ooy, oox};
+  return conv2d_fwd_impl(x, w_packed, bias, y, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, slope, 1, tile, 0, stream, &ex);
+}
+
 int dim_conv2d_fwd_partial(const float* x, const float* w_packed, float* workspace, int N, int H, int W, int Cin, int Cout, int KH,
                            int KW, int stride, int pad, int splits, int tile, void* stream) {
   DIM_REQUIRE(splits > 1, "dim_conv2d_fwd_partial is the split-K first phase: splits must be > 1");
   return conv2d_fwd_impl(x, w_packed, nullptr, workspace, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, 1.0f, splits, tile, 1,
                          stream);
+}
+
+long dim_deconv4x4s2_packed_weight_floats(int Cin, int Cout) {
+  int CinPad = (Cin + 31) / 32 * 32;
+  return 4L * CinPad * 4 * Cout;
+}
+
+int dim_deconv4x4s2_pack_weight(const float* w_iohw, float* w_packed, int Cin, int Cout, void* stream) {
+  DIM_REQUIRE(w_iohw && w_packed, "null pointer");
+  int CinPad = (Cin + 31) / 32 * 32;
+  long total = 4L * CinPad * 4 * Cout;
+  hipLaunchKernelGGL(pack_deconv4x4s2_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_iohw, w_packed,
+                     Cin, CinPad, Cout);
+  return check_launch("pack_deconv_weight");
+}
+
+// y[:, oy, ox, out_coff : out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x, k=4, s=2, p=0) + bias, offset=(crop,crop)))   (NHWC)
+// x (N,H,W,in_cstride) with Cin valid channels, zero weights for the padding up to a multiple of 32.
+int dim_deconv4x4s2_fwd(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin,
+                        int in_cstride, int Cout, int OH, int OW, int crop, float slope, int out_cstride, int out_coff, int tile,
+                        void* stream) {
+  if (N == 0) return DIM_OK;
+  int CinPad = (Cin + 31) / 32 * 32;
+  DIM_REQUIRE(in_cstride >= CinPad, "in_cstride (%d) must cover the padded channel count %d (pad channels must hold zeros)", in_cstride,
+              CinPad);
+  DIM_REQUIRE(OH + crop <= 2 * H + 2 && OW + crop <= 2 * W + 2, "crop window outside the deconvolution output");
+  const long per_phase = (long)CinPad * 4 * Cout;
+  for (int phase = 0; phase < 4; ++phase) {
+    int py = phase / 2, px = phase % 2;
+    ConvEx ex = {in_cstride, out_cstride, out_coff, OH, OW, 2, 2, py - crop, px - crop};
+    int rc = conv2d_fwd_impl(x, w_packed + phase * per_phase, bias, y, nullptr, N, H, W, CinPad, Cout, 2, 2, 1, 1, slope, 1, tile, 0,
+                             stream, &ex);
+    if (rc != DIM_OK) return rc;
+  }
+  return DIM_OK;
+}
+
+int dim_conv_small_cout_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream) {
+  DIM_REQUIRE(w_oihw && w_packed, "null pointer");
+  int CinPad = (Cin + 31) / 32 * 32;
+  long total = (long)Cout * KH * KW * CinPad;
+  hipLaunchKernelGGL(pack_small_cout_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed,
+                     Cout, Cin, CinPad, KH, KW);
+  return check_launch("pack_small_cout_weight");
+}
+
+int dim_conv_small_cout_fwd(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin,
+                            int in_cstride, int Cout, int KH, int KW, int pad, int out_cstride, int out_coff, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(x && w_packed && y, "null pointer");
+  DIM_REQUIRE(Cout == 1 || Cout == 2, "small-Cout kernel handles Cout 1 or 2 (got %d)", Cout);
+  int CinPad = (Cin + 31) / 32 * 32;
+  DIM_REQUIRE(in_cstride >= CinPad && in_cstride % 4 == 0, "in_cstride must cover the padded channel count");
+  long pix = (long)N * H * W;
+  dim3 grid(ceil_div(pix, 4)), block(256);
+  if (Cout == 1)
+    hipLaunchKernelGGL(conv_small_cout_kernel<1>, grid, block, 0, as_stream(stream), x, w_packed, bias, y, N, H, W, CinPad, in_cstride,
+                       KH, KW, pad, out_cstride, out_coff);
+  else
+    hipLaunchKernelGGL(conv_small_cout_kernel<2>, grid, block, 0, as_stream(stream), x, w_packed, bias, y, N, H, W, CinPad, in_cstride,
+                       KH, KW, pad, out_cstride, out_coff);
+  return check_launch("conv_small_cout");
+}
+
+int dim_deconv4x4s2_tiny_fwd(const float* x, const float* w_iohw, const float* bias, float* y, int N, int H, int W, int Cin,
+                             int in_cstride, int Cout, int OH, int OW, int crop, int out_cstride, int out_coff, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(x && w_iohw && y, "null pointer");
+  long total = (long)N * OH * OW * Cout;
+  hipLaunchKernelGGL(deconv4x4s2_tiny_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), x, w_iohw, bias, y, N, H,
+                     W, Cin, in_cstride, Cout, OH, OW, crop, out_cstride, out_coff);
+  return check_launch("deconv_tiny");
+}
+
+int dim_upsample16_fwd(const float* x_nhwc, const float* w_c1_32_32, float* y_nchw, int N, int C, int h, int w, int OH, int OW,
+                       int crop, float scale, int mode, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(x_nhwc && w_c1_32_32 && y_nchw, "null pointer");
+  DIM_REQUIRE(mode == 0 || mode == 1, "mode 0 (linear) or 1 (sigmoid)");
+  DIM_REQUIRE(OH + crop <= 16 * h + 16 && OW + crop <= 16 * w + 16, "crop window outside the deconvolution output");
+  hipLaunchKernelGGL(upsample16_kernel, dim3(ceil_div(OW, 256), OH, N * C), dim3(256), 0, as_stream(stream), x_nhwc, w_c1_32_32,
+                     y_nchw, C, h, w, OH, OW, crop, scale, mode);
+  return check_launch("upsample16");
 }
 
 int dim_pose_head_fwd(const float* fc6, const float* fc7_w, const float* fc7_b, const float* rot_w, const float* rot_b,

@@ -186,6 +186,24 @@ class FlowNetHip(object):
         self.layer_info["fc6"] = dict(M=B, K=81920, N=256, flops=2 * B * 81920 * 256, tile=tile, splits=splits, cin=1024)
         max_ws = max(max_ws, ops.lib().dim_conv2d_workspace_floats(B, 8, 10, 1024, 256, 8, 10, 1, 0, splits))
         self.workspace = torch.empty((max(max_ws, 4),), dtype=torch.float32, device=d)
+        # ---- decoder + flow / mask heads (only in the graph when not FAST_TEST, reference :840-954)
+        self.has_decoder = "deconv5_weight" in self.params
+        if self.has_decoder:
+            self.packed["deconv5"] = ops.deconv4x4s2_pack_weight(self.params["deconv5_weight"])
+            self.packed["deconv4"] = ops.deconv4x4s2_pack_weight(self.params["deconv4_weight"])
+            for n in ("Convolution1", "Convolution2", "Convolution3", "mask_conv3"):
+                if n + "_weight" in self.params:
+                    self.packed[n] = ops.conv_small_cout_pack_weight(self.params[n + "_weight"])
+            self.flow6 = torch.empty((B, 8, 10, 2), dtype=torch.float32, device=d)          # Convolution1
+            self.concat2 = torch.zeros((B, 15, 20, ops.pad32(1026)), dtype=torch.float32, device=d)  # [ReLU8 | ReLU11 | up6to5 | 0-pad]
+            self.flow5 = torch.empty((B, 15, 20, 2), dtype=torch.float32, device=d)         # Convolution2
+            self.concat3 = torch.zeros((B, 30, 40, ops.pad32(770)), dtype=torch.float32, device=d)   # [ReLU6 | ReLU12 | up5to4 | 0-pad]
+            self.flow4 = torch.empty((B, 30, 40, 2), dtype=torch.float32, device=d)         # Convolution3
+            self.mask4 = torch.empty((B, 30, 40, 1), dtype=torch.float32, device=d)         # mask_conv3
+            self.zoom_flow = torch.empty((B, 2, H, W), dtype=torch.float32, device=d)
+            self.flow_est = torch.empty((B, 2, H, W), dtype=torch.float32, device=d)
+            self.zoom_mask_prob = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
+            self.mask_pred = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
         self.fc6 = torch.empty((B, 1, 1, 256), dtype=torch.float32, device=d)
         self.fc7 = torch.empty((B, 256), dtype=torch.float32, device=d)
         self.se3 = torch.empty((B, 7), dtype=torch.float32, device=d)
@@ -256,13 +274,54 @@ class FlowNetHip(object):
     def head(self):
         return ops.pose_head_fwd(self.fc6.view(self.B, 256), self.params, self.zoom_factor, se3=self.se3, fc7_out=self.fc7)
 
+    def decoder(self):
+        """get_convs :213-299: Convolution1, deconv5 (+Crop, LeakyReLU), upsample_flow6to5, Concat2, Convolution2, deconv4,
+        upsample_flow5to4, Concat3.  The concats are channel ranges of one NHWC buffer each (zero-padded to a multiple of 32)."""
+        p = self.params
+        r10, r8, r6 = self.acts["conv6_1"], self.acts["conv5_1"], self.acts["conv4_1"]
+        ops.conv_small_cout_fwd(r10, 1024, self.packed["Convolution1"], p["Convolution1_bias"], 2, out=self.flow6)
+        self.concat2[..., :512].copy_(r8)
+        ops.deconv4x4s2_fwd(r10, 1024, self.packed["deconv5"], p["deconv5_bias"], self.concat2, 512, crop=1, slope=0.1, out_coff=512)
+        ops.deconv4x4s2_tiny_fwd(self.flow6, 2, p["upsample_flow6to5_weight"], p["upsample_flow6to5_bias"], self.concat2, 2, crop=1,
+                                 out_coff=1024)
+        ops.conv_small_cout_fwd(self.concat2, 1026, self.packed["Convolution2"], p["Convolution2_bias"], 2, out=self.flow5)
+        self.concat3[..., :512].copy_(r6)
+        ops.deconv4x4s2_fwd(self.concat2, 1026, self.packed["deconv4"], p["deconv4_bias"], self.concat3, 256, crop=1, slope=0.1,
+                            out_coff=512)
+        ops.deconv4x4s2_tiny_fwd(self.flow5, 2, p["upsample_flow5to4_weight"], p["upsample_flow5to4_bias"], self.concat3, 2, crop=1,
+                                 out_coff=768)
+        return self.concat3
+
+    def heads(self):
+        """test-graph flow / mask heads (:845-954): conv -> frozen x16 bilinear deconvolution -> Crop(8,8) -> inverse zoom."""
+        cfg, p, out = self.cfg, self.params, {}
+        if cfg.network.PRED_MASK:
+            ops.conv_small_cout_fwd(self.concat3, 770, self.packed["mask_conv3"], p["mask_conv3_bias"], 1, out=self.mask4)
+            ops.upsample16_fwd(self.mask4, p["mask_upsampling_weight"], self.H, self.W, crop=8, sigmoid=True, out=self.zoom_mask_prob)
+            # ZoomMaskWithFactor(b_inv_zoom) binarises at 0.2, samples, rounds; the following mx.sym.round is then a no-op
+            ops.zoom_planes(self.zoom_mask_prob, self.zoom_factor, inverse=True, pre=1, post=1, out=self.mask_pred)
+            out["mask_observed_pred_output"] = self.mask_pred
+            out["zoom_mask_observed_prob_iter_output"] = self.zoom_mask_prob
+        if cfg.network.PRED_FLOW:
+            ops.conv_small_cout_fwd(self.concat3, 770, self.packed["Convolution3"], p["Convolution3_bias"], 2, out=self.flow4)
+            ops.upsample16_fwd(self.flow4, p["upsampling_weight"], self.H, self.W, crop=8, scale=float(cfg.dataset.NORMALIZE_FLOW),
+                               out=self.zoom_flow)
+            ops.zoom_planes(self.zoom_flow, self.zoom_factor, inverse=True, scale_mode=2, out=self.flow_est)
+            out["flow_est_crop_output"] = self.flow_est
+        return out
+
     def forward_test(self, batch, bbox_ren=None):
-        """One test-graph forward (FAST_TEST graph: zoom + encoder + FC heads).  Returns the output dict the
-        refinement loop reads (tester.py:483): se3_output (B,7), zoom_factor (B,4)."""
+        """One test-graph forward.  FAST_TEST graph: zoom + encoder + FC heads; otherwise also decoder + flow / mask heads
+        (reference :840-843, :913).  Returns the output dict the refinement loop reads (tester.py:483-491)."""
         self.zoom(batch, bbox_ren=bbox_ren)
         self.encoder()
         self.head()
-        return {"se3_output": self.se3, "zoom_factor": self.zoom_factor}
+        out = {"se3_output": self.se3, "zoom_factor": self.zoom_factor}
+        cfg = self.cfg
+        if self.has_decoder and not cfg.TEST.FAST_TEST and (cfg.network.PRED_MASK or cfg.network.PRED_FLOW):
+            self.decoder()
+            out.update(self.heads())
+        return out
 
     def flops_per_forward(self):
         """algorithmic MACs*2 of encoder + head for this batch (SURVEY.md 8a layer table)."""

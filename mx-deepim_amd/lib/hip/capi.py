@@ -40,6 +40,14 @@ SIGNATURES = {
     "dim_conv2d_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, P]),
     "dim_conv2d_fwd_partial": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_splitk_reduce": (I, [P, P, P, L, I, I, F, P]),
+    "dim_conv2d_fwd_ex": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, I, I, I, I, I, I, I, I, I, P]),
+    "dim_deconv4x4s2_packed_weight_floats": (L, [I, I]),
+    "dim_deconv4x4s2_pack_weight": (I, [P, P, I, I, P]),
+    "dim_deconv4x4s2_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, P]),
+    "dim_deconv4x4s2_tiny_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dim_conv_small_cout_pack_weight": (I, [P, P, I, I, I, I, P]),
+    "dim_conv_small_cout_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dim_upsample16_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P]),
     "dim_fc_pack_weight": (I, [P, P, I, I, I, I, P]),
     "dim_pose_head_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, P]),
 }

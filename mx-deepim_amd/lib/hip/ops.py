@@ -195,3 +195,55 @@ def pose_head_fwd(fc6, p, zf, se3=None, fc7_out=None):
                                   dptr(p["rot_bias"], f32), dptr(p["trans_weight"], f32), dptr(p["trans_bias"], f32), dptr(zf, f32),
                                   dptr(se3, f32), dptr(fc7_out, f32), B, current_stream()))
     return se3
+
+
+# ---------------------------------------------------------------- decoder pieces (deepIM_flownet.py:213-299, :315-340, :502-529)
+def pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def deconv4x4s2_pack_weight(w_iohw):
+    Cin, Cout = w_iohw.shape[:2]
+    wp = _new((lib().dim_deconv4x4s2_packed_weight_floats(Cin, Cout),), w_iohw)
+    check(lib().dim_deconv4x4s2_pack_weight(dptr(w_iohw.contiguous(), f32), dptr(wp, f32), Cin, Cout, current_stream()))
+    return wp
+
+
+def deconv4x4s2_fwd(x_nhwc, Cin, w_packed, bias, y_nhwc, Cout, crop, slope, out_coff=0, tile=3):
+    """y[..., out_coff:out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x[..., :Cin]) + bias)); y's H,W define the crop window."""
+    N, H, W, in_cs = x_nhwc.shape
+    _, OH, OW, out_cs = y_nhwc.shape
+    check(lib().dim_deconv4x4s2_fwd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(y_nhwc, f32), N, H, W, Cin, in_cs, Cout,
+                                    OH, OW, crop, float(slope), out_cs, out_coff, tile, current_stream()))
+    return y_nhwc
+
+
+def deconv4x4s2_tiny_fwd(x_nhwc, Cin, w_iohw, bias, y_nhwc, Cout, crop, out_coff=0):
+    N, H, W, in_cs = x_nhwc.shape
+    _, OH, OW, out_cs = y_nhwc.shape
+    check(lib().dim_deconv4x4s2_tiny_fwd(dptr(x_nhwc, f32), dptr(w_iohw, f32), dptr(bias, f32), dptr(y_nhwc, f32), N, H, W, Cin, in_cs,
+                                         Cout, OH, OW, crop, out_cs, out_coff, current_stream()))
+    return y_nhwc
+
+
+def conv_small_cout_pack_weight(w_oihw):
+    Cout, Cin, KH, KW = w_oihw.shape
+    wp = _new((Cout * KH * KW * pad32(Cin),), w_oihw)
+    check(lib().dim_conv_small_cout_pack_weight(dptr(w_oihw.contiguous(), f32), dptr(wp, f32), Cout, Cin, KH, KW, current_stream()))
+    return wp
+
+
+def conv_small_cout_fwd(x_nhwc, Cin, w_packed, bias, Cout, KH=3, KW=3, pad=1, out=None, out_coff=0):
+    N, H, W, in_cs = x_nhwc.shape
+    out = out if out is not None else _new((N, H, W, Cout), x_nhwc)
+    check(lib().dim_conv_small_cout_fwd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), N, H, W, Cin, in_cs, Cout,
+                                        KH, KW, pad, out.shape[3], out_coff, current_stream()))
+    return out
+
+
+def upsample16_fwd(x_nhwc, w_c1_32_32, OH, OW, crop=8, scale=1.0, sigmoid=False, out=None):
+    N, h, w, C = x_nhwc.shape
+    out = out if out is not None else _new((N, C, OH, OW), x_nhwc)
+    check(lib().dim_upsample16_fwd(dptr(x_nhwc, f32), dptr(w_c1_32_32, f32), dptr(out, f32), N, C, h, w, OH, OW, crop, float(scale),
+                                   1 if sigmoid else 0, current_stream()))
+    return out
