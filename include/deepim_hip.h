@@ -143,6 +143,27 @@ int dim_conv_small_cout_fwd(const float* x, const float* w_packed, const float* 
  * mode 1 applies a sigmoid (mask probability).  deepIM_flownet.py:326-340, :513-529, :845-872. */
 int dim_upsample16_fwd(const float* x_nhwc, const float* w_c1_32_32, float* y_nchw, int N, int C, int h, int w, int OH, int OW,
                        int crop, float scale, int mode, void* stream);
+/* ---------------------------------------------------------------- backward of the convolution stack (training)
+ * dgrad: dx[..., :Cin] (+)= d/dx of y = conv(x, W (Cout,Cin,KH,KW), stride 1|2, pad); runs on the forward MFMA kernel with the
+ * weights re-packed by dim_conv2d_dgrad_pack_weight (stride 2 = four input phases).  dx's channel stride must be >= Cin
+ * rounded up to 64. */
+long dim_conv2d_dgrad_packed_weight_floats(int Cout, int Cin, int KH, int KW, int stride, int pad);
+int dim_conv2d_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, int stride, int pad,
+                                 void* stream);
+int dim_conv2d_dgrad(const float* dy, const float* w_dgrad_packed, float* dx, int N, int H, int W, int Cin, int dx_cstride, int Ho,
+                     int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad, int accumulate, int tile, void* stream);
+/* wgrad: dw_packed (same layout as dim_conv2d_pack_weight's output, so SGD updates the packed weights in place)
+ * (+)= sum over pixels of dz (N,Ho,Wo,dz_cstride)[dz_coff:+Cout] x gathered x (N,H,W,in_cstride)[:Cin]. */
+long dim_conv2d_wgrad_workspace_floats(int Cout, int Cin, int KH, int KW, int splits);
+int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* workspace, int N, int H, int W, int Cin, int in_cstride,
+                     int Ho, int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits,
+                     int accumulate, void* stream);
+/* db[c] (+)= sum_m dz[m][dz_coff + c]   (workspace: dim_bias_grad_workspace_floats) */
+long dim_bias_grad_workspace_floats(int M, int C);
+int dim_bias_grad(const float* dz, float* db, float* workspace, int M, int C, int dz_cstride, int dz_coff, int accumulate, void* stream);
+/* LeakyReLU backward in place on a channel range: dy *= (y > 0 ? 1 : slope) */
+int dim_lrelu_bwd(const float* y, int y_cstride, int y_coff, float* dy, int dy_cstride, int dy_coff, long M, int C, float slope,
+                  void* stream);
 /* FullyConnected weight (Out, C*H*W) [mx Flatten order c,h,w] -> [(h,w,c)][Out] so fc6 is dim_conv2d_fwd
  * with KH=H, KW=W on the NHWC feature map. */
 int dim_fc_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream);

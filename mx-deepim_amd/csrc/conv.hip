@@ -26,7 +26,7 @@ struct ConvArgs {
   float* y;        // final output (splits == 1) or slab base (splits > 1)
   int N, H, W, Cin;
   int Ho, Wo, Cout;
-  int KH, KW, stride, pad;
+  int KH, KW, stride, pad_h, pad_w;
   int M;           // N*Ho*Wo
   int nchunks;     // total K chunks of 32
   int chunks_per_split;
@@ -36,6 +36,7 @@ struct ConvArgs {
   // and an output scatter (oy,ox) = (ho*osy + ooy, wo*osx + oox) clipped to OH x OW (sub-pixel phases of a deconvolution + Crop)
   int in_cstride, out_cstride, out_coff;
   int dense_out, OH, OW, osy, osx, ooy, oox;
+  int accumulate;  // out += v (final pass only)
 };
 
 __device__ const float4 g_zero16 = {0.f, 0.f, 0.f, 0.f};  // source of padding taps
@@ -78,11 +79,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     int t = mm / a.Wo;
     int ho = t % a.Ho;
     int n = t / a.Ho;
-    a_hi0[i] = ok ? ho * a.stride - a.pad : -(1 << 28);  // rows past M: every tap fails the bounds test
-    a_wi0[i] = wo * a.stride - a.pad + (CIN8 ? (q >> 1) : 0);
+    a_hi0[i] = ok ? ho * a.stride - a.pad_h : -(1 << 28);  // rows past M: every tap fails the bounds test
+    a_wi0[i] = wo * a.stride - a.pad_w + (CIN8 ? (q >> 1) : 0);
     // element offset of this thread's float4 at tap (0,0), channel 0 (may be negative in the padding; int32, host-checked).
     // For the 8-channel layer the 4 taps of a chunk are contiguous in memory, so "+ q*4" covers tap and channel half.
-    a_pix[i] = (n * a.H + a_hi0[i]) * a.W * a.in_cstride + (wo * a.stride - a.pad) * a.in_cstride + q * 4;
+    a_pix[i] = (n * a.H + a_hi0[i]) * a.W * a.in_cstride + (wo * a.stride - a.pad_w) * a.in_cstride + q * 4;
   }
   const float* wbase = a.w + ((long)(n0 + srow) * BK + q * 4);  // packed [chunk][Cout][32]
   const long wchunk = (long)a.Cout * BK;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) bv[j] = (final && a.has_bias) ? a.bias[ncol + 32 * j] : 0.f;
   const float slope = final ? a.slope : 1.0f;
+  const bool acc_out = final && a.accumulate;
   const int mrow = m0 + wm * (BM / WM) + 4 * khalf;
   if (!final || a.dense_out) {
     float* out = (final ? a.y + a.out_coff : a.y + (long)split * a.M * a.Cout) + (long)mrow * ldc + ncol;
@@ -244,7 +246,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
           for (int r = 0; r < 16; ++r) {
             float v = acc[i][j][r] + bv[j];
             v = v > 0.f ? v : v * slope;
-            out[(long)(32 * i + (r & 3) + 8 * (r >> 2)) * ldc + 32 * j] = v;
+            float* o = out + (long)(32 * i + (r & 3) + 8 * (r >> 2)) * ldc + 32 * j;
+            if (acc_out) v += *o;
+            *o = v;
           }
     } else {
 #pragma unroll
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             if (mrow + dm < a.M) {
               float v = acc[i][j][r] + bv[j];
               v = v > 0.f ? v : v * slope;
+              if (acc_out) v += out[(long)dm * ldc + 32 * j];
               out[(long)dm * ldc + 32 * j] = v;
             }
           }
@@ -280,6 +285,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             for (int j = 0; j < TN; ++j) {
               float v = acc[i][j][r] + bv[j];
               v = v > 0.f ? v : v * slope;
+              if (acc_out) v += o[32 * j];
               o[32 * j] = v;
             }
           }
@@ -586,6 +592,9 @@ int dim_splitk_reduce(const float* slabs, const float* bias, float* y, long M, i
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64
 struct ConvEx {
   int in_cstride, out_cstride, out_coff, OH, OW, osy, osx, ooy, oox;  // 0 / 0 / 0 / 0.. = dense defaults
+  int accumulate = 0;    // out += result (skip-connection gradients)
+  int pad_w = -1;        // >= 0: horizontal padding differs from `pad` (sub-pixel phases of a strided dgrad)
+  int Ho = 0, Wo = 0;    // > 0: explicit output grid instead of floor((H+2p-k)/s)+1 (asymmetric padding)
 };
 
 static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
@@ -599,10 +608,13 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   DIM_REQUIRE(Cin != 8 || KW <= 8, "Cin==8 path needs KW<=8");
   ConvArgs a;
   a.x = x; a.w = w_packed; a.bias = bias;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
-  a.Ho = (H + 2 * pad - KH) / stride + 1;
-  a.Wo = (W + 2 * pad - KW) / stride + 1;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride;
+  a.pad_h = pad;
+  a.pad_w = (ex && ex->pad_w >= 0) ? ex->pad_w : pad;
+  a.Ho = (ex && ex->Ho > 0) ? ex->Ho : (H + 2 * pad - KH) / stride + 1;
+  a.Wo = (ex && ex->Wo > 0) ? ex->Wo : (W + 2 * a.pad_w - KW) / stride + 1;
   DIM_REQUIRE(a.Ho > 0 && a.Wo > 0, "empty output");
+  a.accumulate = ex ? ex->accumulate : 0;
   a.in_cstride = (ex && ex->in_cstride) ? ex->in_cstride : Cin;
   a.out_cstride = (ex && ex->out_cstride) ? ex->out_cstride : Cout;
   a.out_coff = ex ? ex->out_coff : 0;
@@ -660,6 +672,113 @@ int dim_conv2d_fwd_ex(const float* x, const float* w_packed, const float* bias, 
                       int OW, int osy, int osx, int ooy, int oox, void* stream) {
   ConvEx ex = {in_cstride, out_cstride, out_coff, OH, OW, osy, osx, ooy, oox};
   return conv2d_fwd_impl(x, w_packed, bias, y, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, slope, 1, tile, 0, stream, &ex);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- dgrad
+// Gradient w.r.t. the input of y = conv(x, W (Cout,Cin,KH,KW), stride s in {1,2}, pad p) on the SAME MFMA kernel with re-packed
+// weights (channel roles swapped).
+//   s = 1:  dX[i] = sum_j dY[i - (K-1-p) + j] * W[K-1-j]                      one stride-1 convolution over dY
+//   s = 2:  input rows iy = 2t + ph (phase ph):  dX[2t+ph] = sum_e dY[t + e] * W[ph + p - 2e],  e in [emin, emax]
+//           = stride-1 convolution over dY with KH' = emax-emin+1 taps and pad' = -emin, scattered to rows 2t+ph.
+// Packed layout: phases (py,px) one after the other, each [chunk][CinPad][32] with chunk = (32-slice of Cout, jy, jx) and
+// CinPad = Cin rounded up to 64 (the kernel's channel tile; padded outputs are zero).
+struct DgAxis {
+  int ntaps, emin;
+};
+static inline DgAxis dg_axis(int K, int stride, int p, int ph) {
+  if (stride == 1) return {K, -(K - 1 - p)};
+  int emin = 1000, emax = -1000;
+  for (int e = -K; e <= K; ++e) {
+    int k = ph + p - 2 * e;
+    if (k >= 0 && k < K) { emin = min(emin, e); emax = max(emax, e); }
+  }
+  if (emin > emax) return {0, 0};
+  return {emax - emin + 1, emin};
+}
+
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int CinPad, int KH, int KW,
+                                         int stride, int pad, int py, int px, int nth, int ntw, int eminh, int eminw, int deconv_layout) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)(Cout / 32) * nth * ntw * CinPad * 32;
+  if (idx >= total) return;
+  int kin = (int)(idx % 32);
+  long t = idx / 32;
+  int ci = (int)(t % CinPad);
+  int kc = (int)(t / CinPad);
+  int taps = nth * ntw;
+  int cc = kc / taps, tap = kc % taps, jy = tap / ntw, jx = tap % ntw;
+  int co = cc * 32 + kin;
+  int ky = (stride == 1) ? KH - 1 - jy : py + pad - 2 * (jy + eminh);
+  int kx = (stride == 1) ? KW - 1 - jx : px + pad - 2 * (jx + eminw);
+  float v = 0.f;
+  if (ci < Cin && ky >= 0 && ky < KH && kx >= 0 && kx < KW)
+    v = deconv_layout ? w[(((long)ci * Cout + co) * KH + ky) * KW + kx]   // never used (deconv dgrad is a plain forward conv)
+                      : w[(((long)co * Cin + ci) * KH + ky) * KW + kx];
+  wp[idx] = v;
+}
+
+long dim_conv2d_dgrad_packed_weight_floats(int Cout, int Cin, int KH, int KW, int stride, int pad) {
+  int CinPad = (Cin + 63) / 64 * 64;
+  long total = 0;
+  int nph = stride == 1 ? 1 : 2;
+  for (int py = 0; py < nph; ++py)
+    for (int px = 0; px < nph; ++px)
+      total += (long)(Cout / 32) * dg_axis(KH, stride, pad, py).ntaps * dg_axis(KW, stride, pad, px).ntaps * CinPad * 32;
+  return total;
+}
+
+int dim_conv2d_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, int stride, int pad,
+                                 void* stream) {
+  DIM_REQUIRE(w_oihw && w_packed, "null pointer");
+  DIM_REQUIRE(stride == 1 || stride == 2, "dgrad supports stride 1 or 2");
+  DIM_REQUIRE(Cout % 32 == 0, "Cout must be a multiple of 32 (it is the contraction dimension of dgrad)");
+  int CinPad = (Cin + 63) / 64 * 64;
+  int nph = stride == 1 ? 1 : 2;
+  long off = 0;
+  for (int py = 0; py < nph; ++py)
+    for (int px = 0; px < nph; ++px) {
+      DgAxis ah = dg_axis(KH, stride, pad, py), aw = dg_axis(KW, stride, pad, px);
+      long total = (long)(Cout / 32) * ah.ntaps * aw.ntaps * CinPad * 32;
+      if (total > 0) {
+        hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw,
+                           w_packed + off, Cout, Cin, CinPad, KH, KW, stride, pad, py, px, ah.ntaps, aw.ntaps, ah.emin, aw.emin, 0);
+      }
+      off += total;
+    }
+  return check_launch("pack_dgrad_weight");
+}
+
+// dx (N,H,W,dx_cstride)[..., :Cin] (+)= dgrad(dy (N,Ho,Wo,dy_cstride)[..., :Cout]).  accumulate != 0 adds to dx (skip connections).
+int dim_conv2d_dgrad(const float* dy, const float* w_dgrad_packed, float* dx, int N, int H, int W, int Cin, int dx_cstride, int Ho,
+                     int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad, int accumulate, int tile, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(stride == 1 || stride == 2, "dgrad supports stride 1 or 2");
+  int CinPad = (Cin + 63) / 64 * 64;
+  DIM_REQUIRE(dx_cstride >= CinPad, "dx channel stride (%d) must be >= Cin rounded up to 64 (%d)", dx_cstride, CinPad);
+  int nph = stride == 1 ? 1 : 2;
+  long off = 0;
+  for (int py = 0; py < nph; ++py)
+    for (int px = 0; px < nph; ++px) {
+      DgAxis ah = dg_axis(KH, stride, pad, py), aw = dg_axis(KW, stride, pad, px);
+      long total = (long)(Cout / 32) * ah.ntaps * aw.ntaps * CinPad * 32;
+      int Th = stride == 1 ? H : (H - py + 1) / 2, Tw = stride == 1 ? W : (W - px + 1) / 2;
+      if (Th > 0 && Tw > 0) {
+        ConvEx ex = {dy_cstride, dx_cstride, 0, H, W, stride == 1 ? 0 : 2, stride == 1 ? 0 : 2, py, px};
+        ex.pad_w = -aw.emin;
+        ex.Ho = Th;
+        ex.Wo = Tw;
+        ex.accumulate = accumulate;
+        if (total > 0) {
+          int rc = conv2d_fwd_impl(dy, w_dgrad_packed + off, nullptr, dx, nullptr, N, Ho, Wo, Cout, CinPad, ah.ntaps, aw.ntaps, 1,
+                                   -ah.emin, 1.0f, 1, tile, 0, stream, &ex);
+          if (rc != DIM_OK) return rc;
+        } else if (!accumulate) {
+          return set_err(DIM_ERR_ARG, "phase (%d,%d) has no taps: dX rows of that phase would stay unwritten", py, px);
+        }
+      }
+      off += total;
+    }
+  return DIM_OK;
 }
 
 int dim_conv2d_fwd_partial(const float* x, const float* w_packed, float* workspace, int N, int H, int W, int Cin, int Cout, int KH,

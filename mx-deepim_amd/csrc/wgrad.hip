@@ -1,0 +1,260 @@
+// Weight gradient of the direct convolution, im2col-free, on the f32 MFMA pipe.
+//
+//   dWp[chunk][co][kin] = sum over pixels m=(n,ho,wo) of  dZ[m][co] * X[n, ho*s-p+kh, wo*s-p+kw, c0+kin]
+//
+// written DIRECTLY in the forward kernel's packed weight layout ([chunk][Cout][32], chunk = (32-channel slice, kh, kw) or, for
+// the 8-channel first layer, (kh, 4-tap group)), so SGD (elementwise) updates the packed weights in place and nothing is ever
+// re-packed during training.  Replaces the cuDNN backward-filter calls behind MXNet's Convolution / FullyConnected backward
+// (reference graph: deepim/symbols/deepIM_flownet.py:67-208; executor: deepim/core/module.py:1205-1209).
+//
+// Implicit GEMM with the PIXELS as the contraction dimension: A = dZ^T (co x pixels), B = gathered X (pixels x 32).
+// Workgroup = NW waves, each owning a 32(co) x 32(kin) accumulator; 32 pixels per step are staged in LDS in their natural
+// layouts ([pixel][co], [pixel][kin]) -- lane (i, h) reads A[co=i][pixel=2s+h] and B[pixel=2s+h][kin=i] with conflict-free
+// ds_read_b32.  grid = (chunks, Cout/(32*NW), pixel splits); splits write slabs that dim_splitk_reduce sums (deterministic).
+#include "common.h"
+
+namespace dim {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+  const float* x;   // (N,H,W,in_cstride)
+  const float* dz;  // (N,Ho,Wo,dz_cstride)  gradient w.r.t. the pre-activation output
+  float* dw;        // packed layout, or slab base when splits > 1
+  int N, H, W, Cin, in_cstride, Ho, Wo, Cout, dz_cstride, dz_coff;
+  int KH, KW, stride, pad;
+  int M, nchunks, steps_per_split, nsteps;
+  int accumulate;
+};
+
+__device__ const float4 g_wzero16 = {0.f, 0.f, 0.f, 0.f};
+
+template <int NW, bool CIN8>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int BP = 32;            // pixels per step
+  constexpr int BM = 32 * NW;       // output channels per workgroup
+  constexpr int LDZ = BM + 4;       // row stride keeps float4 stores aligned; rows 2s and 2s+1 are read by different lane groups
+  constexpr int LDX = 32 + 4;
+  constexpr int NT = 64 * NW;
+  constexpr int Z_PER_T = (BP * BM / 4) / NT;  // = 4
+  constexpr int X_PER_T = (BP * 32 / 4) / NT;  // 1 (NW=4) or 2 (NW=2)
+  __shared__ __attribute__((aligned(16))) float sZ[2][BP * LDZ];
+  __shared__ __attribute__((aligned(16))) float sX[2][BP * LDX];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kc = blockIdx.x;
+  const int co0 = blockIdx.y * BM;
+  const int split = blockIdx.z;
+  const int step_begin = split * a.steps_per_split;
+  const int step_end = min(a.nsteps, step_begin + a.steps_per_split);
+
+  // chunk -> tap / channel slice (same order as conv_fwd_kernel / pack_conv_weight_kernel)
+  int kh, kw, c0;
+  if (CIN8) {
+    kh = kc >> 1; kw = (kc & 1) * 4; c0 = 0;
+  } else {
+    int taps = a.KH * a.KW;
+    int cc = kc / taps, tap = kc - cc * taps;
+    c0 = cc << 5; kh = tap / a.KW; kw = tap - kh * a.KW;
+  }
+
+  // staging maps.  dZ: float4 #zq of pixel row zr (+ passes);  X: float4 #xq (of 8) of pixel row xr (+ passes)
+  constexpr int ZQ = BM / 4;
+  const int zq = tid % ZQ, zr0 = tid / ZQ;
+  constexpr int ZR_STEP = NT / ZQ;
+  const int xq = tid & 7, xr0 = tid >> 3;
+  constexpr int XR_STEP = NT / 8;
+
+  float4 rz[Z_PER_T], rx[X_PER_T];
+
+  auto load_step = [&](int st) {
+    const int p0 = st * BP;
+#pragma unroll
+    for (int i = 0; i < Z_PER_T; ++i) {
+      int m = p0 + zr0 + ZR_STEP * i;
+      const float* src = (m < a.M) ? a.dz + (long)m * a.dz_cstride + a.dz_coff + co0 + zq * 4 : reinterpret_cast<const float*>(&g_wzero16);
+      rz[i] = *reinterpret_cast<const float4*>(src);
+    }
+#pragma unroll
+    for (int i = 0; i < X_PER_T; ++i) {
+      int m = p0 + xr0 + XR_STEP * i;
+      bool ok = m < a.M;
+      int mm = ok ? m : 0;
+      int wo = mm % a.Wo;
+      int t = mm / a.Wo;
+      int ho = t % a.Ho;
+      int n = t / a.Ho;
+      int hi = ho * a.stride - a.pad + kh;
+      int wi = wo * a.stride - a.pad + kw + (CIN8 ? (xq >> 1) : 0);
+      ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && (!CIN8 || kw + (xq >> 1) < a.KW);
+      long off = ((long)(n * a.H + hi) * a.W + wi) * a.in_cstride + c0 + (CIN8 ? (xq & 1) * 4 : xq * 4);
+      const float* src = ok ? a.x + off : reinterpret_cast<const float*>(&g_wzero16);
+      rx[i] = *reinterpret_cast<const float4*>(src);
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < Z_PER_T; ++i) *reinterpret_cast<float4*>(&sZ[buf][(zr0 + ZR_STEP * i) * LDZ + zq * 4]) = rz[i];
+#pragma unroll
+    for (int i = 0; i < X_PER_T; ++i) *reinterpret_cast<float4*>(&sX[buf][(xr0 + XR_STEP * i) * LDX + xq * 4]) = rx[i];
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  if (step_begin < step_end) {
+    load_step(step_begin);
+    store_step(0);
+  }
+  __syncthreads();
+  const int fi = lane & 31, fh = lane >> 5;
+  int buf = 0;
+  for (int st = step_begin; st < step_end; ++st) {
+    const bool more = st + 1 < step_end;
+    if (more) load_step(st + 1);
+    const float* cz = &sZ[buf][fh * LDZ + wave * 32 + fi];
+    const float* cx = &sX[buf][fh * LDX + fi];
+#pragma unroll
+    for (int s = 0; s < BP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cz[2 * s * LDZ], cx[2 * s * LDX], acc, 0, 0, 0);
+    if (more) store_step(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // D: col = lane&31 -> kin, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co within the wave's 32
+  float* out = (gridDim.z == 1 ? a.dw : a.dw + (long)split * a.nchunks * a.Cout * 32) + ((long)kc * a.Cout + co0 + wave * 32 + 4 * fh) * 32 + fi;
+  const bool add = gridDim.z == 1 && a.accumulate;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float* o = out + (long)((r & 3) + 8 * (r >> 2)) * 32;
+    float v = acc[r];
+    if (add) v += *o;
+    *o = v;
+  }
+}
+
+// column sums: db[c] = sum_m dz[m][coff + c]; grid (C/64, nsplit) -> partial[nsplit][C]; then a tiny reduce
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dz, int M, int C, int cstride, int coff,
+                                                             int rows_per_block, float* __restrict__ partial) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rsub = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < C)
+    for (int m = r0 + rsub; m < r1; m += 4) s += dz[(long)m * cstride + coff + c];
+  __shared__ float red[4][64];
+  red[rsub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rsub == 0 && c < C) partial[(long)blockIdx.y * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ db, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += partial[(long)k * C + c];
+  db[c] = accumulate ? db[c] + s : s;
+}
+
+// dz = dy * (y > 0 ? 1 : slope) elementwise on a channel range of NHWC rows (LeakyReLU backward)
+__global__ void lrelu_bwd_kernel(const float* __restrict__ y, int y_cstride, int y_coff, float* __restrict__ dy, int dy_cstride, int dy_coff,
+                                 long M, int C, float slope) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = M * (C / 4);
+  if (idx >= total) return;
+  long m = idx / (C / 4);
+  int c4 = (int)(idx % (C / 4)) * 4;
+  float4 yv = *reinterpret_cast<const float4*>(y + m * y_cstride + y_coff + c4);
+  float4* g = reinterpret_cast<float4*>(dy + m * dy_cstride + dy_coff + c4);
+  float4 gv = *g;
+  gv.x *= yv.x > 0.f ? 1.f : slope;
+  gv.y *= yv.y > 0.f ? 1.f : slope;
+  gv.z *= yv.z > 0.f ? 1.f : slope;
+  gv.w *= yv.w > 0.f ? 1.f : slope;
+  *g = gv;
+}
+
+}  // namespace dim
+
+using namespace dim;
+
+extern "C" {
+
+long dim_conv2d_wgrad_workspace_floats(int Cout, int Cin, int KH, int KW, int splits) {
+  if (splits <= 1) return 0;
+  long n = (Cin == 8) ? (long)KH * 2 * 32 * Cout : (long)KH * KW * Cin * Cout;
+  return n * splits;
+}
+
+// dw_packed (+)= wgrad(x, dz).  splits > 1: pixel range split through `workspace` (slabs) and summed deterministically.
+int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* workspace, int N, int H, int W, int Cin, int in_cstride,
+                     int Ho, int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits,
+                     int accumulate, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(x && dz && dw_packed, "null pointer");
+  DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
+  DIM_REQUIRE(Cout % 64 == 0, "Cout must be a multiple of 64 (got %d)", Cout);
+  DIM_REQUIRE((long)N * H * W * in_cstride < (1L << 31) && (long)N * Ho * Wo * dz_cstride < (1L << 31), "tensor too large");
+  DIM_REQUIRE(dz_cstride % 4 == 0 && dz_coff % 4 == 0 && in_cstride % 4 == 0, "channel strides / offsets must be multiples of 4");
+  WgradArgs a;
+  a.x = x; a.dz = dz;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_cstride = in_cstride; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+  a.dz_cstride = dz_cstride; a.dz_coff = dz_coff; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.M = N * Ho * Wo;
+  a.nchunks = (Cin == 8) ? KH * 2 : KH * KW * (Cin / 32);
+  a.nsteps = ceil_div(a.M, 32);
+  if (splits < 1) splits = 1;
+  if (splits > a.nsteps) splits = a.nsteps;
+  a.steps_per_split = ceil_div(a.nsteps, splits);
+  splits = ceil_div(a.nsteps, a.steps_per_split);
+  DIM_REQUIRE(splits == 1 || workspace, "split wgrad needs a workspace (dim_conv2d_wgrad_workspace_floats)");
+  a.dw = splits > 1 ? workspace : dw_packed;
+  a.accumulate = accumulate;
+  hipStream_t st = as_stream(stream);
+  const bool nw4 = Cout % 128 == 0;
+  dim3 grid(a.nchunks, Cout / (nw4 ? 128 : 64), splits);
+  if (Cin == 8) {
+    if (nw4) hipLaunchKernelGGL((conv_wgrad_kernel<4, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<2, true>), grid, dim3(128), 0, st, a);
+  } else {
+    if (nw4) hipLaunchKernelGGL((conv_wgrad_kernel<4, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<2, false>), grid, dim3(128), 0, st, a);
+  }
+  int rc = check_launch("conv_wgrad");
+  if (rc != DIM_OK) return rc;
+  if (splits > 1) {
+    long n = (long)a.nchunks * Cout * 32;
+    if (accumulate) {
+      // slabs + existing value: treat dw itself as one more addend by summing into a temp is avoided -- reduce then add
+      return set_err(DIM_ERR_ARG, "accumulate with splits > 1 is not supported (reduce first, then accumulate with splits == 1)");
+    }
+    return dim_splitk_reduce(workspace, nullptr, dw_packed, n / 4, 4, splits, 1.0f, stream);
+  }
+  return DIM_OK;
+}
+
+long dim_bias_grad_workspace_floats(int M, int C) { return (long)ceil_div(M, 2048) * C; }
+
+int dim_bias_grad(const float* dz, float* db, float* workspace, int M, int C, int dz_cstride, int dz_coff, int accumulate, void* stream) {
+  if (M == 0) return DIM_OK;
+  DIM_REQUIRE(dz && db && workspace, "null pointer");
+  int nsplit = ceil_div(M, 2048);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C, 64), nsplit), dim3(256), 0, st, dz, M, C, dz_cstride, dz_coff, 2048, workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, workspace, nsplit, C, db, accumulate);
+  return check_launch("bias_grad");
+}
+
+int dim_lrelu_bwd(const float* y, int y_cstride, int y_coff, float* dy, int dy_cstride, int dy_coff, long M, int C, float slope,
+                  void* stream) {
+  if (M == 0) return DIM_OK;
+  DIM_REQUIRE(y && dy, "null pointer");
+  DIM_REQUIRE(C % 4 == 0 && y_cstride % 4 == 0 && dy_cstride % 4 == 0 && y_coff % 4 == 0 && dy_coff % 4 == 0, "multiples of 4 required");
+  long total = M * (C / 4);
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), y, y_cstride, y_coff, dy, dy_cstride,
+                     dy_coff, M, C, slope);
+  return check_launch("lrelu_bwd");
+}
+
+}  // extern "C"

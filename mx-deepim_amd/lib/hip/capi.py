@@ -48,6 +48,14 @@ SIGNATURES = {
     "dim_conv_small_cout_pack_weight": (I, [P, P, I, I, I, I, P]),
     "dim_conv_small_cout_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_upsample16_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P]),
+    "dim_conv2d_dgrad_packed_weight_floats": (L, [I, I, I, I, I, I]),
+    "dim_conv2d_dgrad_pack_weight": (I, [P, P, I, I, I, I, I, I, P]),
+    "dim_conv2d_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dim_conv2d_wgrad_workspace_floats": (L, [I, I, I, I, I]),
+    "dim_conv2d_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dim_bias_grad_workspace_floats": (L, [I, I]),
+    "dim_bias_grad": (I, [P, P, P, I, I, I, I, I, P]),
+    "dim_lrelu_bwd": (I, [P, I, I, P, I, I, L, I, F, P]),
     "dim_fc_pack_weight": (I, [P, P, I, I, I, I, P]),
     "dim_pose_head_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, P]),
 }

@@ -247,3 +247,50 @@ def upsample16_fwd(x_nhwc, w_c1_32_32, OH, OW, crop=8, scale=1.0, sigmoid=False,
     check(lib().dim_upsample16_fwd(dptr(x_nhwc, f32), dptr(w_c1_32_32, f32), dptr(out, f32), N, C, h, w, OH, OW, crop, float(scale),
                                    1 if sigmoid else 0, current_stream()))
     return out
+
+
+# ---------------------------------------------------------------- backward of the convolution stack
+def pad64(c):
+    return (c + 63) // 64 * 64
+
+
+def conv2d_dgrad_pack_weight(w_oihw, stride, pad):
+    Cout, Cin, KH, KW = w_oihw.shape
+    wp = _new((lib().dim_conv2d_dgrad_packed_weight_floats(Cout, Cin, KH, KW, stride, pad),), w_oihw)
+    check(lib().dim_conv2d_dgrad_pack_weight(dptr(w_oihw.contiguous(), f32), dptr(wp, f32), Cout, Cin, KH, KW, stride, pad, current_stream()))
+    return wp
+
+
+def conv2d_dgrad(dy_nhwc, Cout, w_dgrad_packed, dx_nhwc, Cin, KH, KW, stride, pad, accumulate=False, tile=3):
+    """dx[..., :Cin] (+)= dgrad(dy[..., :Cout]); dx / dy may be wider concat buffers."""
+    N, Ho, Wo, dy_cs = dy_nhwc.shape
+    _, H, W, dx_cs = dx_nhwc.shape
+    check(lib().dim_conv2d_dgrad(dptr(dy_nhwc, f32), dptr(w_dgrad_packed, f32), dptr(dx_nhwc, f32), N, H, W, Cin, dx_cs, Ho, Wo, Cout, dy_cs,
+                                 KH, KW, stride, pad, int(accumulate), tile, current_stream()))
+    return dx_nhwc
+
+
+def conv2d_wgrad(x_nhwc, Cin, dz_nhwc, Cout, KH, KW, stride, pad, dw_packed, splits=1, dz_coff=0, workspace=None, accumulate=False):
+    N, H, W, in_cs = x_nhwc.shape
+    _, Ho, Wo, dz_cs = dz_nhwc.shape
+    if splits > 1 and workspace is None:
+        workspace = _new((lib().dim_conv2d_wgrad_workspace_floats(Cout, Cin, KH, KW, splits),), x_nhwc)
+    check(lib().dim_conv2d_wgrad(dptr(x_nhwc, f32), dptr(dz_nhwc, f32), dptr(dw_packed, f32), dptr(workspace, f32), N, H, W, Cin, in_cs, Ho,
+                                 Wo, Cout, dz_cs, dz_coff, KH, KW, stride, pad, splits, int(accumulate), current_stream()))
+    return dw_packed
+
+
+def bias_grad(dz_nhwc, C, db, dz_coff=0, workspace=None, accumulate=False):
+    M = dz_nhwc.numel() // dz_nhwc.shape[-1]
+    if workspace is None:
+        workspace = _new((lib().dim_bias_grad_workspace_floats(M, C),), dz_nhwc)
+    check(lib().dim_bias_grad(dptr(dz_nhwc, f32), dptr(db, f32), dptr(workspace, f32), M, C, dz_nhwc.shape[-1], dz_coff, int(accumulate),
+                              current_stream()))
+    return db
+
+
+def lrelu_bwd(y_nhwc, dy_nhwc, C, slope=0.1, y_coff=0, dy_coff=0):
+    M = dy_nhwc.numel() // dy_nhwc.shape[-1]
+    check(lib().dim_lrelu_bwd(dptr(y_nhwc, f32), y_nhwc.shape[-1], y_coff, dptr(dy_nhwc, f32), dy_nhwc.shape[-1], dy_coff, M, C, float(slope),
+                              current_stream()))
+    return dy_nhwc

@@ -1,0 +1,99 @@
+"""GPU parity of the conv backward kernels (dgrad / wgrad / bias grad / LeakyReLU') vs torch autograd on the CPU (float64)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    assert torch.cuda.is_available()
+    from lib.hip import ops as _ops
+
+    return _ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+BWD_CASES = [
+    # N, H, W, Cin, Cout, k, s, p, wgrad splits
+    (2, 15, 20, 64, 64, 3, 1, 1, 1),
+    (2, 15, 20, 64, 128, 3, 2, 1, 2),
+    (1, 30, 40, 64, 128, 5, 2, 2, 3),
+    (2, 9, 11, 128, 64, 3, 2, 1, 1),
+    (1, 17, 23, 64, 128, 5, 2, 2, 1),   # odd sizes: phases of different extent
+    (2, 8, 10, 256, 512, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", BWD_CASES)
+def test_dgrad_wgrad_bias_vs_autograd(ops, case):
+    N, H, W, Cin, Cout, k, s, p, splits = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((N, Cin, H, W), generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn((Cout, Cin, k, k), generator=g, dtype=torch.float64) / np.sqrt(Cin * k * k)).requires_grad_()
+    b = torch.randn((Cout,), generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    Ho, Wo = y.shape[2:]
+    # dgrad into a wider buffer with accumulate on top of an existing value
+    dx = torch.full((N, H, W, ops.pad64(Cin) + 64), 0.5, device=DEV)
+    wd = ops.conv2d_dgrad_pack_weight(w.detach().float().to(DEV), s, p)
+    ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dx, Cin, k, k, s, p, accumulate=True)
+    got = dx[..., :Cin].permute(0, 3, 1, 2).cpu().double() - 0.5
+    scale = x.grad.abs().max().item()
+    assert (got - x.grad).abs().max().item() <= 2e-5 * scale + 1e-5
+    assert (dx[..., ops.pad64(Cin):] == 0.5).all()
+    dx2 = torch.empty((N, H, W, ops.pad64(Cin)), device=DEV)
+    ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dx2, Cin, k, k, s, p, accumulate=False)
+    assert (dx2[..., :Cin].permute(0, 3, 1, 2).cpu().double() - x.grad).abs().max().item() <= 2e-5 * scale + 1e-5
+    # wgrad in the packed layout == pack(dW)
+    dwp = torch.zeros_like(ops.conv2d_pack_weight(w.detach().float().to(DEV)))
+    ops.conv2d_wgrad(nhwc(x.detach().float()), Cin, nhwc(dy.float()), Cout, k, k, s, p, dwp, splits=splits)
+    ref = ops.conv2d_pack_weight(w.grad.float().to(DEV))
+    wscale = w.grad.abs().max().item()
+    assert (dwp - ref).abs().max().item() <= 3e-5 * wscale + 1e-5
+    db = torch.empty(Cout, device=DEV)
+    ops.bias_grad(nhwc(dy.float()), Cout, db)
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.float().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_wgrad_first_layer_cin8_and_fc6(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 8, 33, 41), generator=g, dtype=torch.float64)
+    w = torch.randn((64, 8, 7, 7), generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=2, padding=3)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    dwp = torch.zeros_like(ops.conv2d_pack_weight(w.detach().float().to(DEV)))
+    ops.conv2d_wgrad(nhwc(x.float()), 8, nhwc(dy.float()), 64, 7, 7, 2, 3, dwp, splits=4)
+    ref = ops.conv2d_pack_weight(w.grad.float().to(DEV))
+    assert (dwp - ref).abs().max().item() <= 3e-5 * w.grad.abs().max().item() + 1e-5
+    # fc6 as an 8x10 "convolution": wgrad in the fc packed layout
+    B = 3
+    feat = torch.randn((B, 1024, 8, 10), generator=g, dtype=torch.float64)
+    w6 = torch.randn((256, 81920), generator=g, dtype=torch.float64, requires_grad=True)
+    out = F.linear(feat.reshape(B, -1), w6)
+    dz = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(dz)
+    dwp6 = torch.zeros(256 * 81920, device=DEV)
+    ops.conv2d_wgrad(nhwc(feat.float()), 1024, dz.float().reshape(B, 1, 1, 256).to(DEV), 256, 8, 10, 1, 0, dwp6)
+    ref6 = ops.fc_pack_weight(w6.grad.float().to(DEV), 1024, 8, 10)
+    assert (dwp6 - ref6).abs().max().item() <= 3e-5 * w6.grad.abs().max().item() + 1e-5
+
+
+def test_lrelu_bwd(ops):
+    g = torch.Generator().manual_seed(2)
+    y = torch.randn((2, 5, 7, 96), generator=g).to(DEV)
+    dy = torch.randn((2, 5, 7, 128), generator=g).to(DEV)
+    ref = dy.clone()
+    ref[..., 32:96] *= torch.where(y[..., 16:80] > 0, 1.0, 0.1)
+    ops.lrelu_bwd(y, dy, 64, slope=0.1, y_coff=16, dy_coff=32)
+    np.testing.assert_allclose(dy.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
