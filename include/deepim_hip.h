@@ -121,9 +121,12 @@ int dim_splitk_reduce(const float* slabs, const float* bias, float* y, long M, i
 /* generalised dim_conv2d_fwd (no split-K): input pixel stride `in_cstride` (>= Cin), output written at channel offset
  * `out_coff` of rows `out_cstride` wide (concat buffers), and -- when osy > 0 -- scattered to
  * (oy,ox) = (ho*osy + ooy, wo*osx + oox) inside an OH x OW map (used for the phases of a deconvolution + Crop). */
+/* Ho/Wo > 0: explicit output grid (asymmetric padding); pad_w >= 0: horizontal padding differs from pad; accumulate: y += result */
 int dim_conv2d_fwd_ex(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int in_cstride,
                       int Cout, int KH, int KW, int stride, int pad, float slope, int tile, int out_cstride, int out_coff, int OH,
-                      int OW, int osy, int osx, int ooy, int oox, void* stream);
+                      int OW, int osy, int osx, int ooy, int oox, int Ho, int Wo, int pad_w, int accumulate, void* stream);
+/* dim_conv2d_pack_weight with the output channels zero-padded to CoutPad (multiple of 64) */
+int dim_conv2d_pack_weight_padded(const float* w_oihw, float* w_packed, int Cout, int CoutPad, int Cin, int KH, int KW, void* stream);
 /* Decoder (deepIM_flownet.py:213-299): y[..., out_coff:out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x, k=4, s=2, p=0) + bias,
  * offset=(crop,crop))) as four 2x2 sub-pixel convolutions on the MFMA kernel.  Weight: MXNet layout (Cin, Cout, 4, 4). */
 long dim_deconv4x4s2_packed_weight_floats(int Cin, int Cout);
@@ -164,6 +167,33 @@ int dim_bias_grad(const float* dz, float* db, float* workspace, int M, int C, in
 /* LeakyReLU backward in place on a channel range: dy *= (y > 0 ? 1 : slope) */
 int dim_lrelu_bwd(const float* y, int y_cstride, int y_coff, float* dy, int dy_cstride, int dy_coff, long M, int C, float slope,
                   void* stream);
+/* ---------------------------------------------------------------- training-only pieces (csrc/train.hip)
+ * layout converters: packed conv / fc weights (or gradients) back to the MXNet layouts; fc6 dgrad weights */
+int dim_conv2d_unpack_weight(const float* w_packed, float* w_oihw, int Cout, int CoutPad, int Cin, int KH, int KW, float scale,
+                             int accumulate, void* stream);
+int dim_fc_unpack_weight(const float* w_packed, float* w_out_in, int Out, int C, int H, int W, void* stream);
+int dim_fc_dgrad_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream);
+/* loss gradients (get_loss, deepIM_flownet.py:303-560); loss_sum (1 float, may be NULL) accumulates the un-scaled loss for metrics */
+int dim_flow_loss_grad(const float* flow_est, const float* flow_label, const float* flow_weights, float* grad, long n, float normalize_flow,
+                       float grad_scale, float* loss_sum, void* stream);
+int dim_logistic_grad(const float* logits, const float* label, float* grad, float* prob, long n, float grad_scale_over_num_output,
+                      void* stream);
+int dim_pm_l1_grad(const float* p_est, const float* p_obs, const float* weights, float* grad, long n, float norm_term, float grad_scale,
+                   float* loss_sum, void* stream);
+/* L2Normalization(instance, eps 1e-10) of the quaternion head; backward of the pose head down to dz6 (B,256) */
+int dim_quat_normalize(const float* rot, float* rot_norm, int B, void* stream);
+int dim_pose_head_bwd(const float* fc6a, const float* fc7, const float* rot_raw, const float* d_rot_norm, const float* d_trans,
+                      const float* fc7_w, const float* rot_w, const float* trans_w, float* d_rot, float* dz7, float* dz6, int B,
+                      void* stream);
+int dim_fc_wgrad(const float* dz, const float* x, float* dW, float* db, int B, int Out, int In, void* stream);
+int dim_upsample16_bwd(const float* dout_nchw, const float* w_c1_32_32, float* df_nhwc, int N, int C, int h, int w, int OH, int OW, int crop,
+                       float scale, void* stream);
+int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw, float* dx, float* dw_oihw, float* db, int N, int H, int W,
+                            int Cin, int in_cstride, int dx_cstride, int Cout, int KH, int KW, int pad, int accumulate_dx, void* stream);
+int dim_deconv4x4s2_tiny_bwd(const float* x, int x_cstride, const float* dy, int dy_cstride, int dy_coff, const float* w_iohw, float* dx,
+                             float* dw_iohw, float* db, int N, int H, int W, int Cin, int Cout, int OH, int OW, int crop, void* stream);
+/* mx.optimizer.SGD: mom = momentum*mom - lr*(rescale_grad*g + wd*w); w += mom */
+int dim_sgd_momentum(float* w, const float* grad, float* mom, long n, float lr, float momentum, float wd, float rescale_grad, void* stream);
 /* FullyConnected weight (Out, C*H*W) [mx Flatten order c,h,w] -> [(h,w,c)][Out] so fc6 is dim_conv2d_fwd
  * with KH=H, KW=W on the NHWC feature map. */
 int dim_fc_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream);

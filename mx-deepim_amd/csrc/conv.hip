@@ -318,7 +318,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const floa
 
 // OIHW (MXNet / reference layout) -> packed [chunk][Cout][32]  (a workgroup's B chunk is one contiguous block)
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KH, int KW,
-                                        int nchunks, int cin8) {
+                                        int nchunks, int cin8, int CoutValid) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)nchunks * 32 * Cout;
   if (idx >= total) return;
@@ -340,7 +340,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
     kw = tap - kh * KW;
   }
   float v = 0.f;
-  if (kh < KH && kw < KW && c < Cin) v = w[(((long)co * Cin + c) * KH + kh) * KW + kw];
+  if (kh < KH && kw < KW && c < Cin && co < CoutValid) v = w[(((long)co * Cin + c) * KH + kh) * KW + kw];
   wp[idx] = v;
 }
 
@@ -561,8 +561,19 @@ int dim_conv2d_pack_weight(const float* w_oihw, float* w_packed, int Cout, int C
   int nchunks = cin8 ? KH * 2 : KH * KW * (Cin / 32);
   long total = (long)nchunks * 32 * Cout;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed,
-                     Cout, Cin, KH, KW, nchunks, cin8);
+                     Cout, Cin, KH, KW, nchunks, cin8, Cout);
   return check_launch("pack_conv_weight");
+}
+
+// same, with the output-channel count padded with zero rows up to CoutPad (a multiple of 64): w_oihw has Cout rows
+int dim_conv2d_pack_weight_padded(const float* w_oihw, float* w_packed, int Cout, int CoutPad, int Cin, int KH, int KW, void* stream) {
+  DIM_REQUIRE(w_oihw && w_packed, "null weight pointer");
+  DIM_REQUIRE(Cin % 32 == 0 && CoutPad >= Cout && CoutPad % 64 == 0, "Cin %% 32 == 0 and CoutPad a multiple of 64 >= Cout required");
+  int nchunks = KH * KW * (Cin / 32);
+  long total = (long)nchunks * 32 * CoutPad;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed,
+                     CoutPad, Cin, KH, KW, nchunks, 0, Cout);
+  return check_launch("pack_conv_weight_padded");
 }
 
 int dim_fc_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream) {
@@ -669,8 +680,12 @@ int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, flo
 
 int dim_conv2d_fwd_ex(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int in_cstride,
                       int Cout, int KH, int KW, int stride, int pad, float slope, int tile, int out_cstride, int out_coff, int OH,
-                      int OW, int osy, int osx, int ooy, int oox, void* stream) {
+                      int OW, int osy, int osx, int ooy, int oox, int Ho, int Wo, int pad_w, int accumulate, void* stream) {
   ConvEx ex = {in_cstride, out_cstride, out_coff, OH, OW, osy, osx, ooy, oox};
+  ex.Ho = Ho;
+  ex.Wo = Wo;
+  ex.pad_w = pad_w;
+  ex.accumulate = accumulate;
   return conv2d_fwd_impl(x, w_packed, bias, y, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, slope, 1, tile, 0, stream, &ex);
 }
 

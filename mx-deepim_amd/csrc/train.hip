@@ -1,0 +1,454 @@
+// Training-only kernels: loss gradients, head / decoder backward pieces, weight-layout converters, SGD.
+//
+// Reference semantics (deepim/symbols/deepIM_flownet.py get_loss :303-560, executor deepim/core/module.py:1205-1209):
+//   flow loss   MakeLoss(w * (f_est - f/NORMALIZE_FLOW)^2, grad_scale = LW_FLOW/(480*640))          :344-352
+//   PM loss     MakeLoss(w * |(P_est - P_obs)/NORMALIZE_3D_POINT|, grad_scale = LW_PM/NUM_3D_SAMPLE) :446-499 (type L1)
+//   mask loss   LogisticRegressionOutput(x, y, grad_scale = LW_MASK)                                :531-536
+// MXNet-internal conventions assumed (source not in /root/reference -> "parity unpinned"):
+//   MakeLoss backward = grad_scale * d(loss)/dx (normalization 'null'); LogisticRegressionOutput backward =
+//   grad_scale / num_output * (sigmoid(x) - y) with num_output = label.size / batch; gradients are SUMMED over the batch
+//   (rescale_grad = 1.0, deepim/train.py:383); SGD: mom = momentum*mom - lr*(g + wd*w), w += mom, wd_mult = 0 for biases.
+#include "common.h"
+
+namespace dim {
+
+// ---------------------------------------------------------------------------------------------- weight layout converters
+// packed [chunk][Cout][32] (chunk = (32-channel slice, kh, kw) | first layer: (kh, 4-tap group)) -> OIHW.  Inverse of
+// pack_conv_weight_kernel (conv.hip); used to bring wgrad's output into the flat MXNet-layout gradient bucket.
+__global__ void unpack_conv_weight_kernel(const float* __restrict__ wp, float* __restrict__ w, int Cout, int CoutPad, int Cin, int KH, int KW,
+                                          int cin8, float scale, int accumulate) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)Cout * Cin * KH * KW;
+  if (idx >= total) return;
+  int kw = (int)(idx % KW);
+  long t = idx / KW;
+  int kh = (int)(t % KH); t /= KH;
+  int ci = (int)(t % Cin);
+  int co = (int)(t / Cin);
+  int kc, kin;
+  if (cin8) {
+    kc = kh * 2 + (kw >> 2);
+    kin = (kw & 3) * 8 + ci;
+  } else {
+    kc = (ci >> 5) * KH * KW + kh * KW + kw;
+    kin = ci & 31;
+  }
+  float v = wp[((long)kc * CoutPad + co) * 32 + kin] * scale;
+  w[idx] = accumulate ? w[idx] + v : v;
+}
+
+// fc packed [chunk = (32-channel slice, h, w)][Out][32] -> (Out, C*H*W) in MXNet's (c,h,w) flatten order
+__global__ void unpack_fc_weight_kernel(const float* __restrict__ wp, float* __restrict__ w, int Out, int C, int H, int W) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)Out * C * H * W;
+  if (idx >= total) return;
+  long k = idx % ((long)C * H * W);
+  int o = (int)(idx / ((long)C * H * W));
+  int c = (int)(k / (H * W));
+  int hw = (int)(k % (H * W));
+  long kc = (long)(c >> 5) * H * W + hw;
+  w[idx] = wp[(kc * Out + o) * 32 + (c & 31)];
+}
+
+// fc dgrad weights: dX (B, (h,w,c)) = dz (B, Out) * W  as a 1x1 "convolution" with Cin' = Out, Cout' = C*H*W (NHWC order):
+// wp[kc][n = (h,w,c)][kin] = W[o = kc*32+kin][c*H*W + h*W + w]
+__global__ void pack_fc_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Out, int C, int H, int W) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)Out * C * H * W;
+  if (idx >= total) return;
+  int kin = (int)(idx % 32);
+  long t = idx / 32;
+  long n = t % ((long)C * H * W);
+  int kc = (int)(t / ((long)C * H * W));
+  int c = (int)(n % C);
+  long hw = n / C;
+  wp[idx] = w[(long)(kc * 32 + kin) * C * H * W + (long)c * H * W + hw];
+}
+
+// ---------------------------------------------------------------------------------------------- loss gradients
+// flow: g = gs * w * 2 * (f_est - f/nf); also accumulates sum(w * (f_est - f/nf)^2) per block into loss_sum (metric)
+__global__ __launch_bounds__(256) void flow_loss_grad_kernel(const float* __restrict__ f_est, const float* __restrict__ f_lab,
+                                                             const float* __restrict__ wgt, float* __restrict__ grad, long n, float inv_nf,
+                                                             float gs, float* __restrict__ loss_sum) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  float local = 0.f;
+  if (i < n) {
+    float4 a = *reinterpret_cast<const float4*>(f_est + i), b = *reinterpret_cast<const float4*>(f_lab + i),
+           w = *reinterpret_cast<const float4*>(wgt + i);
+    float4 d = make_float4(a.x - b.x * inv_nf, a.y - b.y * inv_nf, a.z - b.z * inv_nf, a.w - b.w * inv_nf);
+    *reinterpret_cast<float4*>(grad + i) = make_float4(gs * w.x * 2.f * d.x, gs * w.y * 2.f * d.y, gs * w.z * 2.f * d.z, gs * w.w * 2.f * d.w);
+    local = w.x * d.x * d.x + w.y * d.y * d.y + w.z * d.z * d.z + w.w * d.w * d.w;
+  }
+  if (loss_sum) {
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);  // metric only; gradients never depend on it
+  }
+}
+
+// mask: x = pre-sigmoid logits; g = gs/num_output * (sigmoid(x) - y); prob output optional
+__global__ __launch_bounds__(256) void logistic_grad_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ grad,
+                                                            float* __restrict__ prob, long n, float gs_over_n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p = 1.f / (1.f + expf(-x[i]));
+  if (prob) prob[i] = p;
+  grad[i] = gs_over_n * (p - y[i]);
+}
+
+// PM (L1): g = gs * w * sign(p_est - p_obs) / norm_term     (all (B,3,N))
+__global__ void pm_l1_grad_kernel(const float* __restrict__ p_est, const float* __restrict__ p_obs, const float* __restrict__ wgt,
+                                  float* __restrict__ grad, long n, float inv_norm, float gs, float* __restrict__ loss_sum) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float local = 0.f;
+  if (i < n) {
+    float d = (p_est[i] - p_obs[i]) * inv_norm;
+    float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    grad[i] = gs * wgt[i] * s * inv_norm;
+    local = wgt[i] * fabsf(d);
+  }
+  if (loss_sum) {
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- pose head backward
+// L2Normalization(instance, eps=1e-10) forward: y = x / sqrt(sum x^2 + eps)
+__global__ void quat_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* q = x + 4 * b;
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + 1e-10f);
+  for (int i = 0; i < 4; ++i) y[4 * b + i] = q[i] / n;
+}
+
+// one block per sample: d_rot_norm, d_trans -> d_rot (through L2Normalization), d_fc7 -> dz7 (LeakyReLU') -> d_fc6a -> dz6
+__global__ __launch_bounds__(256) void pose_head_bwd_kernel(const float* __restrict__ fc6a, const float* __restrict__ fc7,
+                                                            const float* __restrict__ rot_raw, const float* __restrict__ d_rot_norm,
+                                                            const float* __restrict__ d_trans, const float* __restrict__ w7,
+                                                            const float* __restrict__ wr, const float* __restrict__ wt,
+                                                            float* __restrict__ d_rot, float* __restrict__ dz7, float* __restrict__ dz6) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  __shared__ float s_dr[4], s_dt[3], s_dz7[256];
+  if (t == 0) {
+    const float* q = rot_raw + 4 * b;
+    const float* g = d_rot_norm + 4 * b;
+    float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + 1e-10f);
+    float y[4], dot = 0.f;
+    for (int i = 0; i < 4; ++i) { y[i] = q[i] / n; dot += y[i] * g[i]; }
+    for (int i = 0; i < 4; ++i) { s_dr[i] = (g[i] - y[i] * dot) / n; d_rot[4 * b + i] = s_dr[i]; }
+    for (int i = 0; i < 3; ++i) s_dt[i] = d_trans[3 * b + i];  // inverse ZoomTrans backward = identity (b_zoom_grad False)
+  }
+  __syncthreads();
+  // d_fc7[t] = sum_o d_rot[o] Wr[o][t] + sum_o d_ztrans[o] Wt[o][t]
+  float g7 = 0.f;
+  for (int o = 0; o < 4; ++o) g7 = fmaf(s_dr[o], wr[o * 256 + t], g7);
+  for (int o = 0; o < 3; ++o) g7 = fmaf(s_dt[o], wt[o * 256 + t], g7);
+  g7 *= fc7[(long)b * 256 + t] > 0.f ? 1.f : 0.1f;
+  s_dz7[t] = g7;
+  dz7[(long)b * 256 + t] = g7;
+  __syncthreads();
+  // d_fc6a[t] = sum_o dz7[o] W7[o][t]
+  float g6 = 0.f;
+  for (int o = 0; o < 256; ++o) g6 = fmaf(s_dz7[o], w7[o * 256 + t], g6);
+  g6 *= fc6a[(long)b * 256 + t] > 0.f ? 1.f : 0.1f;
+  dz6[(long)b * 256 + t] = g6;
+}
+
+// dW[o][i] = sum_b A[b][o] * X[b][i];  db[o] = sum_b A[b][o]      (tiny fully-connected layers)
+__global__ void fc_wgrad_kernel(const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ dW, float* __restrict__ db,
+                                int B, int Out, int In) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Out * In) return;
+  int i = (int)(idx % In), o = (int)(idx / In);
+  float s = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float a = A[(long)b * Out + o];
+    s = fmaf(a, X[(long)b * In + i], s);
+    sb += a;
+  }
+  dW[idx] = s;
+  if (i == 0 && db) db[o] = sb;
+}
+
+// ---------------------------------------------------------------------------------------------- head backward pieces
+// backward of Deconvolution(k=32, s=16, group=C) + Crop(crop): dF[n,iy,ix,c] = sum_{ky,kx} dOut[n,c,16iy+ky-crop,16ix+kx-crop] wk[c,ky,kx]
+// one wave per output element
+__global__ __launch_bounds__(256) void upsample16_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ wk,
+                                                             float* __restrict__ df, int N, int C, int h, int w, int OH, int OW, int crop,
+                                                             float scale) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  long e = (long)blockIdx.x * 4 + wave;
+  if (e >= (long)N * h * w * C) return;
+  int c = (int)(e % C);
+  long t = e / C;
+  int ix = (int)(t % w); t /= w;
+  int iy = (int)(t % h);
+  int n = (int)(t / h);
+  float s = 0.f;
+  for (int k = lane; k < 1024; k += 64) {
+    int ky = k >> 5, kx = k & 31;
+    int oy = 16 * iy + ky - crop, ox = 16 * ix + kx - crop;
+    if ((unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW)
+      s = fmaf(dout[(((long)n * C + c) * OH + oy) * OW + ox], wk[((long)c * 32 + ky) * 32 + kx], s);
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) df[e] = s * scale;
+}
+
+// small-Cout conv backward, data: dX[pix][ci] (+)= sum_{co,kh,kw} dY[pix - tap][co] * W[co][ci][kh][kw]   (stride 1)
+// one thread per (pixel, 4 channels); w in MXNet layout (Cout,Cin,KH,KW)
+__global__ void conv_small_cout_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int H,
+                                             int W, int Cin, int dx_cstride, int Cout, int KH, int KW, int pad, int accumulate) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int c4n = (Cin + 3) / 4;
+  long total = (long)N * H * W * c4n;
+  if (idx >= total) return;
+  int c0 = (int)(idx % c4n) * 4;
+  long pix = idx / c4n;
+  int x = (int)(pix % W);
+  int y = (int)((pix / W) % H);
+  int n = (int)(pix / ((long)W * H));
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int kh = 0; kh < KH; ++kh) {
+    int oy = y + pad - kh;
+    if ((unsigned)oy >= (unsigned)H) continue;
+    for (int kw = 0; kw < KW; ++kw) {
+      int ox = x + pad - kw;
+      if ((unsigned)ox >= (unsigned)W) continue;
+      const float* g = dy + ((long)(n * H + oy) * W + ox) * Cout;
+      for (int co = 0; co < Cout; ++co) {
+        float gv = g[co];
+        for (int j = 0; j < 4; ++j)
+          if (c0 + j < Cin) acc[j] = fmaf(gv, w[(((long)co * Cin + c0 + j) * KH + kh) * KW + kw], acc[j]);
+      }
+    }
+  }
+  float* o = dx + pix * dx_cstride + c0;
+  for (int j = 0; j < 4; ++j)
+    if (c0 + j < Cin) o[j] = accumulate ? o[j] + acc[j] : acc[j];
+}
+
+// small-Cout conv backward, weights: dW[co][ci][kh][kw] = sum_pix dY[pix][co] * X[pix + tap][ci]; db[co] = sum_pix dY[pix][co]
+// grid (ceil(Cin/256), KH*KW, Cout); each thread owns one ci and walks the pixels (X rows are contiguous over ci: coalesced)
+__global__ __launch_bounds__(256) void conv_small_cout_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                    float* __restrict__ dw, float* __restrict__ db, int N, int H, int W,
+                                                                    int Cin, int in_cstride, int Cout, int KH, int KW, int pad) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tap = blockIdx.y, kh = tap / KW, kw = tap % KW;
+  const int co = blockIdx.z;
+  float s = 0.f, sb = 0.f;
+  for (int n = 0; n < N; ++n)
+    for (int y = 0; y < H; ++y) {
+      int iy = y - pad + kh;
+      for (int xx = 0; xx < W; ++xx) {
+        float g = dy[((long)(n * H + y) * W + xx) * Cout + co];
+        sb += g;
+        int ix = xx - pad + kw;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && ci < Cin)
+          s = fmaf(g, x[((long)(n * H + iy) * W + ix) * in_cstride + ci], s);
+      }
+    }
+  if (ci < Cin) dw[(((long)co * Cin + ci) * KH + kh) * KW + kw] = s;
+  if (ci == 0 && tap == 0 && db) db[co] = sb;
+}
+
+// tiny deconv (k4 s2, Cin,Cout <= 4) backward: dX, dW, db.  dy is a channel range of a concat buffer over the crop window.
+__global__ void deconv_tiny_bwd_data_kernel(const float* __restrict__ dy, int dy_cstride, int dy_coff, const float* __restrict__ w,
+                                            float* __restrict__ dx, int N, int H, int W, int Cin, int Cout, int OH, int OW, int crop) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)N * H * W * Cin) return;
+  int ci = (int)(idx % Cin);
+  long t = idx / Cin;
+  int ix = (int)(t % W); t /= W;
+  int iy = (int)(t % H);
+  int n = (int)(t / H);
+  float s = 0.f;
+  for (int ky = 0; ky < 4; ++ky) {
+    int oy = 2 * iy + ky - crop;
+    if ((unsigned)oy >= (unsigned)OH) continue;
+    for (int kx = 0; kx < 4; ++kx) {
+      int ox = 2 * ix + kx - crop;
+      if ((unsigned)ox >= (unsigned)OW) continue;
+      const float* g = dy + ((long)(n * OH + oy) * OW + ox) * dy_cstride + dy_coff;
+      for (int co = 0; co < Cout; ++co) s = fmaf(g[co], w[(((long)ci * Cout + co) * 4 + ky) * 4 + kx], s);
+    }
+  }
+  dx[idx] = s;
+}
+
+__global__ void deconv_tiny_bwd_weight_kernel(const float* __restrict__ x, int x_cstride, const float* __restrict__ dy, int dy_cstride,
+                                              int dy_coff, float* __restrict__ dw, float* __restrict__ db, int N, int H, int W, int Cin,
+                                              int Cout, int OH, int OW, int crop) {
+  // one block per (ci, co, ky, kx) [+ one extra set for db]; threads stride the input pixels
+  const int e = blockIdx.x;
+  const int kx = e % 4, ky = (e / 4) % 4, co = (e / 16) % Cout, ci = e / (16 * Cout);
+  float s = 0.f, sb = 0.f;
+  for (long p = threadIdx.x; p < (long)N * H * W; p += blockDim.x) {
+    int ix = (int)(p % W);
+    int iy = (int)((p / W) % H);
+    int n = (int)(p / ((long)W * H));
+    int oy = 2 * iy + ky - crop, ox = 2 * ix + kx - crop;
+    if ((unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW)
+      s = fmaf(x[p * x_cstride + ci], dy[((long)(n * OH + oy) * OW + ox) * dy_cstride + dy_coff + co], s);
+  }
+  if (ci == 0 && ky == 0 && kx == 0)
+    for (long p = threadIdx.x; p < (long)N * OH * OW; p += blockDim.x) sb += dy[p * dy_cstride + dy_coff + co];
+  __shared__ float red[256], redb[256];
+  red[threadIdx.x] = s;
+  redb[threadIdx.x] = sb;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { red[threadIdx.x] += red[threadIdx.x + off]; redb[threadIdx.x] += redb[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    dw[e] = red[0];
+    if (ci == 0 && ky == 0 && kx == 0 && db) db[co] = redb[0];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- SGD
+// mx.optimizer.SGD with momentum: mom = momentum*mom - lr*(rescale*g + wd*w); w += mom     (float4)
+__global__ void sgd_momentum_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ mom, long n, float lr,
+                                    float momentum, float wd, float rescale) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float m = momentum * mom[i] - lr * (rescale * g[i] + wd * w[i]);
+  mom[i] = m;
+  w[i] += m;
+}
+
+}  // namespace dim
+
+using namespace dim;
+
+extern "C" {
+
+int dim_conv2d_unpack_weight(const float* w_packed, float* w_oihw, int Cout, int CoutPad, int Cin, int KH, int KW, float scale,
+                             int accumulate, void* stream) {
+  DIM_REQUIRE(w_packed && w_oihw, "null pointer");
+  DIM_REQUIRE(CoutPad >= Cout, "CoutPad < Cout");
+  long total = (long)Cout * Cin * KH * KW;
+  hipLaunchKernelGGL(unpack_conv_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_packed, w_oihw, Cout, CoutPad,
+                     Cin, KH, KW, Cin == 8, scale, accumulate);
+  return check_launch("unpack_conv_weight");
+}
+
+int dim_fc_unpack_weight(const float* w_packed, float* w_out_in, int Out, int C, int H, int W, void* stream) {
+  DIM_REQUIRE(w_packed && w_out_in, "null pointer");
+  long total = (long)Out * C * H * W;
+  hipLaunchKernelGGL(unpack_fc_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_packed, w_out_in, Out, C, H, W);
+  return check_launch("unpack_fc_weight");
+}
+
+int dim_fc_dgrad_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream) {
+  DIM_REQUIRE(w_out_in && w_packed, "null pointer");
+  DIM_REQUIRE(Out % 32 == 0, "Out must be a multiple of 32");
+  long total = (long)Out * C * H * W;
+  hipLaunchKernelGGL(pack_fc_dgrad_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_out_in, w_packed, Out, C, H,
+                     W);
+  return check_launch("pack_fc_dgrad_weight");
+}
+
+int dim_flow_loss_grad(const float* flow_est, const float* flow_label, const float* flow_weights, float* grad, long n, float normalize_flow,
+                       float grad_scale, float* loss_sum, void* stream) {
+  if (n == 0) return DIM_OK;
+  DIM_REQUIRE(flow_est && flow_label && flow_weights && grad, "null pointer");
+  DIM_REQUIRE(n % 4 == 0, "element count must be a multiple of 4");
+  hipLaunchKernelGGL(flow_loss_grad_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, as_stream(stream), flow_est, flow_label, flow_weights,
+                     grad, n, 1.0f / normalize_flow, grad_scale, loss_sum);
+  return check_launch("flow_loss_grad");
+}
+
+int dim_logistic_grad(const float* logits, const float* label, float* grad, float* prob, long n, float grad_scale_over_num_output,
+                      void* stream) {
+  if (n == 0) return DIM_OK;
+  DIM_REQUIRE(logits && label && grad, "null pointer");
+  hipLaunchKernelGGL(logistic_grad_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), logits, label, grad, prob, n,
+                     grad_scale_over_num_output);
+  return check_launch("logistic_grad");
+}
+
+int dim_pm_l1_grad(const float* p_est, const float* p_obs, const float* weights, float* grad, long n, float norm_term, float grad_scale,
+                   float* loss_sum, void* stream) {
+  if (n == 0) return DIM_OK;
+  DIM_REQUIRE(p_est && p_obs && weights && grad, "null pointer");
+  hipLaunchKernelGGL(pm_l1_grad_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), p_est, p_obs, weights, grad, n,
+                     1.0f / norm_term, grad_scale, loss_sum);
+  return check_launch("pm_l1_grad");
+}
+
+int dim_quat_normalize(const float* rot, float* rot_norm, int B, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(rot && rot_norm, "null pointer");
+  hipLaunchKernelGGL(quat_normalize_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), rot, rot_norm, B);
+  return check_launch("quat_normalize");
+}
+
+int dim_pose_head_bwd(const float* fc6a, const float* fc7, const float* rot_raw, const float* d_rot_norm, const float* d_trans,
+                      const float* fc7_w, const float* rot_w, const float* trans_w, float* d_rot, float* dz7, float* dz6, int B,
+                      void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(fc6a && fc7 && rot_raw && d_rot_norm && d_trans && fc7_w && rot_w && trans_w && d_rot && dz7 && dz6, "null pointer");
+  hipLaunchKernelGGL(pose_head_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), fc6a, fc7, rot_raw, d_rot_norm, d_trans, fc7_w, rot_w,
+                     trans_w, d_rot, dz7, dz6);
+  return check_launch("pose_head_bwd");
+}
+
+int dim_fc_wgrad(const float* dz, const float* x, float* dW, float* db, int B, int Out, int In, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(dz && x && dW, "null pointer");
+  hipLaunchKernelGGL(fc_wgrad_kernel, dim3(ceil_div((long)Out * In, 256)), dim3(256), 0, as_stream(stream), dz, x, dW, db, B, Out, In);
+  return check_launch("fc_wgrad");
+}
+
+int dim_upsample16_bwd(const float* dout_nchw, const float* w_c1_32_32, float* df_nhwc, int N, int C, int h, int w, int OH, int OW, int crop,
+                       float scale, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(dout_nchw && w_c1_32_32 && df_nhwc, "null pointer");
+  long total = (long)N * h * w * C;
+  hipLaunchKernelGGL(upsample16_bwd_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, as_stream(stream), dout_nchw, w_c1_32_32, df_nhwc, N, C,
+                     h, w, OH, OW, crop, scale);
+  return check_launch("upsample16_bwd");
+}
+
+int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw, float* dx, float* dw_oihw, float* db, int N, int H, int W,
+                            int Cin, int in_cstride, int dx_cstride, int Cout, int KH, int KW, int pad, int accumulate_dx, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(x && dy && w_oihw && dw_oihw, "null pointer");
+  hipStream_t st = as_stream(stream);
+  if (dx) {
+    long total = (long)N * H * W * ((Cin + 3) / 4);
+    hipLaunchKernelGGL(conv_small_cout_dgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, dy, w_oihw, dx, N, H, W, Cin, dx_cstride,
+                       Cout, KH, KW, pad, accumulate_dx);
+  }
+  hipLaunchKernelGGL(conv_small_cout_wgrad_kernel, dim3(ceil_div(Cin, 256), KH * KW, Cout), dim3(256), 0, st, x, dy, dw_oihw, db, N, H, W,
+                     Cin, in_cstride, Cout, KH, KW, pad);
+  return check_launch("conv_small_cout_bwd");
+}
+
+int dim_deconv4x4s2_tiny_bwd(const float* x, int x_cstride, const float* dy, int dy_cstride, int dy_coff, const float* w_iohw, float* dx,
+                             float* dw_iohw, float* db, int N, int H, int W, int Cin, int Cout, int OH, int OW, int crop, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(x && dy && w_iohw && dw_iohw, "null pointer");
+  hipStream_t st = as_stream(stream);
+  if (dx) {
+    long total = (long)N * H * W * Cin;
+    hipLaunchKernelGGL(deconv_tiny_bwd_data_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, dy, dy_cstride, dy_coff, w_iohw, dx, N, H,
+                       W, Cin, Cout, OH, OW, crop);
+  }
+  hipLaunchKernelGGL(deconv_tiny_bwd_weight_kernel, dim3(Cin * Cout * 16), dim3(256), 0, st, x, x_cstride, dy, dy_cstride, dy_coff, dw_iohw,
+                     db, N, H, W, Cin, Cout, OH, OW, crop);
+  return check_launch("deconv_tiny_bwd");
+}
+
+int dim_sgd_momentum(float* w, const float* grad, float* mom, long n, float lr, float momentum, float wd, float rescale_grad, void* stream) {
+  if (n == 0) return DIM_OK;
+  DIM_REQUIRE(w && grad && mom, "null pointer");
+  hipLaunchKernelGGL(sgd_momentum_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), w, grad, mom, n, lr, momentum, wd,
+                     rescale_grad);
+  return check_launch("sgd_momentum");
+}
+
+}  // extern "C"

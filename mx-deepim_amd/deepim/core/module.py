@@ -1,0 +1,273 @@
+"""Training executor of the DeepIM graph on the HIP kernels.
+
+Mirror of the reference's training path: `MutableModule.fit`'s inner loop (/root/reference/deepim/core/module.py:1205-1213:
+forward_backward -> get_outputs -> update), the per-GPU executor (deepim/core/DataParallelExecutorGroup.py) and the
+kvstore-based SGD (`Module.init_optimizer` :533-623, `update` :666-688), for ONE process = ONE GPU:
+
+    forward_backward(batch)   train graph of deepim/symbols/deepIM_flownet.py:562-762 + get_loss :303-560, then the full
+                              backward (loss gradients -> heads -> decoder -> encoder) on hand-written HIP kernels
+    update()                  RCCL all-reduce(SUM) of the flat fp32 gradient (replaces kvstore push/pull; rescale_grad = 1.0,
+                              deepim/train.py:383) + mx.optimizer.SGD(momentum, wd) on the flat parameter vector
+
+Master parameters keep the MXNet layouts and names (one flat fp32 vector, 57.75 M elements); the kernels' packed copies
+(forward + dgrad layouts) are refreshed after every update.
+"""
+from __future__ import print_function, division
+
+import numpy as np
+import torch
+
+from lib.hip import ops
+from deepim.symbols.deepIM_flownet import ENCODER, FlowNetHip, deepIM_flownet
+
+FROZEN = ("upsampling_weight", "mask_upsampling_weight")  # attr lr_mult 0.0 (deepIM_flownet.py:334, :520)
+
+
+class MutableModule(object):
+    def __init__(self, config, arg_params, batch_size, device="cuda:0", process_group=None):
+        cfg = config
+        if not (cfg.network.PRED_FLOW and cfg.network.PRED_MASK and cfg.train_iter.SE3_PM_LOSS and not cfg.train_iter.SE3_DIST_LOSS):
+            raise NotImplementedError("the HIP training graph covers the shipped configuration: PRED_FLOW, PRED_MASK, SE3_PM_LOSS (L1)")
+        if cfg.train_iter.SE3_PM_LOSS_TYPE != "L1":
+            raise Exception("Unknown Point Matching Loss Type on the HIP path: {}".format(cfg.train_iter.SE3_PM_LOSS_TYPE))
+        self.cfg = cfg
+        self.B = batch_size
+        self.device = torch.device(device)
+        self.pg = process_group
+        d = self.device
+        sym = deepIM_flownet()
+        shapes = sym.infer_param_shapes(cfg)
+        # ---- flat master parameters / gradients / momentum, MXNet layouts, in the shape table's order
+        self.names = list(shapes.keys())
+        self.shapes = shapes
+        sizes = [int(np.prod(shapes[n])) for n in self.names]
+        total = sum(sizes)
+        self.flat_w = torch.empty(total, dtype=torch.float32, device=d)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=d)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=d)
+        self.w, self.g, self.m = {}, {}, {}
+        off = 0
+        for n, sz in zip(self.names, sizes):
+            self.w[n] = self.flat_w[off:off + sz].view(shapes[n])
+            self.g[n] = self.flat_g[off:off + sz].view(shapes[n])
+            self.m[n] = self.flat_m[off:off + sz].view(shapes[n])
+            self.w[n].copy_(torch.as_tensor(np.ascontiguousarray(arg_params[n]), dtype=torch.float32))
+            off += sz
+        # ---- forward executor shares the master tensors (params dict = views of flat_w)
+        self.net = FlowNetHip.__new__(FlowNetHip)
+        self._init_forward(cfg, batch_size)
+        self._init_backward(batch_size)
+        self.num_update = 0
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _init_forward(self, cfg, B):
+        net = self.net
+        FlowNetHip.__init__(net, cfg, {n: self.w[n].cpu().numpy() for n in self.names}, B, device=str(self.device))
+        net.params = self.w  # the executor reads biases / small weights straight from the master vector
+        d = self.device
+        H, W = 480, 640
+        self.zoom_mask_gt = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
+        self.zoom_flow_lab = torch.empty((B, 2, H, W), dtype=torch.float32, device=d)
+        self.zoom_flow_w = torch.empty((B, 2, H, W), dtype=torch.float32, device=d)
+        self.flow_est_crop = torch.empty((B, 2, H, W), dtype=torch.float32, device=d)
+        self.mask_logit = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
+        self.mask_prob = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
+        self.rot_norm = torch.empty((B, 4), dtype=torch.float32, device=d)
+        self.loss_sums = torch.zeros(3, dtype=torch.float32, device=d)  # flow, pm (un-scaled sums; metrics only)
+        self.T_means = np.asarray(cfg.dataset.trans_means, dtype=np.float32)
+        self.T_stds = np.asarray(cfg.dataset.trans_stds, dtype=np.float32)
+
+    def _init_backward(self, B):
+        d, net = self.device, self.net
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=d)  # noqa: E731
+        self.dacts = {name: torch.empty_like(net.acts[name]) for name, *_ in ENCODER}
+        self.dconcat3 = z(B, 30, 40, ops.pad64(770))
+        self.dconcat2 = z(B, 15, 20, ops.pad64(1026))
+        self.dflow4, self.dmask4 = z(B, 30, 40, 2), z(B, 30, 40, 1)
+        self.dflow5, self.dflow6 = z(B, 15, 20, 2), z(B, 8, 10, 2)
+        self.dflow_full, self.dlogit = z(B, 2, 480, 640), z(B, 1, 480, 640)
+        self.d_rot_norm, self.d_rot, self.d_trans = z(B, 4), z(B, 4), z(B, 3)
+        self.dz7, self.dz6 = z(B, 256), z(B, 256)
+        self.pts_est = None
+        self.dpts = None
+        # wgrad plan: enough workgroups to fill the chip (split over pixels), scratch = biggest slab set / packed gradient
+        self.wgrad_splits, max_ws, max_pack = {}, 4, 4
+        h, w, c = 480, 640, 8
+        for name, cout, k, s, p in ENCODER:
+            ho, wo = ops.conv_out_hw(h, w, k, k, s, p)
+            nchunks = k * 2 if c == 8 else k * k * (c // 32)
+            blocks = nchunks * (cout // 128 if cout % 128 == 0 else cout // 64)
+            nsteps = -(-B * ho * wo // 32)
+            sp = max(1, min(-(-1024 // blocks), max(1, nsteps // 4)))
+            self.wgrad_splits[name] = sp
+            max_ws = max(max_ws, ops.lib().dim_conv2d_wgrad_workspace_floats(cout, c, k, k, sp))
+            max_pack = max(max_pack, ops.lib().dim_conv2d_packed_weight_floats(cout, c, k, k))
+            h, w, c = ho, wo, cout
+        max_pack = max(max_pack, 256 * 81920, 4 * 4 * 512 * 1024, 4 * 4 * 256 * ops.pad64(1026))
+        self.ws = torch.empty(max_ws, dtype=torch.float32, device=d)
+        self.gpack = torch.empty(max_pack, dtype=torch.float32, device=d)
+        self.bias_ws = torch.empty(ops.lib().dim_bias_grad_workspace_floats(B * 240 * 320, 64) + 1024 * 64, dtype=torch.float32, device=d)
+        # dgrad-layout weights (refreshed by repack())
+        self.dgrad_packed = {}
+        self.repack(forward=False)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def repack(self, forward=True):
+        """master (MXNet layout) -> the kernels' packed copies: forward layouts (FlowNetHip.packed) and dgrad layouts"""
+        net, w = self.net, self.w
+        for name, cout, k, s, p in ENCODER:
+            if forward:
+                net.packed[name] = ops.conv2d_pack_weight(w[name + "_weight"])
+            if name != "flow_conv1":
+                self.dgrad_packed[name] = ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p)
+        if forward:
+            net.packed["fc6"] = ops.fc_pack_weight(w["fc6_weight"], 1024, 8, 10)
+            net.packed["deconv5"] = ops.deconv4x4s2_pack_weight(w["deconv5_weight"])
+            net.packed["deconv4"] = ops.deconv4x4s2_pack_weight(w["deconv4_weight"])
+            for n in ("Convolution1", "Convolution2", "Convolution3", "mask_conv3"):
+                net.packed[n] = ops.conv_small_cout_pack_weight(w[n + "_weight"])
+        self.dgrad_packed["fc6"] = ops.fc_dgrad_pack_weight(w["fc6_weight"], 1024, 8, 10)
+        # deconv dgrad = a plain stride-2 convolution of the output gradient with the deconv weight read as (O=Cin, I=Cout, 4, 4)
+        self.dgrad_packed["deconv5"] = ops.conv2d_pack_weight_padded(w["deconv5_weight"], 1024)
+        self.dgrad_packed["deconv4"] = ops.conv2d_pack_weight_padded(w["deconv4_weight"], ops.pad64(1026))
+
+    # ------------------------------------------------------------------------------------------------------------
+    def forward(self, batch):
+        """train graph forward (get_train_symbol :562-762).  batch: reference blob names (data + labels), CUDA tensors."""
+        cfg, net = self.cfg, self.net
+        H, W = 480, 640
+        # ZoomMask: the zoom window comes from mask_GT_observed and mask_rendered (zoom_mask.py:35-37)
+        ops.mask_bbox(batch["mask_gt_observed"], 0.3, out=net.bbox_obs)
+        ops.mask_bbox(batch["mask_rendered"], 0.2, out=net.bbox_ren)
+        ops.zoom_factor(net.bbox_obs, net.bbox_ren, batch["src_pose"], net.K, H, W, out=net.zoom_factor, status=net.status)
+        ops.zoom_net_input(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"], net.zoom_factor,
+                           net.plane_means, X=net.X)
+        ops.zoom_planes(batch["mask_gt_observed"], net.zoom_factor, post=1, out=self.zoom_mask_gt)
+        ops.zoom_planes(batch["flow"], net.zoom_factor, scale_mode=1, out=self.zoom_flow_lab)          # ZoomFlow :689-698
+        ops.zoom_planes(batch["flow_weights"], net.zoom_factor, post=2, out=self.zoom_flow_w)
+        net.encoder()
+        net.head()                                               # se3 = [rot (raw), inverse-zoomed trans]; fc7
+        ops.quat_normalize(net.se3[:, :4].contiguous(), out=self.rot_norm)   # L2Normalization :375
+        net.decoder()
+        p = self.w
+        ops.conv_small_cout_fwd(net.concat3, 770, net.packed["Convolution3"], p["Convolution3_bias"], 2, out=net.flow4)
+        ops.upsample16_fwd(net.flow4, p["upsampling_weight"], H, W, crop=8, out=self.flow_est_crop)
+        ops.conv_small_cout_fwd(net.concat3, 770, net.packed["mask_conv3"], p["mask_conv3_bias"], 1, out=net.mask4)
+        ops.upsample16_fwd(net.mask4, p["mask_upsampling_weight"], H, W, crop=8, out=self.mask_logit)
+        self.trans_est = net.se3[:, 4:].contiguous()
+        pts = batch["point_cloud_model"]
+        self.pts_est = ops.transform3d_fwd(pts, self.rot_norm, self.trans_est, batch["src_pose"], cfg.network.ROT_COORD, self.T_means,
+                                           self.T_stds, out=self.pts_est)
+        return {"rot_est_norm": self.rot_norm, "trans_est": self.trans_est, "flow_est_crop": self.flow_est_crop,
+                "mask_logit": self.mask_logit, "point_cloud_observed_est": self.pts_est, "zoom_factor": net.zoom_factor}
+
+    def backward(self, batch):
+        cfg, net, w, g = self.cfg, self.net, self.w, self.g
+        ti = cfg.train_iter
+        B = self.B
+        self.loss_sums.zero_()
+        # ---------------- loss gradients (get_loss :344-357, :446-499, :531-536)
+        ops.flow_loss_grad(self.flow_est_crop, self.zoom_flow_lab, self.zoom_flow_w, self.dflow_full, cfg.dataset.NORMALIZE_FLOW,
+                           ti.LW_FLOW / (480.0 * 640.0), loss_sum=self.loss_sums[0:1])
+        ops.logistic_grad(self.mask_logit, self.zoom_mask_gt, self.dlogit, ti.LW_MASK / (480.0 * 640.0), prob=self.mask_prob)
+        if self.dpts is None:
+            self.dpts = torch.empty_like(self.pts_est)
+        ops.pm_l1_grad(self.pts_est, batch["point_cloud_observed"], batch["point_cloud_weights"], self.dpts,
+                       cfg.dataset.NORMALIZE_3D_POINT, ti.LW_PM / float(ti.NUM_3D_SAMPLE), loss_sum=self.loss_sums[1:2])
+        d_rn, d_t = ops.transform3d_bwd(self.dpts, batch["point_cloud_model"], self.rot_norm, self.trans_est, batch["src_pose"],
+                                        cfg.network.ROT_COORD, self.T_means, self.T_stds)
+        # ---------------- flow / mask heads
+        ops.upsample16_bwd(self.dflow_full, w["upsampling_weight"], self.dflow4)
+        ops.conv_small_cout_bwd(net.concat3, 770, self.dflow4, w["Convolution3_weight"], self.dconcat3, g["Convolution3_weight"],
+                                g["Convolution3_bias"], accumulate_dx=False)
+        ops.upsample16_bwd(self.dlogit, w["mask_upsampling_weight"], self.dmask4)
+        ops.conv_small_cout_bwd(net.concat3, 770, self.dmask4, w["mask_conv3_weight"], self.dconcat3, g["mask_conv3_weight"],
+                                g["mask_conv3_bias"], accumulate_dx=True)
+        g["upsampling_weight"].zero_()
+        g["mask_upsampling_weight"].zero_()
+        # ---------------- decoder level 4: Concat3 = [ReLU6 | ReLU12 (deconv4) | upsample_flow5to4]
+        ops.deconv4x4s2_tiny_bwd(net.flow5, self.dconcat3, 768, w["upsample_flow5to4_weight"], self.dflow5, g["upsample_flow5to4_weight"],
+                                 g["upsample_flow5to4_bias"])
+        ops.lrelu_bwd(net.concat3, self.dconcat3, 256, y_coff=512, dy_coff=512)
+        self._deconv_bwd("deconv4", x=net.concat2, x_c=1026, x_cpad=ops.pad64(1026), dz=self.dconcat3, dz_coff=512, cout=256, dx=self.dconcat2)
+        ops.conv_small_cout_bwd(net.concat2, 1026, self.dflow5, w["Convolution2_weight"], self.dconcat2, g["Convolution2_weight"],
+                                g["Convolution2_bias"], accumulate_dx=True)
+        # ---------------- decoder level 5: Concat2 = [ReLU8 | ReLU11 (deconv5) | upsample_flow6to5]
+        ops.deconv4x4s2_tiny_bwd(net.flow6, self.dconcat2, 1024, w["upsample_flow6to5_weight"], self.dflow6, g["upsample_flow6to5_weight"],
+                                 g["upsample_flow6to5_bias"])
+        ops.lrelu_bwd(net.concat2, self.dconcat2, 512, y_coff=512, dy_coff=512)
+        d10 = self.dacts["conv6_1"]
+        self._deconv_bwd("deconv5", x=net.acts["conv6_1"], x_c=1024, x_cpad=1024, dz=self.dconcat2, dz_coff=512, cout=512, dx=d10)
+        ops.conv_small_cout_bwd(net.acts["conv6_1"], 1024, self.dflow6, w["Convolution1_weight"], d10, g["Convolution1_weight"],
+                                g["Convolution1_bias"], accumulate_dx=True)
+        # ---------------- pose head (fc7, rot, trans, fc6)
+        fc6a = net.fc6.view(B, 256)
+        ops.pose_head_bwd(fc6a, net.fc7, net.se3[:, :4].contiguous(), d_rn, d_t, w, self.d_rot, self.dz7, self.dz6)
+        ops.fc_wgrad(self.d_rot, net.fc7, g["rot_weight"], g["rot_bias"])
+        ops.fc_wgrad(d_t, net.fc7, g["trans_weight"], g["trans_bias"])
+        ops.fc_wgrad(self.dz7, fc6a, g["fc7_weight"], g["fc7_bias"])
+        dz6 = self.dz6.view(B, 1, 1, 256)
+        ops.conv2d_wgrad(net.acts["conv6_1"], 1024, dz6, 256, 8, 10, 1, 0, self.gpack)
+        ops.fc_unpack_weight(self.gpack, g["fc6_weight"], 1024, 8, 10)
+        torch.sum(self.dz6, dim=0, out=g["fc6_bias"])
+        # d(ReLU10) += dz6 * W6  (fc6 dgrad as a 1x1 convolution to 81920 "channels" = the NHWC feature map)
+        ops.conv2d_fwd_ex(dz6, 0, 256, self.dgrad_packed["fc6"], None, d10.view(B, 1, 1, 81920), 0, 81920, 1, 1, 1, 0, accumulate=True)
+        # ---------------- encoder, top down
+        prev = {ENCODER[i][0]: (ENCODER[i - 1][0] if i else None) for i in range(len(ENCODER))}
+        cin = {}
+        c = 8
+        for name, cout, k, s, p in ENCODER:
+            cin[name] = c
+            c = cout
+        for name, cout, k, s, p in reversed(ENCODER):
+            dy = self.dacts[name]
+            if name == "conv5_1":
+                dy.add_(self.dconcat2[..., :512])   # skip connection into Concat2
+            if name == "conv4_1":
+                dy.add_(self.dconcat3[..., :512])   # skip connection into Concat3
+            ops.lrelu_bwd(net.acts[name], dy, cout)
+            x = net.acts[prev[name]] if prev[name] else net.X
+            ops.conv2d_wgrad(x, cin[name], dy, cout, k, k, s, p, self.gpack, splits=self.wgrad_splits[name], workspace=self.ws)
+            ops.conv2d_unpack_weight(self.gpack, g[name + "_weight"])
+            ops.bias_grad(dy, cout, g[name + "_bias"], workspace=self.bias_ws)
+            if prev[name]:
+                ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False)
+        return g
+
+    def _deconv_bwd(self, name, x, x_c, x_cpad, dz, dz_coff, cout, dx):
+        """Deconvolution(k4,s2)+Crop(1,1) backward.  x: deconv input (N,h,w,stride>=x_cpad), dz: gradient w.r.t. the pre-activation
+        output = channels [dz_coff, dz_coff+cout) of a concat-gradient buffer over the crop window (N,oh,ow,stride)."""
+        g, w = self.g, self.w
+        N, h, wd, _ = x.shape
+        # weight gradient through the convolution view: conv'(input = dz, k4, s2, pad 1) with "output gradient" = x
+        ops.conv2d_wgrad_ex(dz, dz_coff, cout, x, 0, x_cpad, 4, 4, 2, 1, self.gpack)
+        ops.conv2d_unpack_weight(self.gpack, g[name + "_weight"], CoutPad=x_cpad)
+        ops.bias_grad(dz, cout, g[name + "_bias"], dz_coff=dz_coff, workspace=self.bias_ws)
+        # data gradient: the same convolution applied to dz
+        ops.conv2d_fwd_ex(dz, dz_coff, cout, self.dgrad_packed[name], None, dx, 0, x_cpad, 4, 4, 2, 1, Ho=h, Wo=wd, accumulate=False)
+
+    def forward_backward(self, batch):
+        out = self.forward(batch)
+        self.backward(batch)
+        return out
+
+    # ------------------------------------------------------------------------------------------------------------
+    def update(self, lr):
+        """kvstore push/pull + SGD (module.py:666-688): sum gradients over ranks, then the same update on every rank."""
+        cfg = self.cfg
+        if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                   and torch.distributed.get_world_size() > 1):
+            torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        mom, wd = float(cfg.TRAIN.momentum), float(cfg.TRAIN.wd)
+        for n in self.names:
+            if n in FROZEN:
+                continue
+            ops.sgd_momentum(self.w[n], self.g[n], self.m[n], lr, mom, wd if n.endswith("_weight") else 0.0, 1.0)
+        self.num_update += 1
+        self.repack(forward=True)
+
+    def get_params(self):
+        return {n: self.w[n].cpu().numpy() for n in self.names}
+
+    def get_grads(self):
+        return {n: self.g[n].cpu().numpy() for n in self.names}

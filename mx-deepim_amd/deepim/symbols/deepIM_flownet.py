@@ -195,9 +195,9 @@ class FlowNetHip(object):
                 if n + "_weight" in self.params:
                     self.packed[n] = ops.conv_small_cout_pack_weight(self.params[n + "_weight"])
             self.flow6 = torch.empty((B, 8, 10, 2), dtype=torch.float32, device=d)          # Convolution1
-            self.concat2 = torch.zeros((B, 15, 20, ops.pad32(1026)), dtype=torch.float32, device=d)  # [ReLU8 | ReLU11 | up6to5 | 0-pad]
+            self.concat2 = torch.zeros((B, 15, 20, ops.pad64(1026)), dtype=torch.float32, device=d)  # [ReLU8 | ReLU11 | up6to5 | 0-pad]
             self.flow5 = torch.empty((B, 15, 20, 2), dtype=torch.float32, device=d)         # Convolution2
-            self.concat3 = torch.zeros((B, 30, 40, ops.pad32(770)), dtype=torch.float32, device=d)   # [ReLU6 | ReLU12 | up5to4 | 0-pad]
+            self.concat3 = torch.zeros((B, 30, 40, ops.pad64(770)), dtype=torch.float32, device=d)   # [ReLU6 | ReLU12 | up5to4 | 0-pad]
             self.flow4 = torch.empty((B, 30, 40, 2), dtype=torch.float32, device=d)         # Convolution3
             self.mask4 = torch.empty((B, 30, 40, 1), dtype=torch.float32, device=d)         # mask_conv3
             self.zoom_flow = torch.empty((B, 2, H, W), dtype=torch.float32, device=d)

@@ -40,7 +40,21 @@ SIGNATURES = {
     "dim_conv2d_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, P]),
     "dim_conv2d_fwd_partial": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_splitk_reduce": (I, [P, P, P, L, I, I, F, P]),
-    "dim_conv2d_fwd_ex": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, I, I, I, I, I, I, I, I, I, P]),
+    "dim_conv2d_fwd_ex": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dim_conv2d_pack_weight_padded": (I, [P, P, I, I, I, I, I, P]),
+    "dim_conv2d_unpack_weight": (I, [P, P, I, I, I, I, I, F, I, P]),
+    "dim_fc_unpack_weight": (I, [P, P, I, I, I, I, P]),
+    "dim_fc_dgrad_pack_weight": (I, [P, P, I, I, I, I, P]),
+    "dim_flow_loss_grad": (I, [P, P, P, P, L, F, F, P, P]),
+    "dim_logistic_grad": (I, [P, P, P, P, L, F, P]),
+    "dim_pm_l1_grad": (I, [P, P, P, P, L, F, F, P, P]),
+    "dim_quat_normalize": (I, [P, P, I, P]),
+    "dim_pose_head_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, P]),
+    "dim_fc_wgrad": (I, [P, P, P, P, I, I, I, P]),
+    "dim_upsample16_bwd": (I, [P, P, P, I, I, I, I, I, I, I, F, P]),
+    "dim_conv_small_cout_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dim_deconv4x4s2_tiny_bwd": (I, [P, I, P, I, I, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "dim_sgd_momentum": (I, [P, P, P, L, F, F, F, F, P]),
     "dim_deconv4x4s2_packed_weight_floats": (L, [I, I]),
     "dim_deconv4x4s2_pack_weight": (I, [P, P, I, I, P]),
     "dim_deconv4x4s2_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, P]),

@@ -294,3 +294,117 @@ def lrelu_bwd(y_nhwc, dy_nhwc, C, slope=0.1, y_coff=0, dy_coff=0):
     check(lib().dim_lrelu_bwd(dptr(y_nhwc, f32), y_nhwc.shape[-1], y_coff, dptr(dy_nhwc, f32), dy_nhwc.shape[-1], dy_coff, M, C, float(slope),
                               current_stream()))
     return dy_nhwc
+
+
+# ---------------------------------------------------------------- training-only pieces (csrc/train.hip)
+def _p(t, off=0):
+    """device pointer of a contiguous CUDA f32 tensor, advanced by `off` floats (channel offset inside an NHWC row)"""
+    return dptr(t, f32) + 4 * off
+
+
+def conv2d_pack_weight_padded(w_oihw, CoutPad):
+    Cout, Cin, KH, KW = w_oihw.shape
+    wp = _new((KH * KW * Cin * CoutPad,), w_oihw)
+    check(lib().dim_conv2d_pack_weight_padded(dptr(w_oihw.contiguous(), f32), dptr(wp, f32), Cout, CoutPad, Cin, KH, KW, current_stream()))
+    return wp
+
+
+def conv2d_unpack_weight(w_packed, out_oihw, CoutPad=None, scale=1.0, accumulate=False):
+    Cout, Cin, KH, KW = out_oihw.shape
+    check(lib().dim_conv2d_unpack_weight(dptr(w_packed, f32), dptr(out_oihw, f32), Cout, CoutPad or Cout, Cin, KH, KW, float(scale),
+                                         int(accumulate), current_stream()))
+    return out_oihw
+
+
+def fc_unpack_weight(w_packed, out_w, C, H, W):
+    check(lib().dim_fc_unpack_weight(dptr(w_packed, f32), dptr(out_w, f32), out_w.shape[0], C, H, W, current_stream()))
+    return out_w
+
+
+def fc_dgrad_pack_weight(w_out_in, C, H, W, out=None):
+    Out = w_out_in.shape[0]
+    out = out if out is not None else _new((Out * C * H * W,), w_out_in)
+    check(lib().dim_fc_dgrad_pack_weight(dptr(w_out_in, f32), dptr(out, f32), Out, C, H, W, current_stream()))
+    return out
+
+
+def conv2d_fwd_ex(x, x_coff, Cin, w_packed, bias, y, y_coff, Cout, KH, KW, stride, pad, slope=1.0, tile=3, Ho=0, Wo=0, accumulate=False):
+    """dense generalised conv: channel windows [x_coff, x_coff+Cin) of x and [y_coff, y_coff+Cout) of y (NHWC concat buffers)."""
+    N, H, W, in_cs = x.shape
+    out_cs = y.shape[-1]
+    check(lib().dim_conv2d_fwd_ex(_p(x, x_coff), dptr(w_packed, f32), dptr(bias, f32), dptr(y, f32), N, H, W, Cin, in_cs, Cout, KH, KW, stride,
+                                  pad, float(slope), tile, out_cs, y_coff, 0, 0, 0, 0, 0, 0, Ho, Wo, -1, int(accumulate), current_stream()))
+    return y
+
+
+def conv2d_wgrad_ex(x, x_coff, Cin, dz, dz_coff, Cout, KH, KW, stride, pad, dw_packed, splits=1, workspace=None):
+    N, H, W, in_cs = x.shape
+    _, Ho, Wo, dz_cs = dz.shape
+    if splits > 1 and workspace is None:
+        workspace = _new((lib().dim_conv2d_wgrad_workspace_floats(Cout, Cin, KH, KW, splits),), x)
+    check(lib().dim_conv2d_wgrad(_p(x, x_coff), dptr(dz, f32), dptr(dw_packed, f32), dptr(workspace, f32), N, H, W, Cin, in_cs, Ho, Wo, Cout,
+                                 dz_cs, dz_coff, KH, KW, stride, pad, splits, 0, current_stream()))
+    return dw_packed
+
+
+def flow_loss_grad(flow_est, flow_label, flow_weights, grad, normalize_flow, grad_scale, loss_sum=None):
+    check(lib().dim_flow_loss_grad(dptr(flow_est, f32), dptr(flow_label, f32), dptr(flow_weights, f32), dptr(grad, f32), flow_est.numel(),
+                                   float(normalize_flow), float(grad_scale), dptr(loss_sum, f32), current_stream()))
+    return grad
+
+
+def logistic_grad(logits, label, grad, grad_scale_over_num_output, prob=None):
+    check(lib().dim_logistic_grad(dptr(logits, f32), dptr(label, f32), dptr(grad, f32), dptr(prob, f32), logits.numel(),
+                                  float(grad_scale_over_num_output), current_stream()))
+    return grad
+
+
+def pm_l1_grad(p_est, p_obs, weights, grad, norm_term, grad_scale, loss_sum=None):
+    check(lib().dim_pm_l1_grad(dptr(p_est, f32), dptr(p_obs, f32), dptr(weights, f32), dptr(grad, f32), p_est.numel(), float(norm_term),
+                               float(grad_scale), dptr(loss_sum, f32), current_stream()))
+    return grad
+
+
+def quat_normalize(rot, out=None):
+    out = out if out is not None else torch.empty_like(rot)
+    check(lib().dim_quat_normalize(dptr(rot, f32), dptr(out, f32), rot.shape[0], current_stream()))
+    return out
+
+
+def pose_head_bwd(fc6a, fc7, rot_raw, d_rot_norm, d_trans, p, d_rot, dz7, dz6):
+    check(lib().dim_pose_head_bwd(dptr(fc6a, f32), dptr(fc7, f32), dptr(rot_raw, f32), dptr(d_rot_norm, f32), dptr(d_trans, f32),
+                                  dptr(p["fc7_weight"], f32), dptr(p["rot_weight"], f32), dptr(p["trans_weight"], f32), dptr(d_rot, f32),
+                                  dptr(dz7, f32), dptr(dz6, f32), fc6a.shape[0], current_stream()))
+
+
+def fc_wgrad(dz, x, dW, db=None):
+    check(lib().dim_fc_wgrad(dptr(dz, f32), dptr(x, f32), dptr(dW, f32), dptr(db, f32), dz.shape[0], dz.shape[1], x.shape[1], current_stream()))
+
+
+def upsample16_bwd(dout_nchw, w_c1_32_32, df_nhwc, crop=8, scale=1.0):
+    N, C, OH, OW = dout_nchw.shape
+    _, h, w, _ = df_nhwc.shape
+    check(lib().dim_upsample16_bwd(dptr(dout_nchw, f32), dptr(w_c1_32_32, f32), dptr(df_nhwc, f32), N, C, h, w, OH, OW, crop, float(scale),
+                                   current_stream()))
+    return df_nhwc
+
+
+def conv_small_cout_bwd(x, Cin, dy, w_oihw, dx, dw, db, accumulate_dx=False, pad=1):
+    N, H, W, in_cs = x.shape
+    Cout, _, KH, KW = w_oihw.shape
+    check(lib().dim_conv_small_cout_bwd(dptr(x, f32), dptr(dy, f32), dptr(w_oihw, f32), dptr(dx, f32), dptr(dw, f32), dptr(db, f32), N, H, W,
+                                        Cin, in_cs, dx.shape[-1] if dx is not None else 0, Cout, KH, KW, pad, int(accumulate_dx),
+                                        current_stream()))
+
+
+def deconv4x4s2_tiny_bwd(x, dy, dy_coff, w_iohw, dx, dw, db, crop=1):
+    N, H, W, x_cs = x.shape
+    _, OH, OW, dy_cs = dy.shape
+    Cin, Cout = w_iohw.shape[:2]
+    check(lib().dim_deconv4x4s2_tiny_bwd(dptr(x, f32), x_cs, dptr(dy, f32), dy_cs, dy_coff, dptr(w_iohw, f32), dptr(dx, f32), dptr(dw, f32),
+                                         dptr(db, f32), N, H, W, Cin, Cout, OH, OW, crop, current_stream()))
+
+
+def sgd_momentum(w, grad, mom, lr, momentum, wd, rescale_grad=1.0):
+    check(lib().dim_sgd_momentum(dptr(w, f32), dptr(grad, f32), dptr(mom, f32), w.numel(), float(lr), float(momentum), float(wd),
+                                 float(rescale_grad), current_stream()))

@@ -1,0 +1,111 @@
+"""Training graph + gradients + SGD, torch-CPU autograd restatement (oracle; test-only).
+
+Restates /root/reference/deepim/symbols/deepIM_flownet.py get_train_symbol :562-762 and get_loss :303-560 for the shipped
+configuration (INPUT_MASK, PRED_MASK, PRED_FLOW, SE3_PM_LOSS type L1, no SE3_DIST_LOSS), with the MXNet-internal gradient
+conventions listed in SURVEY.md A11 ("parity unpinned": MXNet is absent):
+  MakeLoss backward = grad_scale * dloss/dx; LogisticRegressionOutput backward = grad_scale/num_output * (sigmoid(x) - y);
+  gradients summed over the batch; Transform3D / ZoomTrans use the reference's HAND-WRITTEN backward (oracle.transform3d,
+  zoom_trans.py:55-76), not autograd.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import flownet as oflow, transform3d as ot3d, zoom as ozoom
+
+
+class _Transform3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, rot, trans, pose_src, T_means, T_stds, rot_coord):
+        ctx.save = (points.detach().numpy(), rot.detach().numpy().astype(np.float32), trans.detach().numpy().astype(np.float32), pose_src,
+                    T_means, T_stds, rot_coord)
+        out = ot3d.forward(ctx.save[0], ctx.save[1], ctx.save[2], pose_src, T_means, T_stds, rot_coord)
+        return torch.from_numpy(out.astype(np.float64))
+
+    @staticmethod
+    def backward(ctx, g):
+        pts, rot, trans, pose_src, T_means, T_stds, rot_coord = ctx.save
+        d_rot, d_trans = ot3d.backward(g.numpy().astype(np.float32), pts, rot, trans, pose_src, T_means, T_stds, rot_coord)
+        return None, torch.from_numpy(d_rot.astype(np.float64)), torch.from_numpy(d_trans.astype(np.float64)), None, None, None, None
+
+
+class _InvZoomTrans(torch.autograd.Function):
+    """ZoomTrans(b_inv_zoom=True, b_zoom_grad=False): forward (dx,dy)*wx, backward identity (zoom_trans.py:37-41, :64-72)."""
+
+    @staticmethod
+    def forward(ctx, t, wx):
+        out = t.clone()
+        out[:, :2] = t[:, :2] * wx[:, None]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def loss_and_grads(params, batch, cfg, K, dtype=torch.float64):
+    """-> (outputs dict, grads dict name -> numpy in MXNet layouts).  batch: numpy blobs with the reference names."""
+    H, W = 480, 640
+    ti = cfg.train_iter
+    zmo, zmg, zmr, zf = ozoom.zoom_mask(batch["mask_observed"], batch["mask_gt_observed"], batch["mask_rendered"], batch["src_pose"], K, H, W)
+    zio, zir = ozoom.zoom_image_with_factor(zf, batch["image_observed"], batch["image_rendered"], cfg.network.PIXEL_MEANS, H, W)
+    zflow, zfw = ozoom.zoom_flow(zf, batch["flow"], batch["flow_weights"], b_inv_zoom=False, H=H, W=W)
+    data = oflow.network_input(zio, zir, zmo, zmr)
+    P = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype).requires_grad_(True) for k, v in params.items()}
+    x = torch.from_numpy(data).to(dtype)
+    feats = {}
+    from .flownet import ENCODER, crop_like
+
+    for name, cout, k, s, p in ENCODER:
+        x = F.leaky_relu(F.conv2d(x, P[name + "_weight"], P[name + "_bias"], stride=s, padding=p), 0.1)
+        feats[name] = x
+    fc6 = F.leaky_relu(F.linear(x.reshape(x.shape[0], -1), P["fc6_weight"], P["fc6_bias"]), 0.1)
+    fc7 = F.leaky_relu(F.linear(fc6, P["fc7_weight"], P["fc7_bias"]), 0.1)
+    rot = F.linear(fc7, P["rot_weight"], P["rot_bias"])
+    tz = F.linear(fc7, P["trans_weight"], P["trans_bias"])
+    rot_norm = rot / torch.sqrt((rot * rot).sum(dim=1, keepdim=True) + 1e-10)  # L2Normalization(instance)
+    trans_est = _InvZoomTrans.apply(tz, torch.from_numpy(zf[:, 0].astype(np.float64)).to(dtype))
+    # decoder
+    r10, r8, r6 = feats["conv6_1"], feats["conv5_1"], feats["conv4_1"]
+    c1 = F.conv2d(r10, P["Convolution1_weight"], P["Convolution1_bias"], padding=1)
+    d5 = F.leaky_relu(crop_like(F.conv_transpose2d(r10, P["deconv5_weight"], P["deconv5_bias"], stride=2), r8.shape[2:], (1, 1)), 0.1)
+    u65 = crop_like(F.conv_transpose2d(c1, P["upsample_flow6to5_weight"], P["upsample_flow6to5_bias"], stride=2), r8.shape[2:], (1, 1))
+    cat2 = torch.cat([r8, d5, u65], dim=1)
+    c2 = F.conv2d(cat2, P["Convolution2_weight"], P["Convolution2_bias"], padding=1)
+    d4 = F.leaky_relu(crop_like(F.conv_transpose2d(cat2, P["deconv4_weight"], P["deconv4_bias"], stride=2), r6.shape[2:], (1, 1)), 0.1)
+    u54 = crop_like(F.conv_transpose2d(c2, P["upsample_flow5to4_weight"], P["upsample_flow5to4_bias"], stride=2), r6.shape[2:], (1, 1))
+    cat3 = torch.cat([r6, d4, u54], dim=1)
+    f4 = F.conv2d(cat3, P["Convolution3_weight"], P["Convolution3_bias"], padding=1)
+    flow_est = crop_like(F.conv_transpose2d(f4, P["upsampling_weight"], None, stride=16, groups=2), (H, W), (8, 8))
+    m4 = F.conv2d(cat3, P["mask_conv3_weight"], P["mask_conv3_bias"], padding=1)
+    logit = crop_like(F.conv_transpose2d(m4, P["mask_upsampling_weight"], None, stride=16), (H, W), (8, 8))
+    # losses -> one scalar whose autograd gradient equals MXNet's head gradients
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dtype)  # noqa: E731
+    flow_loss_ = t(zfw) * (flow_est - t(zflow) / cfg.dataset.NORMALIZE_FLOW) ** 2
+    pts_est = _Transform3D.apply(t(batch["point_cloud_model"]), rot_norm, trans_est, batch["src_pose"], np.asarray(cfg.dataset.trans_means, np.float32),
+                                 np.asarray(cfg.dataset.trans_stds, np.float32), cfg.network.ROT_COORD)
+    pm_loss_ = t(batch["point_cloud_weights"]) * torch.abs((pts_est - t(batch["point_cloud_observed"])) / cfg.dataset.NORMALIZE_3D_POINT)
+    bce = F.binary_cross_entropy_with_logits(logit, t(zmg), reduction="sum")  # d/dx = sigmoid(x) - y
+    L = (ti.LW_FLOW / (480.0 * 640.0)) * flow_loss_.sum() + (ti.LW_PM / float(ti.NUM_3D_SAMPLE)) * pm_loss_.sum() + (ti.LW_MASK / (480.0 * 640.0)) * bce
+    for tnsr in (cat2, cat3, r10, r8, r6):
+        tnsr.retain_grad()
+    L.backward()
+    grads = {k: (v.grad.numpy().astype(np.float64) if v.grad is not None else np.zeros(v.shape)) for k, v in P.items()}
+    for k in ("upsampling_weight", "mask_upsampling_weight"):  # lr_mult 0: frozen
+        grads[k] = np.zeros_like(grads[k])
+    out = {"rot_est_norm": rot_norm.detach().numpy(), "trans_est": trans_est.detach().numpy(), "flow_est_crop": flow_est.detach().numpy(),
+           "mask_logit": logit.detach().numpy(), "zoom_factor": zf, "cat2": cat2.detach().numpy(), "cat3": cat3.detach().numpy(), "r10": r10.detach().numpy(), "d_cat2": cat2.grad.numpy(), "d_cat3": cat3.grad.numpy(),
+           "d_r10": r10.grad.numpy(), "d_r8": r8.grad.numpy(), "d_r6": r6.grad.numpy(), "flow_loss_sum": float(flow_loss_.sum()), "pm_loss_sum": float(pm_loss_.sum())}
+    return out, grads
+
+
+def sgd_step(params, grads, moms, lr, momentum, wd):
+    """mx.optimizer.SGD: mom = momentum*mom - lr*(g + wd*w); w += mom; wd_mult = 0 unless the name ends with _weight; frozen skipped."""
+    for k in params:
+        if k in ("upsampling_weight", "mask_upsampling_weight"):
+            continue
+        w = params[k].astype(np.float64)
+        m = momentum * moms[k] - lr * (grads[k] + (wd if k.endswith("_weight") else 0.0) * w)
+        moms[k] = m
+        params[k] = (w + m).astype(np.float32)
+    return params, moms

@@ -54,3 +54,50 @@ def make_test_config(test_iter=4):
     config.TEST.UPDATE_MASK = "box_rendered"
     config.TEST.INIT_MASK = "box_rendered"
     return config
+
+
+def make_train_scene(B=2, seed=2333, subdiv=3, npts=3000):
+    """train-graph blobs: the test scene + mask_gt_observed, flow labels (depth->flow restatement), point clouds."""
+    from oracle import se3 as ose3
+
+    sc = make_scene(B=B, seed=seed, subdiv=subdiv)
+    bl, K = sc["blobs"], sc["K"]
+    rng = np.random.default_rng(seed + 5)
+    mg, d_src, d_tgt, KT, pm, po = [], [], [], [], [], []
+    for b in range(B):
+        v, t, f, tex = sc["models"][int(bl["class_index"][b])]
+        gt, init = sc["pose_gt"][b], sc["pose_init"][b]
+        _, dg = native.render(v, t, f, tex, gt[:, :3], gt[:, 3], K)
+        _, dr = native.render(v, t, f, tex, init[:, :3], init[:, 3], K)
+        mg.append((dg > 0).astype(np.float32)[None, None])
+        d_src.append(dr[None, None]); d_tgt.append(dg[None, None])
+        R, tt = ose3.calc_se3(init, gt)
+        KT.append(np.dot(K, np.concatenate([R, tt.reshape(3, 1)], axis=1)).astype(np.float32)[None])
+        idx = rng.integers(0, v.shape[0], size=npts)
+        P = v[idx].T.astype(np.float32)
+        pm.append(P[None]); po.append((gt[:, :3] @ P + gt[:, 3:4]).astype(np.float32)[None])
+    flow, valid = native.gpu_flow(np.concatenate(d_src), np.concatenate(d_tgt), np.concatenate(KT), np.linalg.inv(K).astype(np.float32))
+    bl = dict(bl)
+    bl["mask_gt_observed"] = np.concatenate(mg)
+    bl["flow"] = flow
+    bl["flow_weights"] = np.tile(valid, (1, 2, 1, 1))  # batch_updater_py_multi.py:352
+    bl["point_cloud_model"] = np.concatenate(pm)
+    bl["point_cloud_weights"] = np.ones_like(bl["point_cloud_model"])
+    bl["point_cloud_observed"] = np.concatenate(po)
+    sc["blobs"] = bl
+    return sc
+
+
+def make_train_config():
+    cfg = make_test_config(test_iter=4)
+    cfg.network.TRAIN_ITER = True
+    cfg.network.TRAIN_ITER_SIZE = 4
+    cfg.train_iter.SE3_PM_LOSS = True
+    cfg.train_iter.LW_PM = 0.1
+    cfg.train_iter.NUM_3D_SAMPLE = 3000
+    cfg.train_iter.LW_FLOW = 0.25
+    cfg.train_iter.LW_MASK = 0.03
+    cfg.TRAIN.lr = 0.0001
+    cfg.TRAIN.momentum = 0.975
+    cfg.TRAIN.wd = 0.0005
+    return cfg

@@ -97,3 +97,31 @@ def test_lrelu_bwd(ops):
     ref[..., 32:96] *= torch.where(y[..., 16:80] > 0, 1.0, 0.1)
     ops.lrelu_bwd(y, dy, 64, slope=0.1, y_coff=16, dy_coff=32)
     np.testing.assert_allclose(dy.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 8, 10, 128, 15, 20), (1, 70, 15, 20, 64, 30, 40)])
+def test_deconv4x4s2_backward_via_conv_view(ops, shape):
+    """Deconvolution(k4,s2)+Crop(1,1) backward as used by the decoder: dgrad = stride-2 convolution of dz with the deconv weight
+    read as (O=Cin, I=Cout); wgrad through the same convolution view with the roles of x and dz swapped."""
+    N, Cin, H, W, Cout, OH, OW = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn((N, Cin, H, W), generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn((Cin, Cout, 4, 4), generator=g, dtype=torch.float64) / np.sqrt(Cin * 4)).requires_grad_()
+    y = F.conv_transpose2d(x, w, None, stride=2)[:, :, 1:1 + OH, 1:1 + OW]
+    dz = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dz)
+    cpad = ops.pad64(Cin)
+    xin = torch.zeros((N, H, W, cpad), device=DEV)
+    xin[..., :Cin] = nhwc(x.detach().float())
+    dzb = torch.zeros((N, OH, OW, Cout + 64), device=DEV)  # dz lives at channel offset 32 of a wider buffer
+    dzb[..., 32:32 + Cout] = nhwc(dz.float())
+    dx = torch.empty((N, H, W, cpad), device=DEV)
+    wd = ops.conv2d_pack_weight_padded(w.detach().float().to(DEV), cpad)
+    ops.conv2d_fwd_ex(dzb, 32, Cout, wd, None, dx, 0, cpad, 4, 4, 2, 1, Ho=H, Wo=W)
+    got = dx[..., :Cin].permute(0, 3, 1, 2).cpu().double()
+    assert (got - x.grad).abs().max().item() <= 2e-5 * x.grad.abs().max().item() + 1e-6
+    gp = torch.empty(16 * Cout * cpad, device=DEV)
+    ops.conv2d_wgrad_ex(dzb, 32, Cout, xin, 0, cpad, 4, 4, 2, 1, gp)
+    dw = torch.empty((Cin, Cout, 4, 4), device=DEV)
+    ops.conv2d_unpack_weight(gp, dw, CoutPad=cpad)
+    assert (dw.cpu().double() - w.grad).abs().max().item() <= 3e-5 * w.grad.abs().max().item() + 1e-6
