@@ -74,6 +74,8 @@ int dim_se3_compose(const float* pose_src, const float* se3, float* pose_out, do
 /* (rot_quat, trans) = calc_RT_delta(pose_src, pose_tgt, rot_type="QUAT")  (RT_transform.py:16-48) */
 int dim_se3_delta(const float* pose_src, const float* pose_tgt, float* rot_quat, float* trans, int B, int rot_coord,
                   const float* T_means3, const float* T_stds3, void* stream);
+/* KT (B,3,4) = K * calc_se3(pose_src, pose_tgt): the per-sample matrix dim_depth_to_flow needs (batch_updater_py_multi.py:306-312) */
+int dim_pose_to_KT(const float* pose_src, const float* pose_tgt, const float* K9, float* KT, int B, void* stream);
 /* Transform3D custom op (transform3d.py:42-327); points/out/out_grad are (B,3,Npts). */
 int dim_transform3d_fwd(const float* points, const float* rot, const float* trans, const float* pose_src, float* out, int B,
                         int Npts, int rot_coord, const float* T_means3, const float* T_stds3, void* stream);

@@ -144,6 +144,33 @@ __global__ void se3_delta_kernel(const float* __restrict__ pose_src, const float
   for (int i = 0; i < 3; ++i) trans[3 * b + i] = (float)dT[i];
 }
 
+// KT[b] = K * calc_se3(pose_src[b], pose_tgt[b])  (batch_updater_py_multi.py:306-312; RT_transform.calc_se3 :186-197 with the
+// float32 intermediates of lib/utils/projection.py:20,39).  Feeds dim_depth_to_flow.
+__global__ void pose_to_KT_kernel(const float* __restrict__ pose_src, const float* __restrict__ pose_tgt, double k00, double k01, double k02,
+                                  double k10, double k11, double k12, double k20, double k21, double k22, float* __restrict__ KT, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* ps = pose_src + 12 * b;
+  const float* pt = pose_tgt + 12 * b;
+  // se3_inverse(pose_src) -> float32
+  float Ri[9], Ti[3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Ri[3 * i + j] = ps[4 * j + i];
+  for (int i = 0; i < 3; ++i)
+    Ti[i] = (float)(-1.0 * ((double)Ri[3 * i] * ps[3] + (double)Ri[3 * i + 1] * ps[7] + (double)Ri[3 * i + 2] * ps[11]));
+  // se3_mul(pose_tgt, inverse) -> float32
+  float M[12];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      M[4 * i + j] = (float)((double)pt[4 * i] * Ri[j] + (double)pt[4 * i + 1] * Ri[3 + j] + (double)pt[4 * i + 2] * Ri[6 + j]);
+    M[4 * i + 3] = (float)(((double)pt[4 * i] * Ti[0] + (double)pt[4 * i + 1] * Ti[1] + (double)pt[4 * i + 2] * Ti[2]) + (double)pt[4 * i + 3]);
+  }
+  const double K[9] = {k00, k01, k02, k10, k11, k12, k20, k21, k22};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j)
+      KT[12 * b + 4 * i + j] = (float)(K[3 * i] * M[j] + K[3 * i + 1] * M[4 + j] + K[3 * i + 2] * M[8 + j]);
+}
+
 // ZoomTrans forward and backward (one thread per sample)
 __global__ void zoom_trans_kernel(const float* __restrict__ zoom_factor, const float* __restrict__ in, float* __restrict__ out,
                                   int B, int mode /*0 copy, 1 divide by wx, 2 multiply by wx*/) {
@@ -344,6 +371,15 @@ int dim_se3_delta(const float* pose_src, const float* pose_tgt, float* rot_quat,
                      rot_coord, (double)T_means3[0], (double)T_means3[1], (double)T_means3[2], (double)T_stds3[0],
                      (double)T_stds3[1], (double)T_stds3[2]);
   return check_launch("se3_delta");
+}
+
+int dim_pose_to_KT(const float* pose_src, const float* pose_tgt, const float* K9, float* KT, int B, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(pose_src && pose_tgt && K9 && KT, "null pointer");
+  hipLaunchKernelGGL(pose_to_KT_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, pose_tgt, (double)K9[0],
+                     (double)K9[1], (double)K9[2], (double)K9[3], (double)K9[4], (double)K9[5], (double)K9[6], (double)K9[7], (double)K9[8],
+                     KT, B);
+  return check_launch("pose_to_KT");
 }
 
 int dim_zoom_trans(const float* zoom_factor, const float* in, float* out, int B, int mode, void* stream) {

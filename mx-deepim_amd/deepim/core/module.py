@@ -271,3 +271,19 @@ class MutableModule(object):
 
     def get_grads(self):
         return {n: self.g[n].cpu().numpy() for n in self.names}
+
+
+def fit_batch(module, data_batch, batch_updater, lr):
+    """The inner TRAIN_ITER_SIZE loop of MutableModule.fit (reference module.py:1205-1213): every iteration is a separate
+    optimizer step on refreshed inputs.  Returns the per-iteration outputs (what get_outputs feeds update_metric)."""
+    cfg = module.cfg
+    n_iter = int(cfg.network.TRAIN_ITER_SIZE) if cfg.network.TRAIN_ITER else 1
+    outs = []
+    for iter_idx in range(n_iter):
+        preds = module.forward_backward(data_batch)
+        outs.append({"rot_est_norm": preds["rot_est_norm"].clone(), "trans_est": preds["trans_est"].clone(),
+                     "loss_sums": module.loss_sums.clone()})
+        module.update(lr)
+        if iter_idx != n_iter - 1:
+            data_batch = batch_updater.forward(data_batch, preds, cfg)
+    return outs

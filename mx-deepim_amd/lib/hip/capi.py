@@ -28,6 +28,7 @@ SIGNATURES = {
     "dim_zoom_trans": (I, [P, P, P, I, I, P]),
     "dim_se3_compose": (I, [P, P, P, P, I, I, P, P, P]),
     "dim_se3_delta": (I, [P, P, P, P, I, I, P, P, P]),
+    "dim_pose_to_KT": (I, [P, P, P, P, I, P]),
     "dim_transform3d_fwd": (I, [P, P, P, P, P, I, I, I, P, P, P]),
     "dim_transform3d_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P, P]),
     "dim_depth_to_flow": (I, [P, P, P, P, I, I, I, P, P, P]),

@@ -408,3 +408,11 @@ def deconv4x4s2_tiny_bwd(x, dy, dy_coff, w_iohw, dx, dw, db, crop=1):
 def sgd_momentum(w, grad, mom, lr, momentum, wd, rescale_grad=1.0):
     check(lib().dim_sgd_momentum(dptr(w, f32), dptr(grad, f32), dptr(mom, f32), w.numel(), float(lr), float(momentum), float(wd),
                                  float(rescale_grad), current_stream()))
+
+
+def pose_to_KT(pose_src, pose_tgt, K, out=None):
+    B = pose_src.shape[0]
+    out = out if out is not None else _new((B, 3, 4), pose_src)
+    keep, kp = host_f32(K, 9)
+    check(lib().dim_pose_to_KT(dptr(pose_src, f32), dptr(pose_tgt, f32), kp, dptr(out, f32), B, current_stream()))
+    return out

@@ -57,3 +57,36 @@ def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord=
             pose_rendered = pose_new
             out = flownet.forward_test(params, batch, K, pixel_means, fast_test=fast_test)
     return poses, se3s
+
+
+def update_train_batch(blobs, preds, meshes, K, pixel_means, T_means, T_stds, rot_coord="CAMERA", znear=0.25, zfar=6.0):
+    """batchUpdaterPyMulti.forward restated (lib/pair_matching/batch_updater_py_multi.py:205-365) for one GPU's blobs (numpy).
+    preds: rot_est (B,4) [= rot_est_norm], trans_est (B,3).  Returns the dict of updated blobs."""
+    B = blobs["src_pose"].shape[0]
+    H, W = blobs["image_rendered"].shape[2:]
+    K = np.asarray(K, dtype=np.float32)
+    Kinv = np.linalg.inv(np.matrix(K))
+    pm = np.asarray(pixel_means, dtype=np.float32).reshape(3)[[2, 1, 0]].reshape(3, 1, 1)  # self.pixel_means (:24-25)
+    img = np.zeros((B, 3, H, W))
+    dep = np.zeros((B, 1, H, W))
+    rot_res, trans_res, poses, KT = np.zeros((B, 4)), np.zeros((B, 3)), np.zeros((B, 3, 4)), np.zeros((B, 3, 4))
+    for b in range(B):
+        refined = ose3.RT_transform(np.squeeze(blobs["src_pose"][b]), np.squeeze(preds["rot_est"][b]), np.squeeze(preds["trans_est"][b]),
+                                    T_means, T_stds, rot_coord)
+        v, t, f, tex = meshes[int(blobs["class_index"][b])]
+        bgr, depth = native.render(v, t, f, tex, refined[:3, :3], refined[:3, 3], K, znear=znear, zfar=zfar)
+        im = bgr[:, :, [2, 1, 0]].transpose([2, 0, 1]).astype(np.float32)
+        im -= pm
+        r, tr = ose3.calc_RT_delta(refined, np.squeeze(blobs["tgt_pose"][b]), T_means, T_stds, rot_coord, "QUAT")
+        poses[b], img[b], dep[b, 0], rot_res[b], trans_res[b] = refined, im, depth, r, tr
+        se3_m = np.zeros([3, 4])
+        se3_m[:, :3], se3_m[:, 3] = ose3.calc_se3(refined, np.squeeze(blobs["tgt_pose"][b]))
+        KT[b] = np.dot(K, se3_m)
+    out = dict(blobs)
+    mask = np.zeros(dep.shape)
+    mask[dep > 0.2] = 1
+    flow, valid = native.gpu_flow(dep.astype(np.float32), blobs["depth_gt_observed"].astype(np.float32), KT.astype(np.float32),
+                                  np.array(Kinv).astype(np.float32))
+    out.update(image_rendered=img.astype(np.float32), src_pose=poses.astype(np.float32), rot=rot_res.astype(np.float32),
+               trans=trans_res.astype(np.float32), flow=flow, flow_weights=np.tile(valid, [1, 2, 1, 1]), mask_rendered=mask.astype(np.float32))
+    return out

@@ -84,6 +84,12 @@ def make_train_scene(B=2, seed=2333, subdiv=3, npts=3000):
     bl["point_cloud_model"] = np.concatenate(pm)
     bl["point_cloud_weights"] = np.ones_like(bl["point_cloud_model"])
     bl["point_cloud_observed"] = np.concatenate(po)
+    bl["tgt_pose"] = sc["pose_gt"].astype(np.float32)
+    bl["depth_gt_observed"] = np.concatenate(d_tgt).astype(np.float32)
+    z3, o3 = np.zeros(3), np.ones(3)
+    rt = [ose3.calc_RT_delta(sc["pose_init"][b], sc["pose_gt"][b], z3, o3, "CAMERA", "QUAT") for b in range(B)]
+    bl["rot"] = np.stack([r for r, _ in rt]).astype(np.float32)
+    bl["trans"] = np.stack([t for _, t in rt]).astype(np.float32)
     sc["blobs"] = bl
     return sc
 

@@ -9,7 +9,7 @@ def test_header_symbols_exported(hip_lib):
     from lib.hip import capi
 
     header = open(os.path.join(ROOT, "include", "deepim_hip.h")).read()
-    declared = set(re.findall(r"\b(dim_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(dim_[A-Za-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
     for name in declared:

@@ -91,3 +91,45 @@ def test_train_step_gradients_and_sgd(setup):
     out3 = mod2.forward(batch)
     np.testing.assert_allclose(out2["flow_est_crop"].cpu().numpy(), out3["flow_est_crop"].cpu().numpy(), atol=1e-6)
     np.testing.assert_array_equal(out2["rot_est_norm"].cpu().numpy(), out3["rot_est_norm"].cpu().numpy())
+
+
+def test_batch_updater_and_fit_batch_vs_oracle(setup):
+    """the between-iteration update (render -> labels -> depth->flow) and two chained optimizer steps"""
+    from deepim.core.module import MutableModule, fit_batch
+    from lib.pair_matching.batch_updater_py_multi import batchUpdaterPyMulti
+    from lib.render_hip.render_py_multi import Render_Py
+    from oracle import refine as orefine
+
+    cfg, params, scene = setup
+    B = 2
+    bl = scene["blobs"]
+    rm = Render_Py(None, cfg.dataset.class_name, scene["K"], meshes=scene["models"])
+    upd = batchUpdaterPyMulti(cfg, 480, 640, render_machine=rm)
+    batch = {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in bl.items()}
+    preds = {"rot_est_norm": torch.tensor([[0.999, 0.02, -0.03, 0.01], [0.98, -0.1, 0.05, 0.12]], device=DEV),
+             "trans_est": torch.tensor([[0.01, -0.02, 0.03], [-0.015, 0.01, -0.05]], device=DEV)}
+    preds["rot_est_norm"] = preds["rot_est_norm"] / preds["rot_est_norm"].norm(dim=1, keepdim=True)
+    new = upd.forward(batch, preds)
+    z3, o3 = np.zeros(3), np.ones(3)
+    ref = orefine.update_train_batch(bl, {"rot_est": preds["rot_est_norm"].cpu().numpy(), "trans_est": preds["trans_est"].cpu().numpy()},
+                                     scene["models"], scene["K"], cfg.network.PIXEL_MEANS, z3, o3)
+    np.testing.assert_allclose(new["src_pose"].cpu().numpy(), ref["src_pose"], atol=2e-6)
+    np.testing.assert_allclose(new["rot"].cpu().numpy(), ref["rot"], atol=5e-6)
+    np.testing.assert_allclose(new["trans"].cpu().numpy(), ref["trans"], atol=5e-6)
+    assert (new["mask_rendered"].cpu().numpy() != ref["mask_rendered"]).sum() <= 8
+    img_bad = (np.abs(new["image_rendered"].cpu().numpy() - ref["image_rendered"]).max(axis=1) > 1e-3).sum()
+    assert img_bad <= 32, img_bad
+    fw, rfw = new["flow_weights"].cpu().numpy(), ref["flow_weights"]
+    assert (fw != rfw).sum() <= 200 and fw.sum() > 1000
+    same = (fw == rfw) & (fw > 0)
+    np.testing.assert_allclose(new["flow"].cpu().numpy()[same], ref["flow"][same], atol=2e-3)
+    # two chained optimizer steps run and move the parameters; inputs of the 2nd step are the updater's outputs
+    cfg.network.TRAIN_ITER_SIZE = 2
+    mod = MutableModule(cfg, params, B)
+    batch = {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in bl.items()}
+    before = mod.flat_w.clone()
+    outs = fit_batch(mod, batch, upd, cfg.TRAIN.lr)
+    assert len(outs) == 2 and mod.num_update == 2
+    assert torch.isfinite(mod.flat_w).all() and (mod.flat_w - before).abs().max() > 0
+    assert not torch.equal(batch["src_pose"].cpu(), torch.as_tensor(bl["src_pose"]))  # src_pose advanced by the first iteration
+    cfg.network.TRAIN_ITER_SIZE = 4
