@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from lib.hip import ops
+from lib.utils.dist_utils import allreduce_sum_
 from deepim.symbols.deepIM_flownet import ENCODER, FlowNetHip, deepIM_flownet
 
 FROZEN = ("upsampling_weight", "mask_upsampling_weight")  # attr lr_mult 0.0 (deepIM_flownet.py:334, :520)
@@ -255,9 +256,7 @@ class MutableModule(object):
     def update(self, lr):
         """kvstore push/pull + SGD (module.py:666-688): sum gradients over ranks, then the same update on every rank."""
         cfg = self.cfg
-        if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                   and torch.distributed.get_world_size() > 1):
-            torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        allreduce_sum_(self.flat_g, group=self.pg)
         mom, wd = float(cfg.TRAIN.momentum), float(cfg.TRAIN.wd)
         for n in self.names:
             if n in FROZEN:

@@ -1,0 +1,69 @@
+"""CPU, world_size 2, gloo: the N>1 path -- pair sharding, gradient all-reduce(SUM) + identical SGD on every rank, MAX timing."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lib.utils.dist_utils import shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lib.utils.dist_utils import allreduce_sum_, barrier, max_over_ranks
+    from oracle import train as otrain
+
+    rng = np.random.RandomState(100 + rank)
+    shapes = {"conv_weight": (8, 4, 3, 3), "conv_bias": (8,), "upsampling_weight": (2, 1, 4, 4)}
+    params = {k: np.random.RandomState(7).randn(*s).astype(np.float32) for k, s in shapes.items()}  # same init on every rank
+    grads = {k: rng.randn(*s) for k, s in shapes.items()}                                            # rank-local gradients
+    flat = torch.from_numpy(np.concatenate([grads[k].ravel() for k in shapes]))
+    allreduce_sum_(flat)
+    off, summed = 0, {}
+    for k, s in shapes.items():
+        n = int(np.prod(s))
+        summed[k] = flat[off:off + n].numpy().reshape(s)
+        off += n
+    moms = {k: np.zeros(s) for k, s in shapes.items()}
+    params, moms = otrain.sgd_step(params, summed, moms, lr=1e-2, momentum=0.975, wd=5e-4)
+    t = max_over_ranks(1.0 + rank)
+    barrier()
+    np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), tmax=t, **{"g_" + k: grads[k] for k in shapes}, **{"s_" + k: summed[k] for k in shapes},
+             **{"p_" + k: params[k] for k in shapes})
+    dist.destroy_process_group()
+
+
+def test_allreduce_sum_sgd_and_timing_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "rank{}.npz".format(i))) for i in range(world)]
+    for k in ("conv_weight", "conv_bias", "upsampling_weight"):
+        np.testing.assert_allclose(r[0]["s_" + k], r[0]["g_" + k] + r[1]["g_" + k], rtol=1e-12)  # SUM, not mean
+        np.testing.assert_array_equal(r[0]["s_" + k], r[1]["s_" + k])
+        np.testing.assert_array_equal(r[0]["p_" + k], r[1]["p_" + k])                              # replicas stay identical
+    # every rank draws from its own RandomState(7): identical initial values; the frozen (lr_mult 0) tensor must not move
+    np.testing.assert_array_equal(r[0]["p_upsampling_weight"], np.random.RandomState(7).randn(2, 1, 4, 4).astype(np.float32))
+    assert float(r[0]["tmax"]) == 2.0 and float(r[1]["tmax"]) == 2.0
+
+
+def test_shard_range_partitions_pairs():
+    for total in (1, 7, 16, 128, 129):
+        for world in (1, 2, 4, 8):
+            cover = []
+            for rank in range(world):
+                b, e = shard_range(total, rank, world)
+                assert 0 <= b <= e <= total and (e - b) in (total // world, total // world + 1)
+                cover += list(range(b, e))
+            assert cover == list(range(total))
