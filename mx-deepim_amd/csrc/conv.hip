@@ -113,15 +113,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   // tap_off is wave-uniform (scalar): one vector add per load
 #define DIM_LOAD_A(REG, I)                                                                                         \
   if (I < A_PER_T) {                                                                                                \
-    bool ok = (unsigned)(a_hi0[I] + kh) < (unsigned)a.H && (unsigned)(a_wi0[I] + kw) < (unsigned)a.W &&             \
+    bool ok = pf_ok && (unsigned)(a_hi0[I] + kh) < (unsigned)a.H && (unsigned)(a_wi0[I] + kw) < (unsigned)a.W &&    \
               (!CIN8 || kw + (q >> 1) < a.KW);                                                                      \
     const float* src = ok ? a.x + (a_pix[I] + tap_off) : reinterpret_cast<const float*>(&g_zero16);                 \
     REG = *reinterpret_cast<const float4*>(src);                                                                    \
   }
 #define DIM_LOAD_B(REG, I) \
   if (I < B_PER_T) REG = *reinterpret_cast<const float4*>(wsrc + I * 32 * BK);
-#define DIM_LOAD_CHUNK(KC)                                       \
+  // PF_OK = false on the one prefetch past the last chunk: its (kh,kw,c0) counters already point one channel slice beyond
+  // the tensor, so the (unused) activation read must be redirected to the zero block -- it faulted when x ended at a page end
+#define DIM_LOAD_CHUNK(KC, PF_OK)                                \
   {                                                              \
+    const bool pf_ok = (PF_OK);                                  \
     const int tap_off = (kh * a.W + kw) * a.in_cstride + c0;     \
     DIM_LOAD_A(ra0, 0) DIM_LOAD_A(ra1, 1) DIM_LOAD_A(ra2, 2) DIM_LOAD_A(ra3, 3) \
     const float* wsrc = wbase + (long)(KC) * wchunk;             \
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (kc_begin < kc_end) {
-    DIM_LOAD_CHUNK(kc_begin)
+    DIM_LOAD_CHUNK(kc_begin, true)
     DIM_ADVANCE()
     DIM_STORE_CHUNK(0)
   }
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     // prefetch the next chunk into registers (the last iteration re-reads a clamped chunk: branch-free)
     const int kn = min(kc + 1, a.nchunks - 1);
-    DIM_LOAD_CHUNK(kn)
+    DIM_LOAD_CHUNK(kn, kc + 1 < kc_end)
     DIM_ADVANCE()
     __builtin_amdgcn_sched_barrier(0);  // keep the global prefetch AHEAD of the MFMA block (hipcc sinks it otherwise)
 #pragma unroll

@@ -185,3 +185,39 @@ def build_device_batch(render_machine, B, seed, n_classes=1, pixel_means=PIXEL_M
     return {"image_observed": image_observed, "image_rendered": image_rendered, "mask_observed": mask_observed,
             "mask_rendered": mask_rendered, "src_pose": torch.from_numpy(init).to(d), "class_index": cls_t,
             "pose_gt": torch.from_numpy(gt).to(d)}
+
+
+def build_device_train_batch(render_machine, B, seed, models, n_classes=1, pixel_means=PIXEL_MEANS, npts=3000, device="cuda:0"):
+    """build_device_batch + the training blobs/labels (reference names, deepim/core/loader.py:164-193): mask_gt_observed, tgt_pose,
+    depth_gt_observed, rot/trans labels, flow/flow_weights (depth->flow kernel), point clouds."""
+    import torch
+
+    from lib.hip import ops
+
+    b = build_device_batch(render_machine, B, seed, n_classes=n_classes, pixel_means=pixel_means, device=device)
+    d = torch.device(device)
+    H, W = render_machine.height, render_machine.width
+    K = render_machine.K
+    gt, init = b["pose_gt"], b["src_pose"]
+    depth_gt = torch.empty((B, 1, H, W), device=d)
+    depth_r = torch.empty((B, 1, H, W), device=d)
+    mask_gt = torch.empty((B, 1, H, W), device=d)
+    render_machine.render_batch(b["class_index"], gt, depth=depth_gt, mask=mask_gt, mask_thr=0.0)
+    render_machine.render_batch(b["class_index"], init, depth=depth_r)
+    z3, o3 = np.zeros(3, np.float32), np.ones(3, np.float32)
+    rot, trans = ops.se3_delta(init, gt, "CAMERA", z3, o3)
+    KT = ops.pose_to_KT(init, gt, K)
+    flow, valid = ops.depth_to_flow(depth_r, depth_gt, KT, np.linalg.inv(K).astype(np.float32))
+    rng = np.random.default_rng(seed + 17)
+    cls = b["class_index"].cpu().numpy()
+    gt_np = gt.cpu().numpy()
+    pm, po = [], []
+    for i in range(B):
+        v = models[int(cls[i])][0]
+        P = np.ascontiguousarray(v[rng.integers(0, v.shape[0], size=npts)].T.astype(np.float32))
+        pm.append(P[None])
+        po.append((gt_np[i][:, :3] @ P + gt_np[i][:, 3:4]).astype(np.float32)[None])
+    b.update(mask_gt_observed=mask_gt, tgt_pose=gt.clone(), depth_gt_observed=depth_gt, rot=rot, trans=trans, flow=flow,
+             flow_weights=valid.repeat(1, 2, 1, 1).contiguous(), point_cloud_model=torch.from_numpy(np.concatenate(pm)).to(d),
+             point_cloud_weights=torch.ones((B, 3, npts), device=d), point_cloud_observed=torch.from_numpy(np.concatenate(po)).to(d))
+    return b
