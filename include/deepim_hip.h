@@ -190,8 +190,10 @@ int dim_pose_head_bwd(const float* fc6a, const float* fc7, const float* rot_raw,
 int dim_fc_wgrad(const float* dz, const float* x, float* dW, float* db, int B, int Out, int In, void* stream);
 int dim_upsample16_bwd(const float* dout_nchw, const float* w_c1_32_32, float* df_nhwc, int N, int C, int h, int w, int OH, int OW, int crop,
                        float scale, void* stream);
-int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw, float* dx, float* dw_oihw, float* db, int N, int H, int W,
-                            int Cin, int in_cstride, int dx_cstride, int Cout, int KH, int KW, int pad, int accumulate_dx, void* stream);
+long dim_conv_small_cout_bwd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW);
+int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw, float* dx, float* dw_oihw, float* db, float* workspace,
+                            int N, int H, int W, int Cin, int in_cstride, int dx_cstride, int Cout, int KH, int KW, int pad,
+                            int accumulate_dx, void* stream);
 int dim_deconv4x4s2_tiny_bwd(const float* x, int x_cstride, const float* dy, int dy_cstride, int dy_coff, const float* w_iohw, float* dx,
                              float* dw_iohw, float* db, int N, int H, int W, int Cin, int Cout, int OH, int OW, int crop, void* stream);
 /* mx.optimizer.SGD: mom = momentum*mom - lr*(rescale_grad*g + wd*w); w += mom */

@@ -79,9 +79,12 @@ __global__ __launch_bounds__(256) void flow_loss_grad_kernel(const float* __rest
     *reinterpret_cast<float4*>(grad + i) = make_float4(gs * w.x * 2.f * d.x, gs * w.y * 2.f * d.y, gs * w.z * 2.f * d.z, gs * w.w * 2.f * d.w);
     local = w.x * d.x * d.x + w.y * d.y * d.y + w.z * d.z * d.z + w.w * d.w * d.w;
   }
-  if (loss_sum) {
+  if (loss_sum) {  // metric only; gradients never depend on it.  One atomic per workgroup (per-wave atomics serialised: 0.5 ms)
+    __shared__ float red[4];
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);  // metric only; gradients never depend on it
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
   }
 }
 
@@ -230,27 +233,51 @@ __global__ void conv_small_cout_dgrad_kernel(const float* __restrict__ dy, const
 }
 
 // small-Cout conv backward, weights: dW[co][ci][kh][kw] = sum_pix dY[pix][co] * X[pix + tap][ci]; db[co] = sum_pix dY[pix][co]
-// grid (ceil(Cin/256), KH*KW, Cout); each thread owns one ci and walks the pixels (X rows are contiguous over ci: coalesced)
-__global__ __launch_bounds__(256) void conv_small_cout_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                    float* __restrict__ dw, float* __restrict__ db, int N, int H, int W,
-                                                                    int Cin, int in_cstride, int Cout, int KH, int KW, int pad) {
-  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
-  const int tap = blockIdx.y, kh = tap / KW, kw = tap % KW;
-  const int co = blockIdx.z;
-  float s = 0.f, sb = 0.f;
-  for (int n = 0; n < N; ++n)
-    for (int y = 0; y < H; ++y) {
-      int iy = y - pad + kh;
-      for (int xx = 0; xx < W; ++xx) {
-        float g = dy[((long)(n * H + y) * W + xx) * Cout + co];
-        sb += g;
-        int ix = xx - pad + kw;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && ci < Cin)
-          s = fmaf(g, x[((long)(n * H + iy) * W + ix) * in_cstride + ci], s);
-      }
+// stage 1: grid (pixel chunks of 128, KH*KW, Cout); thread = ci (strided), X rows are contiguous over ci (coalesced), dY broadcast;
+//          partial[chunk][co][tap][ci] (deterministic, no atomics);  stage 2 sums the chunks.
+__global__ __launch_bounds__(256) void conv_small_cout_wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                            float* __restrict__ partial, float* __restrict__ partial_b,
+                                                                            int N, int H, int W, int Cin, int in_cstride, int Cout, int KH,
+                                                                            int KW, int pad, int chunk_px) {
+  const int chunk = blockIdx.x, tap = blockIdx.y, kh = tap / KW, kw = tap % KW, co = blockIdx.z;
+  const long P = (long)N * H * W;
+  const long p0 = (long)chunk * chunk_px, p1 = min(P, p0 + chunk_px);
+  float sb = 0.f;
+  for (int ci = threadIdx.x; ci < Cin; ci += blockDim.x) {
+    float s = 0.f;
+    for (long p = p0; p < p1; ++p) {
+      int xx = (int)(p % W);
+      int y = (int)((p / W) % H);
+      int iy = y - pad + kh, ix = xx - pad + kw;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        s = fmaf(dy[p * Cout + co], x[(p + (long)(kh - pad) * W + (kw - pad)) * in_cstride + ci], s);
     }
-  if (ci < Cin) dw[(((long)co * Cin + ci) * KH + kh) * KW + kw] = s;
-  if (ci == 0 && tap == 0 && db) db[co] = sb;
+    partial[(((long)chunk * Cout + co) * KH * KW + tap) * Cin + ci] = s;
+  }
+  if (tap == 0 && threadIdx.x == 0) {
+    for (long p = p0; p < p1; ++p) sb += dy[p * Cout + co];
+    partial_b[(long)chunk * Cout + co] = sb;
+  }
+}
+
+__global__ void conv_small_cout_wgrad_final_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b, float* __restrict__ dw,
+                                                   float* __restrict__ db, int nchunk, int Cin, int Cout, int KH, int KW) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long per = (long)Cout * KH * KW * Cin;
+  if (idx < per) {
+    int ci = (int)(idx % Cin);
+    long t = idx / Cin;
+    int tap = (int)(t % (KH * KW));
+    int co = (int)(t / (KH * KW));
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += partial[(long)c * per + idx];
+    dw[((long)co * Cin + ci) * KH * KW + tap] = s;
+  }
+  if (idx < Cout && db) {
+    float sb = 0.f;
+    for (int c = 0; c < nchunk; ++c) sb += partial_b[(long)c * Cout + idx];
+    db[idx] = sb;
+  }
 }
 
 // tiny deconv (k4 s2, Cin,Cout <= 4) backward: dX, dW, db.  dy is a channel range of a concat buffer over the crop window.
@@ -413,18 +440,30 @@ int dim_upsample16_bwd(const float* dout_nchw, const float* w_c1_32_32, float* d
   return check_launch("upsample16_bwd");
 }
 
-int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw, float* dx, float* dw_oihw, float* db, int N, int H, int W,
-                            int Cin, int in_cstride, int dx_cstride, int Cout, int KH, int KW, int pad, int accumulate_dx, void* stream) {
+long dim_conv_small_cout_bwd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW) {
+  long nchunk = ceil_div((long)N * H * W, 128);
+  return nchunk * ((long)Cout * KH * KW * Cin + Cout);
+}
+
+int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw, float* dx, float* dw_oihw, float* db, float* workspace,
+                            int N, int H, int W, int Cin, int in_cstride, int dx_cstride, int Cout, int KH, int KW, int pad,
+                            int accumulate_dx, void* stream) {
   if (N == 0) return DIM_OK;
-  DIM_REQUIRE(x && dy && w_oihw && dw_oihw, "null pointer");
+  DIM_REQUIRE(x && dy && w_oihw && dw_oihw && workspace, "null pointer");
   hipStream_t st = as_stream(stream);
   if (dx) {
     long total = (long)N * H * W * ((Cin + 3) / 4);
     hipLaunchKernelGGL(conv_small_cout_dgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, dy, w_oihw, dx, N, H, W, Cin, dx_cstride,
                        Cout, KH, KW, pad, accumulate_dx);
   }
-  hipLaunchKernelGGL(conv_small_cout_wgrad_kernel, dim3(ceil_div(Cin, 256), KH * KW, Cout), dim3(256), 0, st, x, dy, dw_oihw, db, N, H, W,
-                     Cin, in_cstride, Cout, KH, KW, pad);
+  const int nchunk = ceil_div((long)N * H * W, 128);
+  float* partial = workspace;
+  float* partial_b = workspace + (long)nchunk * Cout * KH * KW * Cin;
+  hipLaunchKernelGGL(conv_small_cout_wgrad_partial_kernel, dim3(nchunk, KH * KW, Cout), dim3(256), 0, st, x, dy, partial, partial_b, N, H,
+                     W, Cin, in_cstride, Cout, KH, KW, pad, 128);
+  long per = (long)Cout * KH * KW * Cin;
+  hipLaunchKernelGGL(conv_small_cout_wgrad_final_kernel, dim3(ceil_div(per, 256)), dim3(256), 0, st, partial, partial_b, dw_oihw, db,
+                     nchunk, Cin, Cout, KH, KW);
   return check_launch("conv_small_cout_bwd");
 }
 

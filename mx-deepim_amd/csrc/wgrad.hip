@@ -29,107 +29,139 @@ struct WgradArgs {
 
 __device__ const float4 g_wzero16 = {0.f, 0.f, 0.f, 0.f};
 
-template <int NW, bool CIN8>
+template <int NW, bool CIN8, int NCH>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int BP = 32;            // pixels per step
-  constexpr int BM = 32 * NW;       // output channels per workgroup
-  constexpr int LDZ = BM + 4;       // row stride keeps float4 stores aligned; rows 2s and 2s+1 are read by different lane groups
-  constexpr int LDX = 32 + 4;
+  constexpr int BM = 32 * NW;       // output channels per workgroup (one 32-row MFMA tile per wave)
+  constexpr int LDZ = BM + 4;       // [pixel][co] rows; float4-aligned
+  constexpr int LDX = 32 * NCH + 4; // [pixel][NCH chunks x 32 kin]
   constexpr int NT = 64 * NW;
-  constexpr int Z_PER_T = (BP * BM / 4) / NT;  // = 4
-  constexpr int X_PER_T = (BP * 32 / 4) / NT;  // 1 (NW=4) or 2 (NW=2)
+  constexpr int ZQ = BM / 4;                       // float4 per dZ row
+  constexpr int Z_PER_T = (BP * ZQ) / NT;          // = 4
+  constexpr int ZR_STEP = NT / ZQ;
+  constexpr int X_PER_T = (BP * 8 * NCH) / NT;     // float4 of X per thread and step
+  constexpr int XR_STEP = NT / 8;
   __shared__ __attribute__((aligned(16))) float sZ[2][BP * LDZ];
   __shared__ __attribute__((aligned(16))) float sX[2][BP * LDX];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kc = blockIdx.x;
+  const int kc0 = blockIdx.x * NCH;
   const int co0 = blockIdx.y * BM;
   const int split = blockIdx.z;
   const int step_begin = split * a.steps_per_split;
   const int step_end = min(a.nsteps, step_begin + a.steps_per_split);
 
-  // chunk -> tap / channel slice (same order as conv_fwd_kernel / pack_conv_weight_kernel)
-  int kh, kw, c0;
-  if (CIN8) {
-    kh = kc >> 1; kw = (kc & 1) * 4; c0 = 0;
-  } else {
-    int taps = a.KH * a.KW;
-    int cc = kc / taps, tap = kc - cc * taps;
-    c0 = cc << 5; kh = tap / a.KW; kw = tap - kh * a.KW;
+  // chunk -> tap / channel slice (same order as conv_fwd_kernel / pack_conv_weight_kernel), one decode per chunk of the block
+  int kh[NCH], kw[NCH], c0[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int kc = kc0 + c;
+    if (CIN8) {
+      kh[c] = kc >> 1; kw[c] = (kc & 1) * 4; c0[c] = 0;
+    } else {
+      int taps = a.KH * a.KW;
+      int cc = kc / taps, tap = kc - cc * taps;
+      c0[c] = cc << 5; kh[c] = tap / a.KW; kw[c] = tap - kh[c] * a.KW;
+    }
+  }
+  const int zq = tid % ZQ, zr0 = tid / ZQ;
+  const int xq = tid & 7, xr0 = tid >> 3;
+
+  constexpr int XP = X_PER_T / NCH;  // pixel rows per thread per chunk (1 for NW=4, 2 for NW=2)
+  static_assert(XP >= 1 && XP <= 2 && Z_PER_T == 4 && NCH <= 2, "staging register plan");
+  // named staging registers: float4 arrays indexed inside macros / lambdas ended up in scratch (hipcc, ROCm 7.2)
+  float4 rz0, rz1, rz2, rz3, rx00, rx01, rx10, rx11;
+
+  f32x16 acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  const float* zero = reinterpret_cast<const float*>(&g_wzero16);
+#define DIM_WG_LZ(REG, I)                                                                                         \
+  {                                                                                                               \
+    int m = p0 + zr0 + ZR_STEP * I;                                                                               \
+    const float* src = (pf && m < a.M) ? a.dz + (long)m * a.dz_cstride + a.dz_coff + co0 + zq * 4 : zero;         \
+    REG = *reinterpret_cast<const float4*>(src);                                                                  \
+  }
+#define DIM_WG_LX(REG, C, I)                                                                                      \
+  if (C < NCH && I < XP) {                                                                                        \
+    int hi = hb##I + kh[C];                                                                                       \
+    int wi = wb##I + kw[C] + (CIN8 ? (xq >> 1) : 0);                                                              \
+    bool ok = okm##I && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && (!CIN8 || kw[C] + (xq >> 1) < a.KW); \
+    const float* src = ok ? a.x + (pix##I + (long)(kh[C] * a.W + kw[C]) * a.in_cstride + c0[C]) : zero;           \
+    REG = *reinterpret_cast<const float4*>(src);                                                                  \
+  }
+#define DIM_WG_PIX(I)                                                                                             \
+  int m##I = p0 + xr0 + XR_STEP * I;                                                                              \
+  bool okm##I = pf && (I < XP) && m##I < a.M;                                                                     \
+  int mm##I = okm##I ? m##I : 0;                                                                                  \
+  int wo##I = mm##I % a.Wo, t##I = mm##I / a.Wo, ho##I = t##I % a.Ho, n##I = t##I / a.Ho;                         \
+  int hb##I = ho##I * a.stride - a.pad, wb##I = wo##I * a.stride - a.pad;                                         \
+  long pix##I = ((long)(n##I * a.H + hb##I) * a.W + wb##I) * a.in_cstride + xq * 4;
+  // global -> registers for step `st` (pf = false: everything reads the zero block; used for the prefetch past the end)
+#define DIM_WG_LOAD(st, pf_ok)                                      \
+  {                                                                 \
+    const int p0 = (st) * BP;                                       \
+    const bool pf = (pf_ok);                                        \
+    DIM_WG_LZ(rz0, 0) DIM_WG_LZ(rz1, 1) DIM_WG_LZ(rz2, 2) DIM_WG_LZ(rz3, 3) \
+    DIM_WG_PIX(0) DIM_WG_PIX(1)                                     \
+    DIM_WG_LX(rx00, 0, 0) DIM_WG_LX(rx01, 0, 1) DIM_WG_LX(rx10, 1, 0) DIM_WG_LX(rx11, 1, 1) \
+  }
+#define DIM_WG_SZ(REG, I) *reinterpret_cast<float4*>(&sZ[buf_][(zr0 + ZR_STEP * I) * LDZ + zq * 4]) = REG;
+#define DIM_WG_SX(REG, C, I) \
+  if (C < NCH && I < XP) *reinterpret_cast<float4*>(&sX[buf_][(xr0 + XR_STEP * I) * LDX + C * 32 + xq * 4]) = REG;
+#define DIM_WG_STORE(buf)                                           \
+  {                                                                 \
+    const int buf_ = (buf);                                         \
+    DIM_WG_SZ(rz0, 0) DIM_WG_SZ(rz1, 1) DIM_WG_SZ(rz2, 2) DIM_WG_SZ(rz3, 3) \
+    DIM_WG_SX(rx00, 0, 0) DIM_WG_SX(rx01, 0, 1) DIM_WG_SX(rx10, 1, 0) DIM_WG_SX(rx11, 1, 1) \
   }
 
-  // staging maps.  dZ: float4 #zq of pixel row zr (+ passes);  X: float4 #xq (of 8) of pixel row xr (+ passes)
-  constexpr int ZQ = BM / 4;
-  const int zq = tid % ZQ, zr0 = tid / ZQ;
-  constexpr int ZR_STEP = NT / ZQ;
-  const int xq = tid & 7, xr0 = tid >> 3;
-  constexpr int XR_STEP = NT / 8;
-
-  float4 rz[Z_PER_T], rx[X_PER_T];
-
-  auto load_step = [&](int st) {
-    const int p0 = st * BP;
-#pragma unroll
-    for (int i = 0; i < Z_PER_T; ++i) {
-      int m = p0 + zr0 + ZR_STEP * i;
-      const float* src = (m < a.M) ? a.dz + (long)m * a.dz_cstride + a.dz_coff + co0 + zq * 4 : reinterpret_cast<const float*>(&g_wzero16);
-      rz[i] = *reinterpret_cast<const float4*>(src);
-    }
-#pragma unroll
-    for (int i = 0; i < X_PER_T; ++i) {
-      int m = p0 + xr0 + XR_STEP * i;
-      bool ok = m < a.M;
-      int mm = ok ? m : 0;
-      int wo = mm % a.Wo;
-      int t = mm / a.Wo;
-      int ho = t % a.Ho;
-      int n = t / a.Ho;
-      int hi = ho * a.stride - a.pad + kh;
-      int wi = wo * a.stride - a.pad + kw + (CIN8 ? (xq >> 1) : 0);
-      ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && (!CIN8 || kw + (xq >> 1) < a.KW);
-      long off = ((long)(n * a.H + hi) * a.W + wi) * a.in_cstride + c0 + (CIN8 ? (xq & 1) * 4 : xq * 4);
-      const float* src = ok ? a.x + off : reinterpret_cast<const float*>(&g_wzero16);
-      rx[i] = *reinterpret_cast<const float4*>(src);
-    }
-  };
-  auto store_step = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < Z_PER_T; ++i) *reinterpret_cast<float4*>(&sZ[buf][(zr0 + ZR_STEP * i) * LDZ + zq * 4]) = rz[i];
-#pragma unroll
-    for (int i = 0; i < X_PER_T; ++i) *reinterpret_cast<float4*>(&sX[buf][(xr0 + XR_STEP * i) * LDX + xq * 4]) = rx[i];
-  };
-
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
   if (step_begin < step_end) {
-    load_step(step_begin);
-    store_step(0);
+    DIM_WG_LOAD(step_begin, true)
+    DIM_WG_STORE(0)
   }
   __syncthreads();
   const int fi = lane & 31, fh = lane >> 5;
   int buf = 0;
   for (int st = step_begin; st < step_end; ++st) {
-    const bool more = st + 1 < step_end;
-    if (more) load_step(st + 1);
+    DIM_WG_LOAD(min(st + 1, a.nsteps - 1), st + 1 < step_end)
+    __builtin_amdgcn_sched_barrier(0);  // prefetch stays ahead of the MFMA block
     const float* cz = &sZ[buf][fh * LDZ + wave * 32 + fi];
     const float* cx = &sX[buf][fh * LDX + fi];
 #pragma unroll
-    for (int s = 0; s < BP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cz[2 * s * LDZ], cx[2 * s * LDX], acc, 0, 0, 0);
-    if (more) store_step(buf ^ 1);
+    for (int s = 0; s < BP / 2; ++s) {
+      float av = cz[2 * s * LDZ];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cx[2 * s * LDX + 32 * c], acc[c], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    DIM_WG_STORE(buf ^ 1)
     __syncthreads();
     buf ^= 1;
   }
+#undef DIM_WG_LOAD
+#undef DIM_WG_STORE
+#undef DIM_WG_LZ
+#undef DIM_WG_LX
+#undef DIM_WG_PIX
+#undef DIM_WG_SZ
+#undef DIM_WG_SX
   // D: col = lane&31 -> kin, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co within the wave's 32
-  float* out = (gridDim.z == 1 ? a.dw : a.dw + (long)split * a.nchunks * a.Cout * 32) + ((long)kc * a.Cout + co0 + wave * 32 + 4 * fh) * 32 + fi;
   const bool add = gridDim.z == 1 && a.accumulate;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float* o = out + (long)((r & 3) + 8 * (r >> 2)) * 32;
-    float v = acc[r];
-    if (add) v += *o;
-    *o = v;
+  for (int c = 0; c < NCH; ++c) {
+    float* out = (gridDim.z == 1 ? a.dw : a.dw + (long)split * a.nchunks * a.Cout * 32) +
+                 ((long)(kc0 + c) * a.Cout + co0 + wave * 32 + 4 * fh) * 32 + fi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* o = out + (long)((r & 3) + 8 * (r >> 2)) * 32;
+      float v = acc[c][r];
+      if (add) v += *o;
+      *o = v;
+    }
   }
 }
 
@@ -213,14 +245,17 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   a.accumulate = accumulate;
   hipStream_t st = as_stream(stream);
   const bool nw4 = Cout % 128 == 0;
-  dim3 grid(a.nchunks, Cout / (nw4 ? 128 : 64), splits);
+  const bool two = a.nchunks % 2 == 0;  // two K chunks (64 packed columns) per workgroup share one dZ tile
+  dim3 grid(a.nchunks / (two ? 2 : 1), Cout / (nw4 ? 128 : 64), splits);
+#define DIM_WG_LAUNCH(NW, C8, NCH) hipLaunchKernelGGL((conv_wgrad_kernel<NW, C8, NCH>), grid, dim3(64 * NW), 0, st, a)
   if (Cin == 8) {
-    if (nw4) hipLaunchKernelGGL((conv_wgrad_kernel<4, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<2, true>), grid, dim3(128), 0, st, a);
+    if (nw4) { if (two) DIM_WG_LAUNCH(4, true, 2); else DIM_WG_LAUNCH(4, true, 1); }
+    else { if (two) DIM_WG_LAUNCH(2, true, 2); else DIM_WG_LAUNCH(2, true, 1); }
   } else {
-    if (nw4) hipLaunchKernelGGL((conv_wgrad_kernel<4, false>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<2, false>), grid, dim3(128), 0, st, a);
+    if (nw4) { if (two) DIM_WG_LAUNCH(4, false, 2); else DIM_WG_LAUNCH(4, false, 1); }
+    else { if (two) DIM_WG_LAUNCH(2, false, 2); else DIM_WG_LAUNCH(2, false, 1); }
   }
+#undef DIM_WG_LAUNCH
   int rc = check_launch("conv_wgrad");
   if (rc != DIM_OK) return rc;
   if (splits > 1) {

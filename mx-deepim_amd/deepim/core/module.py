@@ -105,6 +105,9 @@ class MutableModule(object):
             max_pack = max(max_pack, ops.lib().dim_conv2d_packed_weight_floats(cout, c, k, k))
             h, w, c = ho, wo, cout
         max_pack = max(max_pack, 256 * 81920, 4 * 4 * 512 * 1024, 4 * 4 * 256 * ops.pad64(1026))
+        max_ws = max(max_ws, ops.lib().dim_conv_small_cout_bwd_workspace_floats(B, 30, 40, 770, 2, 3, 3),
+                     ops.lib().dim_conv_small_cout_bwd_workspace_floats(B, 15, 20, 1026, 2, 3, 3),
+                     ops.lib().dim_conv_small_cout_bwd_workspace_floats(B, 8, 10, 1024, 2, 3, 3))
         self.ws = torch.empty(max_ws, dtype=torch.float32, device=d)
         self.gpack = torch.empty(max_pack, dtype=torch.float32, device=d)
         self.bias_ws = torch.empty(ops.lib().dim_bias_grad_workspace_floats(B * 240 * 320, 64) + 1024 * 64, dtype=torch.float32, device=d)
@@ -180,10 +183,10 @@ class MutableModule(object):
         # ---------------- flow / mask heads
         ops.upsample16_bwd(self.dflow_full, w["upsampling_weight"], self.dflow4)
         ops.conv_small_cout_bwd(net.concat3, 770, self.dflow4, w["Convolution3_weight"], self.dconcat3, g["Convolution3_weight"],
-                                g["Convolution3_bias"], accumulate_dx=False)
+                                g["Convolution3_bias"], accumulate_dx=False, workspace=self.ws)
         ops.upsample16_bwd(self.dlogit, w["mask_upsampling_weight"], self.dmask4)
         ops.conv_small_cout_bwd(net.concat3, 770, self.dmask4, w["mask_conv3_weight"], self.dconcat3, g["mask_conv3_weight"],
-                                g["mask_conv3_bias"], accumulate_dx=True)
+                                g["mask_conv3_bias"], accumulate_dx=True, workspace=self.ws)
         g["upsampling_weight"].zero_()
         g["mask_upsampling_weight"].zero_()
         # ---------------- decoder level 4: Concat3 = [ReLU6 | ReLU12 (deconv4) | upsample_flow5to4]
@@ -192,7 +195,7 @@ class MutableModule(object):
         ops.lrelu_bwd(net.concat3, self.dconcat3, 256, y_coff=512, dy_coff=512)
         self._deconv_bwd("deconv4", x=net.concat2, x_c=1026, x_cpad=ops.pad64(1026), dz=self.dconcat3, dz_coff=512, cout=256, dx=self.dconcat2)
         ops.conv_small_cout_bwd(net.concat2, 1026, self.dflow5, w["Convolution2_weight"], self.dconcat2, g["Convolution2_weight"],
-                                g["Convolution2_bias"], accumulate_dx=True)
+                                g["Convolution2_bias"], accumulate_dx=True, workspace=self.ws)
         # ---------------- decoder level 5: Concat2 = [ReLU8 | ReLU11 (deconv5) | upsample_flow6to5]
         ops.deconv4x4s2_tiny_bwd(net.flow6, self.dconcat2, 1024, w["upsample_flow6to5_weight"], self.dflow6, g["upsample_flow6to5_weight"],
                                  g["upsample_flow6to5_bias"])
@@ -200,7 +203,7 @@ class MutableModule(object):
         d10 = self.dacts["conv6_1"]
         self._deconv_bwd("deconv5", x=net.acts["conv6_1"], x_c=1024, x_cpad=1024, dz=self.dconcat2, dz_coff=512, cout=512, dx=d10)
         ops.conv_small_cout_bwd(net.acts["conv6_1"], 1024, self.dflow6, w["Convolution1_weight"], d10, g["Convolution1_weight"],
-                                g["Convolution1_bias"], accumulate_dx=True)
+                                g["Convolution1_bias"], accumulate_dx=True, workspace=self.ws)
         # ---------------- pose head (fc7, rot, trans, fc6)
         fc6a = net.fc6.view(B, 256)
         ops.pose_head_bwd(fc6a, net.fc7, net.se3[:, :4].contiguous(), d_rn, d_t, w, self.d_rot, self.dz7, self.dz6)

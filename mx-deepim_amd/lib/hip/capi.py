@@ -53,7 +53,8 @@ SIGNATURES = {
     "dim_pose_head_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, P]),
     "dim_fc_wgrad": (I, [P, P, P, P, I, I, I, P]),
     "dim_upsample16_bwd": (I, [P, P, P, I, I, I, I, I, I, I, F, P]),
-    "dim_conv_small_cout_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dim_conv_small_cout_bwd_workspace_floats": (L, [I, I, I, I, I, I, I]),
+    "dim_conv_small_cout_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_deconv4x4s2_tiny_bwd": (I, [P, I, P, I, I, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dim_sgd_momentum": (I, [P, P, P, L, F, F, F, F, P]),
     "dim_deconv4x4s2_packed_weight_floats": (L, [I, I]),

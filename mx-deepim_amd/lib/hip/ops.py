@@ -389,12 +389,15 @@ def upsample16_bwd(dout_nchw, w_c1_32_32, df_nhwc, crop=8, scale=1.0):
     return df_nhwc
 
 
-def conv_small_cout_bwd(x, Cin, dy, w_oihw, dx, dw, db, accumulate_dx=False, pad=1):
+def conv_small_cout_bwd(x, Cin, dy, w_oihw, dx, dw, db, accumulate_dx=False, pad=1, workspace=None):
     N, H, W, in_cs = x.shape
     Cout, _, KH, KW = w_oihw.shape
-    check(lib().dim_conv_small_cout_bwd(dptr(x, f32), dptr(dy, f32), dptr(w_oihw, f32), dptr(dx, f32), dptr(dw, f32), dptr(db, f32), N, H, W,
-                                        Cin, in_cs, dx.shape[-1] if dx is not None else 0, Cout, KH, KW, pad, int(accumulate_dx),
-                                        current_stream()))
+    need = lib().dim_conv_small_cout_bwd_workspace_floats(N, H, W, Cin, Cout, KH, KW)
+    if workspace is None or workspace.numel() < need:
+        workspace = _new((need,), x)
+    check(lib().dim_conv_small_cout_bwd(dptr(x, f32), dptr(dy, f32), dptr(w_oihw, f32), dptr(dx, f32), dptr(dw, f32), dptr(db, f32),
+                                        dptr(workspace, f32), N, H, W, Cin, in_cs, dx.shape[-1] if dx is not None else 0, Cout, KH, KW, pad,
+                                        int(accumulate_dx), current_stream()))
 
 
 def deconv4x4s2_tiny_bwd(x, dy, dy_coff, w_iohw, dx, dw, db, crop=1):
