@@ -166,19 +166,44 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // column sums: db[c] = sum_m dz[m][coff + c]; grid (C/64, nsplit) -> partial[nsplit][C]; then a tiny reduce
+// thread = 4 adjacent channels (one 16-byte load per row); workgroup = 64 channels x 16 row lanes, 4 rows in flight per lane
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dz, int M, int C, int cstride, int coff,
                                                              int rows_per_block, float* __restrict__ partial) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rsub = threadIdx.x >> 6;
+  const int cg = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cg * 4;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
-  float s = 0.f;
-  if (c < C)
-    for (int m = r0 + rsub; m < r1; m += 4) s += dz[(long)m * cstride + coff + c];
-  __shared__ float red[4][64];
-  red[rsub][threadIdx.x & 63] = s;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (c < C) {
+    const float* base = dz + coff + c;
+    int m = r0 + rsub;
+    for (; m + 48 < r1; m += 64) {
+      float4 v0 = *reinterpret_cast<const float4*>(base + (long)m * cstride);
+      float4 v1 = *reinterpret_cast<const float4*>(base + (long)(m + 16) * cstride);
+      float4 v2 = *reinterpret_cast<const float4*>(base + (long)(m + 32) * cstride);
+      float4 v3 = *reinterpret_cast<const float4*>(base + (long)(m + 48) * cstride);
+      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+      s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+      s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+      s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+    }
+    for (; m < r1; m += 16) {
+      float4 v0 = *reinterpret_cast<const float4*>(base + (long)m * cstride);
+      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+    }
+  }
+  __shared__ float4 red[16][16];
+  red[rsub][cg] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                              (s0.w + s1.w) + (s2.w + s3.w));
   __syncthreads();
-  if (rsub == 0 && c < C) partial[(long)blockIdx.y * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < 64) {
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    const float* r = reinterpret_cast<const float*>(&red[0][0]) + threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += r[k * 64];
+    if (col < C) partial[(long)blockIdx.y * C + col] = t;
+  }
 }
 
 __global__ void colsum_final_kernel(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ db, int accumulate) {
@@ -269,14 +294,15 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   return DIM_OK;
 }
 
-long dim_bias_grad_workspace_floats(int M, int C) { return (long)ceil_div(M, 2048) * C; }
+long dim_bias_grad_workspace_floats(int M, int C) { return (long)ceil_div(M, 512) * C; }
 
 int dim_bias_grad(const float* dz, float* db, float* workspace, int M, int C, int dz_cstride, int dz_coff, int accumulate, void* stream) {
   if (M == 0) return DIM_OK;
   DIM_REQUIRE(dz && db && workspace, "null pointer");
-  int nsplit = ceil_div(M, 2048);
+  DIM_REQUIRE(C % 4 == 0 && dz_cstride % 4 == 0 && dz_coff % 4 == 0, "bias_grad: channel counts/offsets must be multiples of 4");
+  int nsplit = ceil_div(M, 512);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C, 64), nsplit), dim3(256), 0, st, dz, M, C, dz_cstride, dz_coff, 2048, workspace);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C, 64), nsplit), dim3(256), 0, st, dz, M, C, dz_cstride, dz_coff, 512, workspace);
   hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, workspace, nsplit, C, db, accumulate);
   return check_launch("bias_grad");
 }
