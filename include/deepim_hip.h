@@ -102,6 +102,19 @@ int dim_raster_render(const float* verts, const float* uvs, const int* faces, co
                       const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear, const float* plane_means3,
                       float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox,
                       void* stream);
+/* Lit variant of dim_raster_render: Render_Py_Light_ModelNet_Multi.render
+ * (lib/render_glumpy/render_py_light_modelnet_multi.py:36-77 fragment shader, :153-235 render).
+ * normals: per-vertex normals in the same table as verts.  light_pos (B,3) in GL camera coordinates, light_int (B,3)
+ * (device pointers).  Colour = texel/255 * ((1-ratio) + ratio*clamp(cos(normal, light-position),0,1)) * light_int,
+ * clamped to [0,1] and quantised to 8 bits (round to nearest) like the GL framebuffer. */
+int dim_raster_render_lit(const float* verts, const float* normals, const float* uvs, const int* faces, const int* mesh_table, int vmax,
+                          int fmax, const unsigned char* textures, const int* tex_table, const int* class_index, const float* poses,
+                          const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear, const float* light_pos,
+                          const float* light_int, float brightness_ratio, const float* plane_means3, float mask_thr, void* workspace,
+                          float* image, float* depth, float* mask, float* bgr, int* bbox, void* stream);
+
+/* deepim/core/tester.py:204-225 (and batch_updater_py_multi.py:233-255): light_pos[b] = 0.5*(dx,dy,dz) + (tx,-ty,-tz) of poses[b]. */
+int dim_modelnet_light_position(const float* poses, float dx, float dy, float dz, float* light_pos, int B, void* stream);
 /* mask[b] = rectangle [y0:y1, x0:x1] (end-exclusive) of bbox[b]  (data_pair.py:103-114, UPDATE_MASK box_rendered) */
 int dim_box_mask(const int* bbox, float* mask, int B, int H, int W, void* stream);
 

@@ -141,7 +141,18 @@ __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > 
 //   depth  (B,1,H,W) metres;  mask (B,1,H,W) = depth > mask_thr   (deepim/core/tester.py:575-577)
 //   bgr    (B,H,W,3) 0..255 as Render_Py.render returns it
 //   bbox   (B,4) {min_x,max_x,min_y,max_y} of mask (pre-initialised to {W,-1,H,-1})
-__global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __restrict__ uvs, const int* __restrict__ faces,
+// Lit (ModelNet) shading inputs, render_py_light_modelnet_multi.py:36-77: all null / unused when LIT is false
+struct LitArgs {
+  const float* verts;      // model-frame positions (same table as the vertex pass)
+  const float* normals;    // per-vertex normals, same indexing as verts
+  const float* poses;      // (B,3,4)
+  const float* light_pos;  // (B,3) GL camera coordinates
+  const float* light_int;  // (B,3)
+  float ratio;             // brightness_ratio
+};
+
+template <bool LIT>
+__global__ __launch_bounds__(256) void raster_resolve_kernel(LitArgs lit, const float* __restrict__ uvs, const int* __restrict__ faces,
                                                              const int* __restrict__ mesh_table, const unsigned char* __restrict__ tex,
                                                              const int* __restrict__ tex_table, const int* __restrict__ class_index,
                                                              const float* __restrict__ scr, const unsigned long long* __restrict__ zbuf,
@@ -205,9 +216,50 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __rest
         for (int k = 0; k < 3; ++k) {
           float top = __fmaf_rn(ax, __fsub_rn((float)p01[k], (float)p00[k]), (float)p00[k]);
           float bot = __fmaf_rn(ax, __fsub_rn((float)p11[k], (float)p10[k]), (float)p10[k]);
-          c[k] = floorf(__fmaf_rn(ay, __fsub_rn(bot, top), top));  // tester.py:244 astype("uint8")
+          c[k] = __fmaf_rn(ay, __fsub_rn(bot, top), top);
+          if (!LIT) c[k] = floorf(c[k]);  // tester.py:244 astype("uint8")
         }
         r = c[0]; g = c[1]; bl = c[2];
+      }
+      if (LIT) {
+        // perspective-correct varyings v_normal / v_position, then GL camera frame (y, z flipped)
+        float n[3], p[3];
+        const float* N0 = lit.normals + 3 * (long)(mt[0] + face[0]);
+        const float* N1 = lit.normals + 3 * (long)(mt[0] + face[1]);
+        const float* N2 = lit.normals + 3 * (long)(mt[0] + face[2]);
+        const float* P0 = lit.verts + 3 * (long)(mt[0] + face[0]);
+        const float* P1 = lit.verts + 3 * (long)(mt[0] + face[1]);
+        const float* P2 = lit.verts + 3 * (long)(mt[0] + face[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          n[k] = __fmul_rn(__fmaf_rn(w2, N2[k], __fmaf_rn(w1, N1[k], __fmul_rn(w0, N0[k]))), z);
+          p[k] = __fmul_rn(__fmaf_rn(w2, P2[k], __fmaf_rn(w1, P1[k], __fmul_rn(w0, P0[k]))), z);
+        }
+        const float* P = lit.poses + 12 * b;
+        float Ng[3], Pg[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float sgn = k == 0 ? 1.f : -1.f;
+          Ng[k] = __fmul_rn(sgn, __fmaf_rn(P[4 * k + 2], n[2], __fmaf_rn(P[4 * k + 1], n[1], __fmul_rn(P[4 * k], n[0]))));
+          Pg[k] = __fmul_rn(sgn, __fadd_rn(__fmaf_rn(P[4 * k + 2], p[2], __fmaf_rn(P[4 * k + 1], p[1], __fmul_rn(P[4 * k], p[0]))),
+                                           P[4 * k + 3]));
+        }
+        const float* L = lit.light_pos + 3 * b;
+        float sx = __fsub_rn(L[0], Pg[0]), sy = __fsub_rn(L[1], Pg[1]), sz = __fsub_rn(L[2], Pg[2]);
+        float dotv = __fmaf_rn(Ng[2], sz, __fmaf_rn(Ng[1], sy, __fmul_rn(Ng[0], sx)));
+        float ls = __fsqrt_rn(__fmaf_rn(sz, sz, __fmaf_rn(sy, sy, __fmul_rn(sx, sx))));
+        float ln = __fsqrt_rn(__fmaf_rn(Ng[2], Ng[2], __fmaf_rn(Ng[1], Ng[1], __fmul_rn(Ng[0], Ng[0]))));
+        float br = __fdiv_rn(dotv, __fmul_rn(ls, ln));
+        br = fmaxf(fminf(br, 1.0f), 0.0f);
+        float kk = __fmaf_rn(lit.ratio, br, __fsub_rn(1.0f, lit.ratio));
+        const float* I = lit.light_int + 3 * b;
+        float c0 = __fmul_rn(__fdiv_rn(r, 255.0f), __fmul_rn(kk, I[0]));
+        float c1 = __fmul_rn(__fdiv_rn(g, 255.0f), __fmul_rn(kk, I[1]));
+        float c2 = __fmul_rn(__fdiv_rn(bl, 255.0f), __fmul_rn(kk, I[2]));
+        // 8-bit framebuffer: clamp to [0,1], round to nearest
+        r = floorf(__fmaf_rn(fminf(fmaxf(c0, 0.f), 1.f), 255.0f, 0.5f));
+        g = floorf(__fmaf_rn(fminf(fmaxf(c1, 0.f), 1.f), 255.0f, 0.5f));
+        bl = floorf(__fmaf_rn(fminf(fmaxf(c2, 0.f), 1.f), 255.0f, 0.5f));
       }
     }
     const long o = (long)y * W + x;
@@ -260,6 +312,16 @@ __global__ __launch_bounds__(256) void box_mask_kernel(const int* __restrict__ b
   *reinterpret_cast<float4*>(mask + ((long)b * H + y) * W + x4) = v;
 }
 
+// tester.py:221-225: light = 0.5 * dir, then += tx, -= ty, -= tz (float64 on the host there; the uniform is float32)
+__global__ void modelnet_light_kernel(const float* __restrict__ poses, float dx, float dy, float dz, float* __restrict__ light_pos, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* P = poses + 12 * b;
+  light_pos[3 * b + 0] = (float)(0.5 * (double)dx + (double)P[3]);
+  light_pos[3 * b + 1] = (float)(0.5 * (double)dy - (double)P[7]);
+  light_pos[3 * b + 2] = (float)(0.5 * (double)dz - (double)P[11]);
+}
+
 __global__ void bbox_init2_kernel(int* bbox, int n, int H, int W) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
@@ -278,11 +340,11 @@ long dim_raster_workspace_bytes(int B, int vmax, int H, int W) {
   return (long)B * H * W * 8 + (long)B * vmax * 3 * 4;
 }
 
-int dim_raster_render(const float* verts, const float* uvs, const int* faces, const int* mesh_table, int vmax, int fmax,
-                      const unsigned char* textures, const int* tex_table, const int* class_index, const float* poses,
-                      const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear, const float* plane_means3,
-                      float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox,
-                      void* stream) {
+static int raster_render_impl(const float* verts, const float* normals, const float* uvs, const int* faces, const int* mesh_table, int vmax,
+                              int fmax, const unsigned char* textures, const int* tex_table, const int* class_index, const float* poses,
+                              const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear,
+                              const float* light_pos, const float* light_int, float ratio, const float* plane_means3, float mask_thr,
+                              void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox, void* stream) {
   if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(verts && uvs && faces && mesh_table && textures && tex_table && class_index && poses && K9 && workspace, "null pointer");
   DIM_REQUIRE(vmax > 0 && fmax > 0 && H > 0 && W > 0, "bad sizes");
@@ -298,10 +360,45 @@ int dim_raster_render(const float* verts, const float* uvs, const int* faces, co
                      W, znear, zfar, zbuf);
   if (bbox) hipLaunchKernelGGL(bbox_init2_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, bbox, B, H, W);
   float p0 = plane_means3 ? plane_means3[0] : 0.f, p1 = plane_means3 ? plane_means3[1] : 0.f, p2 = plane_means3 ? plane_means3[2] : 0.f;
-  hipLaunchKernelGGL(raster_resolve_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, st, uvs, faces, mesh_table, textures,
-                     tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, mask_thr, image, depth, mask, bgr,
-                     bbox);
+  LitArgs lit = {verts, normals, poses, light_pos, light_int, ratio};
+  if (normals)
+    hipLaunchKernelGGL(raster_resolve_kernel<true>, dim3(ceil_div(W, 256), H, B), dim3(256), 0, st, lit, uvs, faces, mesh_table, textures,
+                       tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, mask_thr, image, depth, mask, bgr,
+                       bbox);
+  else
+    hipLaunchKernelGGL(raster_resolve_kernel<false>, dim3(ceil_div(W, 256), H, B), dim3(256), 0, st, lit, uvs, faces, mesh_table,
+                       textures, tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, mask_thr, image, depth, mask,
+                       bgr, bbox);
   return check_launch("raster_render");
+}
+
+int dim_raster_render(const float* verts, const float* uvs, const int* faces, const int* mesh_table, int vmax, int fmax,
+                      const unsigned char* textures, const int* tex_table, const int* class_index, const float* poses,
+                      const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear, const float* plane_means3,
+                      float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox,
+                      void* stream) {
+  return raster_render_impl(verts, nullptr, uvs, faces, mesh_table, vmax, fmax, textures, tex_table, class_index, poses, K9, B, H, W,
+                            znear, zfar, tex_bilinear, nullptr, nullptr, 0.f, plane_means3, mask_thr, workspace, image, depth, mask, bgr,
+                            bbox, stream);
+}
+
+int dim_raster_render_lit(const float* verts, const float* normals, const float* uvs, const int* faces, const int* mesh_table, int vmax,
+                          int fmax, const unsigned char* textures, const int* tex_table, const int* class_index, const float* poses,
+                          const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear, const float* light_pos,
+                          const float* light_int, float brightness_ratio, const float* plane_means3, float mask_thr, void* workspace,
+                          float* image, float* depth, float* mask, float* bgr, int* bbox, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(normals && light_pos && light_int, "null pointer");
+  return raster_render_impl(verts, normals, uvs, faces, mesh_table, vmax, fmax, textures, tex_table, class_index, poses, K9, B, H, W,
+                            znear, zfar, tex_bilinear, light_pos, light_int, brightness_ratio, plane_means3, mask_thr, workspace, image,
+                            depth, mask, bgr, bbox, stream);
+}
+
+int dim_modelnet_light_position(const float* poses, float dx, float dy, float dz, float* light_pos, int B, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(poses && light_pos, "null pointer");
+  hipLaunchKernelGGL(modelnet_light_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), poses, dx, dy, dz, light_pos, B);
+  return check_launch("modelnet_light_position");
 }
 
 int dim_box_mask(const int* bbox, float* mask, int B, int H, int W, void* stream) {

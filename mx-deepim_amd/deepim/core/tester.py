@@ -63,6 +63,13 @@ class Refiner(object):
         self.bbox = torch.zeros((B, 4), dtype=torch.int32, device=d)
         self.depth = torch.zeros((B, 1, H, W), dtype=torch.float32, device=d)
         self.status_iter = torch.zeros((self.test_iter, B), dtype=torch.int32, device=d)
+        # per-iteration head outputs of the full (not FAST_TEST) graph, read by the reference at tester.py:485-491
+        self.with_heads = bool(self.net.has_decoder and not cfg.TEST.FAST_TEST)
+        self.mask_pred_iter = self.flow_est_iter = None
+        if self.with_heads and cfg.network.PRED_MASK:
+            self.mask_pred_iter = torch.zeros((self.test_iter, B, 1, H, W), dtype=torch.float32, device=d)
+        if self.with_heads and cfg.network.PRED_FLOW:
+            self.flow_est_iter = torch.zeros((self.test_iter, B, 2, H, W), dtype=torch.float32, device=d)
         self.T_means = np.asarray(cfg.dataset.trans_means, dtype=np.float32)
         self.T_stds = np.asarray(cfg.dataset.trans_stds, dtype=np.float32)
         render_machine.reserve(B)
@@ -88,8 +95,12 @@ class Refiner(object):
             b[k].copy_(v)
         bbox = None
         for it in range(self.test_iter):
-            net.forward_test(b, bbox_ren=bbox)
+            out = net.forward_test(b, bbox_ren=bbox)
             self.se3_iter[it].copy_(net.se3)
+            if self.mask_pred_iter is not None:
+                self.mask_pred_iter[it].copy_(out["mask_observed_pred_output"])
+            if self.flow_est_iter is not None:
+                self.flow_est_iter[it].copy_(out["flow_est_crop_output"])
             self.status_iter[it].copy_(net.status)
             # pose_rendered_update = RT_transform(pose_rendered, se3[:-3], se3[-3:], ...)   (:525-532)
             ops.se3_compose(b["src_pose"], net.se3, cfg.network.ROT_COORD, self.T_means, self.T_stds, out=self.poses_iter[it])

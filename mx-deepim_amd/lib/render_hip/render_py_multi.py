@@ -92,6 +92,7 @@ class Render_Py(object):
     def _upload(self, meshes):
         vo = fo = to = 0
         table, ttable, V, T, F, X = [], [], [], [], [], []
+        seen = {}  # a texture object shared by several meshes (ModelNet's gray_texture.png) is uploaded once
         for v, t, f, tex in meshes:
             v = np.ascontiguousarray(v, np.float32)
             t = np.ascontiguousarray(t, np.float32)
@@ -100,9 +101,15 @@ class Render_Py(object):
             assert tex.ndim == 3 and tex.shape[2] == 3
             assert f.min() >= 0 and f.max() < v.shape[0], "face index out of range"
             table.append([vo, v.shape[0], fo, f.shape[0]])
-            ttable.append([to, tex.shape[0], tex.shape[1]])
-            V.append(v); T.append(t); F.append(f); X.append(tex.reshape(-1))
-            vo += v.shape[0]; fo += f.shape[0]; to += tex.size
+            if id(tex) in seen:
+                ttable.append([seen[id(tex)], tex.shape[0], tex.shape[1]])
+            else:
+                seen[id(tex)] = to
+                ttable.append([to, tex.shape[0], tex.shape[1]])
+                X.append(tex.reshape(-1))
+                to += tex.size
+            V.append(v); T.append(t); F.append(f)
+            vo += v.shape[0]; fo += f.shape[0]
         d = self.device
         self.verts = torch.from_numpy(np.concatenate(V)).to(d)
         self.uvs = torch.from_numpy(np.concatenate(T)).to(d)

@@ -13,6 +13,13 @@
  * top-left fill rule, nearest (default) or bilinear clamp-to-edge filtering.
  * "parity unpinned" w.r.t. a real GL context; the HIP rasteriser is checked against THIS.
  *
+ * Lit variant (lib/render_glumpy/render_py_light_modelnet_multi.py): the fragment shader (:36-77) shades
+ * the texel with  (1-ratio) + ratio*clamp(cos(normal, light - position), 0, 1)  times the light
+ * intensity, in GL camera coordinates (view = diag(1,-1,-1)*[R|t], :256-262; the normal matrix :184-196
+ * is the inverse transpose of the view, i.e. its rotation part for a rigid view, and the shader divides by
+ * length(normal) again so the vec4 normalisation cancels).  The 8-bit framebuffer quantises the clamped colour
+ * with round-to-nearest (:211-214 reads it back as float and rounds again, a no-op).
+ *
  * Geometric near-plane clipping is not implemented: triangles with a vertex at Z<=1e-6 are
  * dropped; fragments outside [znear,zfar] are discarded per pixel.
  */
@@ -68,9 +75,16 @@ static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ?
  * image file; R (9) row-major, t (3), K (9); outputs bgr (H,W,3) float 0..255, depth (H,W) float.
  * shade: NULL, or per-vertex intensity (V) multiplied into the colour then rounded (ModelNet variant).
  * scratch: caller-provided H*W uint64 z-buffer + V*3 floats (cam u,v,z). */
-void dim_oracle_render(const float *verts, const float *uvs, const int32_t *faces, int V, int F,
-                       const uint8_t *tex, int Ht, int Wt, const float *R, const float *t, const float *K,
-                       int H, int W, float znear, float zfar, int tex_bilinear, float *bgr, float *depth) {
+typedef struct {
+  const float *normals;   /* (V,3) per-vertex normals, model frame */
+  const float *light_pos; /* (3) GL camera coordinates (tester.py:221-225) */
+  const float *light_int; /* (3) rgb intensity */
+  float ratio;            /* brightness_ratio (0.7 in tester.py:190) */
+} lit_t;
+
+static void render_impl(const float *verts, const float *uvs, const int32_t *faces, int V, int F,
+                        const uint8_t *tex, int Ht, int Wt, const float *R, const float *t, const float *K,
+                        int H, int W, float znear, float zfar, int tex_bilinear, const lit_t *lit, float *bgr, float *depth) {
   uint64_t *zbuf = (uint64_t *)malloc((size_t)H * W * sizeof(uint64_t));
   float *scr = (float *)malloc((size_t)V * 3 * sizeof(float));
   memset(zbuf, 0xFF, (size_t)H * W * sizeof(uint64_t));
@@ -156,7 +170,35 @@ void dim_oracle_render(const float *verts, const float *uvs, const int32_t *face
         for (int c = 0; c < 3; ++c) {
           float top = fmaf(ax, (float)p01[c] - (float)p00[c], (float)p00[c]);
           float bot = fmaf(ax, (float)p11[c] - (float)p10[c], (float)p10[c]);
-          rgb[c] = floorf(fmaf(ay, bot - top, top)); /* tester.py:244 astype('uint8') truncation */
+          rgb[c] = fmaf(ay, bot - top, top);
+          if (!lit) rgb[c] = floorf(rgb[c]); /* tester.py:244 astype('uint8') truncation */
+        }
+      }
+      if (lit) {
+        float n[3], p[3];
+        for (int c = 0; c < 3; ++c) {
+          const float *N0 = lit->normals + 3 * faces[3 * f], *N1 = lit->normals + 3 * faces[3 * f + 1], *N2 = lit->normals + 3 * faces[3 * f + 2];
+          const float *P0 = verts + 3 * faces[3 * f], *P1 = verts + 3 * faces[3 * f + 1], *P2 = verts + 3 * faces[3 * f + 2];
+          n[c] = fmaf(w2, N2[c], fmaf(w1, N1[c], w0 * N0[c])) * z; /* perspective-correct varyings v_normal, v_position */
+          p[c] = fmaf(w2, P2[c], fmaf(w1, P1[c], w0 * P0[c])) * z;
+        }
+        float Ng[3], Pg[3];
+        for (int r = 0; r < 3; ++r) {
+          float sgn = r == 0 ? 1.f : -1.f; /* OpenCV -> OpenGL camera: y and z flip */
+          Ng[r] = sgn * fmaf(R[3 * r + 2], n[2], fmaf(R[3 * r + 1], n[1], R[3 * r] * n[0]));
+          Pg[r] = sgn * (fmaf(R[3 * r + 2], p[2], fmaf(R[3 * r + 1], p[1], R[3 * r] * p[0])) + t[r]);
+        }
+        float sx = lit->light_pos[0] - Pg[0], sy = lit->light_pos[1] - Pg[1], sz = lit->light_pos[2] - Pg[2];
+        float dotv = fmaf(Ng[2], sz, fmaf(Ng[1], sy, Ng[0] * sx));
+        float ls = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
+        float ln = sqrtf(fmaf(Ng[2], Ng[2], fmaf(Ng[1], Ng[1], Ng[0] * Ng[0])));
+        float br = dotv / (ls * ln);
+        br = fmaxf(fminf(br, 1.0f), 0.0f);
+        float k = fmaf(lit->ratio, br, 1.0f - lit->ratio);
+        for (int c = 0; c < 3; ++c) {
+          float col = (rgb[c] / 255.0f) * (k * lit->light_int[c]);
+          col = fminf(fmaxf(col, 0.0f), 1.0f);
+          rgb[c] = floorf(fmaf(col, 255.0f, 0.5f));
         }
       }
       o[0] = rgb[2]; o[1] = rgb[1]; o[2] = rgb[0];
@@ -164,6 +206,21 @@ void dim_oracle_render(const float *verts, const float *uvs, const int32_t *face
     }
   free(zbuf);
   free(scr);
+}
+
+void dim_oracle_render(const float *verts, const float *uvs, const int32_t *faces, int V, int F,
+                       const uint8_t *tex, int Ht, int Wt, const float *R, const float *t, const float *K,
+                       int H, int W, float znear, float zfar, int tex_bilinear, float *bgr, float *depth) {
+  render_impl(verts, uvs, faces, V, F, tex, Ht, Wt, R, t, K, H, W, znear, zfar, tex_bilinear, NULL, bgr, depth);
+}
+
+/* Render_Py_Light_ModelNet_Multi.render (render_py_light_modelnet_multi.py:153-235) */
+void dim_oracle_render_lit(const float *verts, const float *normals, const float *uvs, const int32_t *faces, int V, int F,
+                           const uint8_t *tex, int Ht, int Wt, const float *R, const float *t, const float *K,
+                           int H, int W, float znear, float zfar, int tex_bilinear, const float *light_pos,
+                           const float *light_int, float ratio, float *bgr, float *depth) {
+  lit_t lit = {normals, light_pos, light_int, ratio};
+  render_impl(verts, uvs, faces, V, F, tex, Ht, Wt, R, t, K, H, W, znear, zfar, tex_bilinear, &lit, bgr, depth);
 }
 
 /* gpu_flow_kernel.cu:32-69 restated on the CPU (float arithmetic, same operation order). */

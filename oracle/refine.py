@@ -30,7 +30,7 @@ def update_mask_observed_box_rendered(mask_rendered):
 
 
 def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord="CAMERA", test_iter=4, znear=0.25, zfar=6.0,
-                tex_bilinear=False, fast_test=True):
+                tex_bilinear=False, fast_test=True, return_outputs=False):
     """One (observed, rendered) pair, batch 1 like the reference.
     blobs: image_observed (1,3,H,W), image_rendered, mask_observed (1,1,H,W), mask_rendered, src_pose (1,3,4).
     mesh: (verts, uvs, faces, tex).  Returns list of poses (test_iter x (3,4) float64) and the per-iteration se3."""
@@ -38,10 +38,11 @@ def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord=
     batch = {k: np.array(v, dtype=np.float32) for k, v in blobs.items()}
     pose_rendered = np.array(batch["src_pose"][0], dtype=np.float64)
     out = flownet.forward_test(params, batch, K, pixel_means, fast_test=fast_test)
-    poses, se3s = [], []
+    poses, se3s, outs = [], [], []
     for it in range(test_iter):
         se3 = np.squeeze(out["se3"]).astype("float32")
         se3s.append(se3)
+        outs.append({k: out[k] for k in ("mask_observed_pred", "zoom_mask_prob", "flow_est_crop", "zoom_factor") if k in out})
         pose_new = ose3.RT_transform(pose_rendered, se3[:-3], se3[-3:], T_means, T_stds, rot_coord)
         poses.append(pose_new)
         if it < test_iter - 1:
@@ -56,6 +57,8 @@ def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord=
             batch["src_pose"] = pose_new[np.newaxis].astype(np.float32)  # nd.array -> float32
             pose_rendered = pose_new
             out = flownet.forward_test(params, batch, K, pixel_means, fast_test=fast_test)
+    if return_outputs:  # tester.py:485-491 reads the mask / flow heads every iteration when not FAST_TEST
+        return poses, se3s, outs
     return poses, se3s
 
 

@@ -84,3 +84,76 @@ def test_refine_4iter_vs_oracle(setup, graph):
             e = pose_error.add(poses[it, b][:, :3].astype(np.float64), poses[it, b][:, 3].astype(np.float64), o_poses[it][:, :3],
                                o_poses[it][:, 3], pts)
             assert e < 1e-3 * diam, (b, it, e)
+
+
+def test_refine_full_graph_multiclass_vs_oracle(hip_lib):
+    """BASELINE configs[3] shape at test size: several classes resident, FAST_TEST False (decoder + mask + flow heads
+    produced every iteration, tester.py:485-491), UPDATE_MASK box_rendered (predicted mask not fed back), hipGraph."""
+    from deepim.core.tester import Predictor, Refiner
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+    from lib.render_hip.render_py_multi import Render_Py
+
+    cfg = make_test_config(test_iter=4)
+    cfg.TEST.FAST_TEST = False
+    cfg.dataset.class_name = ["ape", "can", "cat"]
+    sym = deepIM_flownet()
+    sym.get_symbol(cfg, is_train=False)
+    params = sym.init_weights(cfg, {}, {}, seed=3)
+    rng = np.random.RandomState(4)
+    params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
+    params["rot_weight"][1:] = (rng.randn(3, 256) * 0.01).astype(np.float32)
+    params["mask_conv3_weight"] = (rng.randn(1, 770, 3, 3) * 0.05).astype(np.float32)
+    params["mask_conv3_bias"] = np.array([0.1], np.float32)
+    B = 3
+    scene = make_scene(B=B, seed=909, subdiv=3, n_models=3)
+    bl = scene["blobs"]
+    assert len(set(bl["class_index"].tolist())) >= 2
+    pred = Predictor(cfg, params, B)
+    rm = Render_Py(None, cfg.dataset.class_name, scene["K"], meshes=scene["models"])
+    load = (bl["image_observed"], bl["image_rendered"], bl["mask_observed"], bl["mask_rendered"], bl["src_pose"], bl["class_index"])
+    # eager pass with a hook that snapshots the blobs every iteration's forward sees
+    ref = Refiner(cfg, pred, rm, B, capture_graph=False)
+    ref.load(*load)
+    snaps, orig = [], pred.net.forward_test
+
+    def hooked(batch, bbox_ren=None):
+        snaps.append({k: v.cpu().numpy().copy() for k, v in batch.items()})
+        return orig(batch, bbox_ren=bbox_ren)
+
+    pred.net.forward_test = hooked
+    poses = ref.refine().cpu().numpy().copy()
+    pred.net.forward_test = orig
+    masks = ref.mask_pred_iter.cpu().numpy().copy()
+    flows = ref.flow_est_iter.cpu().numpy().copy()
+    se3s = ref.se3_iter.cpu().numpy().copy()
+    assert len(snaps) == 4
+    # (1) every iteration's network outputs vs the oracle on the SAME blobs (tight: no error feedback through the loop)
+    for it in range(4):
+        o = oflow.forward_test(params, snaps[it], scene["K"], cfg.network.PIXEL_MEANS, fast_test=False)
+        np.testing.assert_allclose(se3s[it], o["se3"], atol=2e-5, rtol=1e-4)
+        assert (masks[it] != o["mask_observed_pred"]).sum() <= 300
+        rfl = o["flow_est_crop"]
+        np.testing.assert_allclose(flows[it], rfl, atol=1e-3 * max(1.0, np.abs(rfl).max()))
+    # (2) the loop as a whole vs the oracle's loop (north_star bar 1e-3; random weights amplify pose differences
+    #     through re-rendering, so later iterations of the dense heads are only compared in (1))
+    z3, o3 = np.zeros(3), np.ones(3)
+    for b in range(B):
+        blobs_b = {k: bl[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
+        o_poses, o_se3, o_out = orefine.refine_pair(params, scene["models"][int(bl["class_index"][b])], blobs_b, scene["K"],
+                                                    cfg.network.PIXEL_MEANS, z3, o3, "CAMERA", test_iter=4, fast_test=False,
+                                                    return_outputs=True)
+        for it in range(4):
+            # the test graph emits the un-normalised quaternion (RT_transform.py:143 normalises on use)
+            np.testing.assert_allclose(se3s[it, b, :4] / np.linalg.norm(se3s[it, b, :4]), o_se3[it][:4] / np.linalg.norm(o_se3[it][:4]),
+                                       atol=1e-3)
+            np.testing.assert_allclose(se3s[it, b, 4:], o_se3[it][4:], atol=1e-3)
+            np.testing.assert_allclose(poses[it, b], o_poses[it], atol=1e-3)
+        rfl = o_out[0]["flow_est_crop"][0]
+        np.testing.assert_allclose(flows[0, b], rfl, atol=1e-3 * max(1.0, np.abs(rfl).max()))
+        assert (masks[0, b] != o_out[0]["mask_observed_pred"][0]).sum() <= 100
+    # (3) hipGraph replay of the same loop is bit-identical to the eager pass
+    refg = Refiner(cfg, pred, rm, B, capture_graph=True)
+    refg.load(*load)
+    np.testing.assert_array_equal(refg.refine().cpu().numpy(), poses)
+    np.testing.assert_array_equal(refg.mask_pred_iter.cpu().numpy(), masks)
+    np.testing.assert_array_equal(refg.flow_est_iter.cpu().numpy(), flows)
