@@ -73,6 +73,9 @@ class Refiner(object):
         self.T_means = np.asarray(cfg.dataset.trans_means, dtype=np.float32)
         self.T_stds = np.asarray(cfg.dataset.trans_stds, dtype=np.float32)
         render_machine.reserve(B)
+        # ModelNet: the lit renderer takes a per-render light intensity drawn on the host (tester.py:227-230)
+        self.lit = hasattr(render_machine, "normals")
+        self.light_int = torch.ones((max(self.test_iter - 1, 1), B, 3), dtype=torch.float32, device=d) if self.lit else None
         self.graph = None
         self._want_graph = capture_graph
 
@@ -86,6 +89,10 @@ class Refiner(object):
         self.init["mask_rendered"].copy_(torch.as_tensor(mask_rendered))
         self.pose_init.copy_(torch.as_tensor(src_pose))
         b["class_index"].copy_(torch.as_tensor(class_index).to(torch.int32))
+        if self.lit and self.test_iter > 1:
+            # same draws, same order as the reference: sample by sample, one np.random.uniform(0.9,1.1,3) per re-render
+            li = np.stack([[np.random.uniform(0.9, 1.1, size=(3,)) for _ in range(self.test_iter - 1)] for _ in range(self.B)])
+            self.light_int.copy_(torch.from_numpy(li.transpose(1, 0, 2).astype(np.float32)))
 
     def _loop(self):
         """tester.py:476-598 for a whole batch; everything enqueued on the current stream, no host sync."""
@@ -106,8 +113,10 @@ class Refiner(object):
             ops.se3_compose(b["src_pose"], net.se3, cfg.network.ROT_COORD, self.T_means, self.T_stds, out=self.poses_iter[it])
             if it < self.test_iter - 1:
                 # render(render_machine, pose_rendered_update, cls_idx) + update_data_batch  (:563-590)
+                extra = {"light_intensity": self.light_int[it]} if self.lit else {}
                 self.render_machine.render_batch(b["class_index"], self.poses_iter[it], image=b["image_rendered"], depth=self.depth,
-                                                 mask=b["mask_rendered"], bbox=self.bbox, plane_means=net.plane_means, mask_thr=0.2)
+                                                 mask=b["mask_rendered"], bbox=self.bbox, plane_means=net.plane_means, mask_thr=0.2,
+                                                 **extra)
                 if cfg.network.INPUT_MASK and cfg.network.PRED_MASK and cfg.TEST.UPDATE_MASK == "box_rendered":
                     ops.box_mask(self.bbox, b["mask_observed"])  # data_pair.py:103-114
                 b["src_pose"].copy_(self.poses_iter[it])

@@ -51,9 +51,14 @@ class batchUpdaterPyMulti(object):
         b["se3"][:, 4:].copy_(preds["trans_est"])
         ops.se3_compose(data_batch["src_pose"], b["se3"], self.rot_coord, self.T_means, self.T_stds, out=b["pose"])
         depth = data_batch.get("depth_rendered", b["depth"])
+        extra = {}
+        if hasattr(self.render_machine, "normals"):  # ModelNet lit renderer (:232-270): light idx 2, host-drawn intensity per sample
+            B = b["pose"].shape[0]
+            li = np.stack([np.random.uniform(0.9, 1.1, size=(3,)) for _ in range(B)]).astype(np.float32)
+            extra["light_intensity"] = torch.from_numpy(li).to(b["pose"].device)
         self.render_machine.render_batch(data_batch["class_index"], b["pose"], image=data_batch["image_rendered"], depth=depth,
                                          mask=data_batch["mask_rendered"] if cfg.network.INPUT_MASK else None, plane_means=self.plane_means,
-                                         mask_thr=0.2)
+                                         mask_thr=0.2, **extra)
         rot, trans = ops.se3_delta(b["pose"], data_batch["tgt_pose"], self.rot_coord, self.T_means, self.T_stds)
         data_batch["rot"].copy_(rot)
         data_batch["trans"].copy_(trans)

@@ -30,8 +30,10 @@ def update_mask_observed_box_rendered(mask_rendered):
 
 
 def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord="CAMERA", test_iter=4, znear=0.25, zfar=6.0,
-                tex_bilinear=False, fast_test=True, return_outputs=False):
+                tex_bilinear=False, fast_test=True, return_outputs=False, lit=None):
     """One (observed, rendered) pair, batch 1 like the reference.
+    lit: None, or dict(normals=(V,3), ratio=0.7) for the ModelNet branch of `render` (tester.py:204-243): light index 2,
+    one np.random.uniform(0.9, 1.1, 3) intensity per re-render drawn from numpy's global RNG like the reference.
     blobs: image_observed (1,3,H,W), image_rendered, mask_observed (1,1,H,W), mask_rendered, src_pose (1,3,4).
     mesh: (verts, uvs, faces, tex).  Returns list of poses (test_iter x (3,4) float64) and the per-iteration se3."""
     verts, uvs, faces, tex = mesh
@@ -46,8 +48,15 @@ def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord=
         pose_new = ose3.RT_transform(pose_rendered, se3[:-3], se3[-3:], T_means, T_stds, rot_coord)
         poses.append(pose_new)
         if it < test_iter - 1:
-            bgr, depth = native.render(verts, uvs, faces, tex, pose_new[:3, :3], pose_new[:, 3], K, znear=znear, zfar=zfar,
-                                       tex_bilinear=tex_bilinear)
+            if lit is None:
+                bgr, depth = native.render(verts, uvs, faces, tex, pose_new[:3, :3], pose_new[:, 3], K, znear=znear, zfar=zfar,
+                                           tex_bilinear=tex_bilinear)
+            else:
+                light_position = native.modelnet_light_position(pose_new, idx=2)
+                light_intensity = np.array([1, 1, 1])[0] * np.random.uniform(0.9, 1.1, size=(3,))
+                bgr, depth = native.render_lit(verts, lit["normals"], uvs, faces, tex, pose_new[:3, :3], pose_new[:3, 3], K,
+                                               light_position, light_intensity, lit.get("ratio", 0.7), znear=znear, zfar=zfar,
+                                               tex_bilinear=tex_bilinear)
             image_refined = bgr.astype("uint8")  # tester.py:246
             mask_r = np.zeros(depth.shape)
             mask_r[depth > 0.2] = 1  # tester.py:575-577

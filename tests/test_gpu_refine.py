@@ -157,3 +157,47 @@ def test_refine_full_graph_multiclass_vs_oracle(hip_lib):
     np.testing.assert_array_equal(refg.refine().cpu().numpy(), poses)
     np.testing.assert_array_equal(refg.mask_pred_iter.cpu().numpy(), masks)
     np.testing.assert_array_equal(refg.flow_est_iter.cpu().numpy(), flows)
+
+
+def test_refine_modelnet_lit_vs_oracle(hip_lib):
+    """BASELINE configs[4] shape at test size: several gray-textured meshes resident, lit renderer in the loop
+    (tester.py:170-243), light intensities drawn from numpy's global RNG in the reference's order."""
+    from deepim.core.tester import Predictor, Refiner
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+    from lib.render_hip.render_py_light_modelnet_multi import Render_Py_Light_ModelNet_Multi, vertex_normals
+
+    cfg = make_test_config(test_iter=4)
+    cfg.dataset.dataset = "ModelNet_v1"
+    cfg.dataset.class_name = ["m0", "m1"]
+    sym = deepIM_flownet()
+    sym.get_symbol(cfg, is_train=False)
+    params = sym.init_weights(cfg, {}, {}, seed=0)
+    rng = np.random.RandomState(1)
+    params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
+    params["rot_weight"][1:] = (rng.randn(3, 256) * 0.01).astype(np.float32)
+    B = 2
+    scene = make_scene(B=B, seed=4242, subdiv=3, n_models=2)
+    bl = scene["blobs"]
+    gray = np.full((32, 32, 3), 180, np.uint8)
+    meshes = [(v, vertex_normals(v, f).astype(np.float32), t, f) for v, t, f, _ in scene["models"]]
+    pred = Predictor(cfg, params, B)
+    rm = Render_Py_Light_ModelNet_Multi(None, gray, scene["K"], 640, 480, 0.25, 6.0, brightness_ratios=[0.7], meshes=meshes)
+    ref = Refiner(cfg, pred, rm, B, capture_graph=True)
+    np.random.seed(99)
+    ref.load(bl["image_observed"], bl["image_rendered"], bl["mask_observed"], bl["mask_rendered"], bl["src_pose"], bl["class_index"])
+    poses = ref.refine().cpu().numpy().copy()
+    assert int(ref.status_iter.abs().sum()) == 0
+    np.random.seed(99)  # the oracle consumes the same stream: sample by sample, one draw per re-render
+    z3, o3 = np.zeros(3), np.ones(3)
+    for b in range(B):
+        c = int(bl["class_index"][b])
+        v, n, t, f = meshes[c]
+        blobs_b = {k: bl[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
+        o_poses, o_se3 = orefine.refine_pair(params, (v, t, f, gray), blobs_b, scene["K"], cfg.network.PIXEL_MEANS, z3, o3, "CAMERA",
+                                             test_iter=4, lit={"normals": n, "ratio": 0.7})
+        for it in range(4):
+            np.testing.assert_allclose(poses[it, b], o_poses[it], atol=1e-3)
+    # the lit image really is what the loop fed back: shading varies over the object
+    img = ref.batch["image_rendered"].cpu().numpy()
+    on = ref.batch["mask_rendered"].cpu().numpy()[:, 0] > 0
+    assert img[:, 0][on].std() > 2.0
