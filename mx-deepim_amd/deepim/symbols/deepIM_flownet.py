@@ -177,13 +177,14 @@ class FlowNetHip(object):
             tile, splits = self.conv_plan.get(name, ops.conv_auto_plan(B * ho * wo, cout, nchunks))
             self.conv_plan[name] = (tile, splits)
             self.layer_info[name] = dict(M=B * ho * wo, K=c * k * k, N=cout, flops=2 * B * ho * wo * cout * c * k * k, tile=tile,
-                                         splits=splits, cin=c)
+                                         splits=splits, cin=c, min_bytes=4 * (B * h * w * c + cout * c * k * k + B * ho * wo * cout))
             if splits > 1:
                 max_ws = max(max_ws, ops.lib().dim_conv2d_workspace_floats(B, h, w, c, cout, k, k, s, p, splits))
             h, w, c = ho, wo, cout
         assert (h, w, c) == (8, 10, 1024)
         tile, splits = self.conv_plan["fc6"]
-        self.layer_info["fc6"] = dict(M=B, K=81920, N=256, flops=2 * B * 81920 * 256, tile=tile, splits=splits, cin=1024)
+        self.layer_info["fc6"] = dict(M=B, K=81920, N=256, flops=2 * B * 81920 * 256, tile=tile, splits=splits, cin=1024,
+                                      min_bytes=4 * (B * 81920 + 256 * 81920 + B * 256))
         max_ws = max(max_ws, ops.lib().dim_conv2d_workspace_floats(B, 8, 10, 1024, 256, 8, 10, 1, 0, splits))
         self.workspace = torch.empty((max(max_ws, 4),), dtype=torch.float32, device=d)
         # ---- decoder + flow / mask heads (only in the graph when not FAST_TEST, reference :840-954)
