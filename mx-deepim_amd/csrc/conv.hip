@@ -37,9 +37,21 @@ struct ConvArgs {
   int in_cstride, out_cstride, out_coff;
   int dense_out, OH, OW, osy, osx, ooy, oox;
   int accumulate;  // out += v (final pass only)
+  unsigned x_bytes, w_bytes;  // extents of x / w for the buffer descriptors (loads past them return 0)
 };
 
-__device__ const float4 g_zero16 = {0.f, 0.f, 0.f, 0.f};  // source of padding taps
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte buffer load: per-lane byte offset `voff` (0xFFFFFFFF = out of range = zeros), wave-uniform byte offset `soff`
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  float4 f;
+  f.x = __uint_as_float(v.x);
+  f.y = __uint_as_float(v.y);
+  f.z = __uint_as_float(v.z);
+  f.w = __uint_as_float(v.w);
+  return f;
+}
 
 template <int BM, int BN, int WM, int WN, bool CIN8>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
@@ -81,12 +93,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     int n = t / a.Ho;
     a_hi0[i] = ok ? ho * a.stride - a.pad_h : -(1 << 28);  // rows past M: every tap fails the bounds test
     a_wi0[i] = wo * a.stride - a.pad_w + (CIN8 ? (q >> 1) : 0);
-    // element offset of this thread's float4 at tap (0,0), channel 0 (may be negative in the padding; int32, host-checked).
+    // BYTE offset of this thread's float4 at tap (0,0), channel 0 (may be negative in the padding; 32 bits, host-checked).
     // For the 8-channel layer the 4 taps of a chunk are contiguous in memory, so "+ q*4" covers tap and channel half.
-    a_pix[i] = (n * a.H + a_hi0[i]) * a.W * a.in_cstride + (wo * a.stride - a.pad_w) * a.in_cstride + q * 4;
+    a_pix[i] = ((n * a.H + (ok ? a_hi0[i] : 0)) * a.W * a.in_cstride + (wo * a.stride - a.pad_w) * a.in_cstride + q * 4) * 4;
   }
-  const float* wbase = a.w + ((long)(n0 + srow) * BK + q * 4);  // packed [chunk][Cout][32]
-  const long wchunk = (long)a.Cout * BK;
+  // Both operands go through buffer descriptors: a padding tap is a load at offset 0xFFFFFFFF (the range check returns
+  // zeros: one v_cndmask on a 32-bit offset, no pointer select, no exec juggling, and -- unlike the flat loads a pointer
+  // select compiles to -- nothing that counts on lgkmcnt next to the LDS fragment reads); the weights take the chunk as
+  // a scalar offset, so their per-lane offset is loop-invariant.
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const int w_voff = ((n0 + srow) * BK + q * 4) * 4;  // packed [chunk][Cout][32]
+  const int wchunk_bytes = a.Cout * BK * 4;
 
   // chunk -> (kh, kw, c0) counters
   int kh, kw, c0;
@@ -109,25 +127,24 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 
   float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // named registers (arrays + lambdas ended up in scratch)
 
-  // padding taps read a 16-byte zero block instead of branching around the load (address select, no exec juggling);
-  // tap_off is wave-uniform (scalar): one vector add per load
+  // tap_off is wave-uniform (scalar): one vector add per load.  (It cannot ride in the instruction's scalar offset: that
+  // one is excluded from the range check, and a_pix alone is negative = out of range in the top/left padding.)
 #define DIM_LOAD_A(REG, I)                                                                                         \
   if (I < A_PER_T) {                                                                                                \
     bool ok = pf_ok && (unsigned)(a_hi0[I] + kh) < (unsigned)a.H && (unsigned)(a_wi0[I] + kw) < (unsigned)a.W &&    \
               (!CIN8 || kw + (q >> 1) < a.KW);                                                                      \
-    const float* src = ok ? a.x + (a_pix[I] + tap_off) : reinterpret_cast<const float*>(&g_zero16);                 \
-    REG = *reinterpret_cast<const float4*>(src);                                                                    \
+    REG = buf_load16(rx, ok ? a_pix[I] + tap_off : -1, 0);                                                          \
   }
 #define DIM_LOAD_B(REG, I) \
-  if (I < B_PER_T) REG = *reinterpret_cast<const float4*>(wsrc + I * 32 * BK);
+  if (I < B_PER_T) REG = buf_load16(rw, w_voff + I * 32 * BK * 4, w_soff);
   // PF_OK = false on the one prefetch past the last chunk: its (kh,kw,c0) counters already point one channel slice beyond
-  // the tensor, so the (unused) activation read must be redirected to the zero block -- it faulted when x ended at a page end
-#define DIM_LOAD_CHUNK(KC, PF_OK)                                \
-  {                                                              \
-    const bool pf_ok = (PF_OK);                                  \
-    const int tap_off = (kh * a.W + kw) * a.in_cstride + c0;     \
+  // the tensor, so the (unused) activation read is dropped like a padding tap
+#define DIM_LOAD_CHUNK(KC, PF_OK)                                  \
+  {                                                                \
+    const bool pf_ok = (PF_OK);                                    \
+    const int tap_off = ((kh * a.W + kw) * a.in_cstride + c0) * 4; \
     DIM_LOAD_A(ra0, 0) DIM_LOAD_A(ra1, 1) DIM_LOAD_A(ra2, 2) DIM_LOAD_A(ra3, 3) \
-    const float* wsrc = wbase + (long)(KC) * wchunk;             \
+    const int w_soff = (KC) * wchunk_bytes;                        \
     DIM_LOAD_B(rb0, 0) DIM_LOAD_B(rb1, 1) DIM_LOAD_B(rb2, 2) DIM_LOAD_B(rb3, 3) \
   }
 #define DIM_ADVANCE()                        \
@@ -638,10 +655,13 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   a.ooy = a.dense_out ? 0 : ex->ooy; a.oox = a.dense_out ? 0 : ex->oox;
   DIM_REQUIRE(a.in_cstride >= Cin && a.in_cstride % 4 == 0, "in_cstride must be >= Cin and a multiple of 4");
   DIM_REQUIRE(a.out_cstride >= a.out_coff + Cout, "out_cstride < out_coff + Cout");
-  DIM_REQUIRE((long)N * H * W * a.in_cstride < (1L << 31), "input too large for 32-bit element offsets (%ld elements)",
+  DIM_REQUIRE((long)N * H * W * a.in_cstride < (1L << 29), "input too large for 32-bit byte offsets (%ld elements)",
               (long)N * H * W * a.in_cstride);
+  a.x_bytes = (unsigned)((long)N * H * W * a.in_cstride * 4);
   a.M = N * a.Ho * a.Wo;
   a.nchunks = (Cin == 8) ? KH * 2 : KH * KW * (Cin / 32);
+  DIM_REQUIRE((long)a.nchunks * Cout * 32 * 4 < (1L << 31), "packed weights too large for 32-bit byte offsets");
+  a.w_bytes = (unsigned)((long)a.nchunks * Cout * 32 * 4);
   if (splits < 1) splits = 1;
   if (splits > a.nchunks) splits = a.nchunks;
   a.chunks_per_split = (a.nchunks + splits - 1) / splits;

@@ -22,6 +22,9 @@ for name, cout, k, s, p in ENCODER:
     c = cout
 x = torch.randn((B, h, w, c), device="cuda:0")
 wt = torch.randn((cout, c, k, k), device="cuda:0") * 0.01
+if os.environ.get("ZERO_DATA"):  # power / clock experiment: all-zero operands draw far less MFMA power
+    x.zero_()
+    wt.zero_()
 wp = ops.conv2d_pack_weight(wt)
 bias = torch.zeros(cout, device="cuda:0")
 ho, wo = ops.conv_out_hw(h, w, k, k, s, p)
