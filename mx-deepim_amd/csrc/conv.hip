@@ -40,19 +40,6 @@ struct ConvArgs {
   unsigned x_bytes, w_bytes;  // extents of x / w for the buffer descriptors (loads past them return 0)
 };
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// 16-byte buffer load: per-lane byte offset `voff` (0xFFFFFFFF = out of range = zeros), wave-uniform byte offset `soff`
-__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-  float4 f;
-  f.x = __uint_as_float(v.x);
-  f.y = __uint_as_float(v.y);
-  f.z = __uint_as_float(v.z);
-  f.w = __uint_as_float(v.w);
-  return f;
-}
-
 template <int BM, int BN, int WM, int WN, bool CIN8>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   constexpr int BK = 32;

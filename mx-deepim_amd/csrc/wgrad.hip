@@ -25,9 +25,9 @@ struct WgradArgs {
   int KH, KW, stride, pad;
   int M, nchunks, steps_per_split, nsteps;
   int accumulate;
+  unsigned x_bytes, dz_bytes;  // extents for the buffer descriptors
+  FastDiv div_wo, div_ho;      // pixel index -> (n, ho, wo) every step without integer division sequences
 };
-
-__device__ const float4 g_wzero16 = {0.f, 0.f, 0.f, 0.f};
 
 template <int NW, bool CIN8, int NCH>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
@@ -78,28 +78,34 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-  const float* zero = reinterpret_cast<const float*>(&g_wzero16);
+  // Buffer descriptors: a padding tap / a pixel past M is a load at offset 0xFFFFFFFF (range check -> zeros).  No pointer
+  // select (it compiled to flat loads, which also count on lgkmcnt and so serialised against the LDS fragment reads).
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz), 0, a.dz_bytes, 0x00020000);
+  const int z_voff = (a.dz_coff + co0 + zq * 4) * 4;
+  int tapb[NCH];  // byte offset of each chunk's tap / channel slice
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) tapb[c] = ((kh[c] * a.W + kw[c]) * a.in_cstride + c0[c]) * 4;
 #define DIM_WG_LZ(REG, I)                                                                                         \
   {                                                                                                               \
     int m = p0 + zr0 + ZR_STEP * I;                                                                               \
-    const float* src = (pf && m < a.M) ? a.dz + (long)m * a.dz_cstride + a.dz_coff + co0 + zq * 4 : zero;         \
-    REG = *reinterpret_cast<const float4*>(src);                                                                  \
+    REG = buf_load16(rsz, (pf && m < a.M) ? m * (a.dz_cstride * 4) + z_voff : -1, 0);                             \
   }
 #define DIM_WG_LX(REG, C, I)                                                                                      \
   if (C < NCH && I < XP) {                                                                                        \
     int hi = hb##I + kh[C];                                                                                       \
     int wi = wb##I + kw[C] + (CIN8 ? (xq >> 1) : 0);                                                              \
     bool ok = okm##I && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && (!CIN8 || kw[C] + (xq >> 1) < a.KW); \
-    const float* src = ok ? a.x + (pix##I + (long)(kh[C] * a.W + kw[C]) * a.in_cstride + c0[C]) : zero;           \
-    REG = *reinterpret_cast<const float4*>(src);                                                                  \
+    REG = buf_load16(rsx, ok ? pix##I + tapb[C] : -1, 0);                                                         \
   }
 #define DIM_WG_PIX(I)                                                                                             \
   int m##I = p0 + xr0 + XR_STEP * I;                                                                              \
   bool okm##I = pf && (I < XP) && m##I < a.M;                                                                     \
-  int mm##I = okm##I ? m##I : 0;                                                                                  \
-  int wo##I = mm##I % a.Wo, t##I = mm##I / a.Wo, ho##I = t##I % a.Ho, n##I = t##I / a.Ho;                         \
+  unsigned mm##I = okm##I ? m##I : 0;                                                                             \
+  unsigned t##I = fastdiv(mm##I, a.div_wo), n##I = fastdiv(t##I, a.div_ho);                                       \
+  int wo##I = mm##I - t##I * a.Wo, ho##I = t##I - n##I * a.Ho;                                                    \
   int hb##I = ho##I * a.stride - a.pad, wb##I = wo##I * a.stride - a.pad;                                         \
-  long pix##I = ((long)(n##I * a.H + hb##I) * a.W + wb##I) * a.in_cstride + xq * 4;
+  int pix##I = (((int)n##I * a.H + hb##I) * a.W + wb##I) * (a.in_cstride * 4) + xq * 16;
   // global -> registers for step `st` (pf = false: everything reads the zero block; used for the prefetch past the end)
 #define DIM_WG_LOAD(st, pf_ok)                                      \
   {                                                                 \
@@ -252,13 +258,18 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   DIM_REQUIRE(x && dz && dw_packed, "null pointer");
   DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
   DIM_REQUIRE(Cout % 64 == 0, "Cout must be a multiple of 64 (got %d)", Cout);
-  DIM_REQUIRE((long)N * H * W * in_cstride < (1L << 31) && (long)N * Ho * Wo * dz_cstride < (1L << 31), "tensor too large");
+  DIM_REQUIRE((long)N * H * W * in_cstride < (1L << 29) && (long)N * Ho * Wo * dz_cstride < (1L << 29),
+              "tensor too large for 32-bit byte offsets");
   DIM_REQUIRE(dz_cstride % 4 == 0 && dz_coff % 4 == 0 && in_cstride % 4 == 0, "channel strides / offsets must be multiples of 4");
   WgradArgs a;
   a.x = x; a.dz = dz;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_cstride = in_cstride; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.dz_cstride = dz_cstride; a.dz_coff = dz_coff; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
   a.M = N * Ho * Wo;
+  a.x_bytes = (unsigned)((long)N * H * W * in_cstride * 4);
+  a.dz_bytes = (unsigned)((long)N * Ho * Wo * dz_cstride * 4);
+  a.div_wo = make_fastdiv((unsigned)Wo);
+  a.div_ho = make_fastdiv((unsigned)Ho);
   a.nchunks = (Cin == 8) ? KH * 2 : KH * KW * (Cin / 32);
   a.nsteps = ceil_div(a.M, 32);
   if (splits < 1) splits = 1;
