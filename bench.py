@@ -162,12 +162,12 @@ def main():
             net.head()
     torch.cuda.synchronize()
     per_kernel = {}
-    TILE_SYM = {1: "128, 128", 2: "128, 64", 3: "64, 64"}
+    TILE_SYM = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 128, 2, 4"}
     for name, evs in events.items():
         info = net.layer_info[name]
         for tag, e0, e1 in evs:
             if tag == "conv":  # the symbol rocprofv3 --kernel-trace reports for this launch
-                kname = "dim::conv_fwd_kernel<{}, 2, 2, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
+                kname = "dim::conv_fwd_kernel<{}, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
                 flops, nbytes = info["flops"], info["min_bytes"]
             else:
                 kname, flops, nbytes = "dim::splitk_reduce_kernel", 0.0, 0.0

@@ -7,12 +7,14 @@
 // with a 32-deep K chunk that is one tap x 32 channels (Cin % 32 == 0) or, for the 8-channel
 // first layer, four horizontally adjacent taps x 8 channels (= 32 contiguous floats in HBM).
 //
-// Block = 256 threads = 4 waves; wave tile = (BM/WM) x (BN/WN) in 32x32 MFMA tiles.
+// Block = 4 (or 8) waves; wave tile = (BM/WM) x (BN/WN) in 32x32 MFMA tiles.
 // LDS: A chunk [BM][32+4] and B chunk [BN][32+4], both k-contiguous: staged with one ds_write_b128 per float4 and read
 //      back as ds_read_b128 = four k-steps of MFMA operands per LDS instruction (the k order inside a chunk is permuted
 //      identically for A and B); two buffers, register prefetch of chunk k+1 under the MFMAs of chunk k.
 // Epilogue: bias + LeakyReLU fused; with gridDim.z > 1 (split-K) raw partials go to a slab
 // and dim_splitk_reduce finishes (deterministic, no atomics).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dim {
@@ -38,17 +40,20 @@ struct ConvArgs {
   int dense_out, OH, OW, osy, osx, ooy, oox;
   int accumulate;  // out += v (final pass only)
   unsigned x_bytes, w_bytes;  // extents of x / w for the buffer descriptors (loads past them return 0)
+  int xcd_chunk;   // > 0: workgroup id -> tile remap that keeps consecutive tiles on one XCD (see conv_fwd_kernel)
 };
 
 template <int BM, int BN, int WM, int WN, bool CIN8>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   constexpr int BK = 32;
+  constexpr int NT = WM * WN * 64;  // 4 or 8 waves
+  constexpr int RP = NT / 8;        // rows staged per pass (8 threads x float4 = one 32-float row)
   constexpr int LDK = BK + 4;       // row stride (floats): 16 rows x 4 dwords hit 16 distinct 4-bank slots for ds_read_b128
   constexpr int TM = BM / WM / 32;  // MFMA tiles per wave along M
   constexpr int TN = BN / WN / 32;
-  constexpr int A_PER_T = BM / 32;  // float4 loads per thread for the A chunk
-  constexpr int B_PER_T = BN / 32;
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int A_PER_T = BM / RP;  // float4 loads per thread for the A chunk
+  constexpr int B_PER_T = BN / RP;
+  static_assert((WM * WN == 4 || WM * WN == 8) && A_PER_T >= 1 && A_PER_T <= 4 && B_PER_T >= 1 && B_PER_T <= 4, "staging plan");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                       // [2][BM][LDK]   pixel-major, k contiguous
@@ -59,8 +64,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
 
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // 1-D tile grid, N tiles fastest: the Cout/BN workgroups that share one A (pixel) tile are adjacent.  Workgroups are
+  // dealt round-robin to the 8 XCDs (each with its own L2), so with xcd_chunk = tiles/8 the id is remapped such that XCD k
+  // walks tiles [k*chunk, (k+1)*chunk) in order: the A tile is fetched into ONE L2 and re-used there by its N tiles, and
+  // neighbouring pixel tiles (which share the 3x3 halo rows) follow on the same XCD.
+  int id = blockIdx.x;
+  if (a.xcd_chunk > 0) id = (id & 7) * a.xcd_chunk + (id >> 3);
+  const int ntiles_n = a.Cout / BN;
+  const int mtile = id / ntiles_n;
+  const int m0 = mtile * BM;
+  const int n0 = (id - mtile * ntiles_n) * BN;
   const int split = blockIdx.z;
   const int kc_begin = split * a.chunks_per_split;
   const int kc_end = min(a.nchunks, kc_begin + a.chunks_per_split);
@@ -71,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   int a_hi0[A_PER_T], a_wi0[A_PER_T], a_pix[A_PER_T];
 #pragma unroll
   for (int i = 0; i < A_PER_T; ++i) {
-    int m = m0 + srow + 32 * i;
+    int m = m0 + srow + RP * i;
     bool ok = m < a.M;
     int mm = ok ? m : 0;
     int wo = mm % a.Wo;
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     REG = buf_load16(rx, ok ? a_pix[I] + tap_off : -1, 0);                                                          \
   }
 #define DIM_LOAD_B(REG, I) \
-  if (I < B_PER_T) REG = buf_load16(rw, w_voff + I * 32 * BK * 4, w_soff);
+  if (I < B_PER_T) REG = buf_load16(rw, w_voff + I * RP * BK * 4, w_soff);
   // PF_OK = false on the one prefetch past the last chunk: its (kh,kw,c0) counters already point one channel slice beyond
   // the tensor, so the (unused) activation read is dropped like a padding tap
 #define DIM_LOAD_CHUNK(KC, PF_OK)                                  \
@@ -145,9 +158,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     }                                        \
   }
 #define DIM_STORE_A(REG, I) \
-  if (I < A_PER_T) *reinterpret_cast<float4*>(dA + (srow + 32 * I) * LDK + q * 4) = REG;
+  if (I < A_PER_T) *reinterpret_cast<float4*>(dA + (srow + RP * I) * LDK + q * 4) = REG;
 #define DIM_STORE_B(REG, I) \
-  if (I < B_PER_T) *reinterpret_cast<float4*>(dB + (srow + 32 * I) * LDK + q * 4) = REG;
+  if (I < B_PER_T) *reinterpret_cast<float4*>(dB + (srow + RP * I) * LDK + q * 4) = REG;
 #define DIM_STORE_CHUNK(BUF)                          \
   {                                                   \
     float* dA = sA + (BUF) * BM * LDK;                \
@@ -544,8 +557,12 @@ static int launch_conv(const ConvArgs& a, int splits, hipStream_t st) {
     if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));
     attr_set = true;
   }
-  dim3 grid(ceil_div(a.M, BM), a.Cout / BN, splits);
-  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, CIN8>), grid, dim3(256), lds, st, a);
+  const int tiles = ceil_div(a.M, BM) * (a.Cout / BN);
+  ConvArgs b = a;
+  static const int xcd_mode = getenv("DIM_CONV_XCD") ? atoi(getenv("DIM_CONV_XCD")) : 0;  // experiment switch
+  b.xcd_chunk = (xcd_mode > 0 && tiles % 8 == 0 && tiles >= xcd_mode) ? tiles / 8 : 0;
+  dim3 grid(tiles, 1, splits);
+  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, CIN8>), grid, dim3(WM * WN * 64), lds, st, b);
   return check_launch("conv_fwd");
 }
 
@@ -607,7 +624,7 @@ int dim_splitk_reduce(const float* slabs, const float* bias, float* y, long M, i
   return check_launch("splitk_reduce");
 }
 
-// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64
+// tile: 0 = auto, 1 = 128x128 (4 waves), 2 = 128x64, 3 = 64x64, 4 = 128x128 with 8 waves (64x32 per wave)
 struct ConvEx {
   int in_cstride, out_cstride, out_coff, OH, OW, osy, osx, ooy, oox;  // 0 / 0 / 0 / 0.. = dense defaults
   int accumulate = 0;    // out += result (skip-connection gradients)
@@ -661,20 +678,19 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   a.has_bias = bias != nullptr;
   hipStream_t st = as_stream(stream);
   if (tile == 0) {
-    long blocks128 = (long)ceil_div(a.M, 128) * (Cout / 128 > 0 ? Cout / 128 : 1);
-    if (Cout % 128 == 0 && blocks128 * splits >= 512) tile = 1;
-    else if (Cout == 64 && a.M >= 128 * 512) tile = 2;
-    else tile = 3;
+    tile = (Cout % 128 == 0 && Cin != 8 && a.M >= 128) ? 4 : 3;  // same rule as lib/hip/ops.py conv_auto_plan
   }
   int rc;
   if (Cin == 8) {
     DIM_REQUIRE(tile != 1 || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
+    DIM_REQUIRE(tile != 4, "tile 4 (128x128, 8 waves) is not built for the 8-channel layer");
     if (tile == 1) rc = launch_conv<128, 128, 2, 2, true>(a, splits, st);
     else if (tile == 2) rc = launch_conv<128, 64, 2, 2, true>(a, splits, st);
     else rc = launch_conv<64, 64, 2, 2, true>(a, splits, st);
   } else {
-    DIM_REQUIRE(tile != 1 || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
-    if (tile == 1) rc = launch_conv<128, 128, 2, 2, false>(a, splits, st);
+    DIM_REQUIRE((tile != 1 && tile != 4) || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
+    if (tile == 4) rc = launch_conv<128, 128, 2, 4, false>(a, splits, st);
+    else if (tile == 1) rc = launch_conv<128, 128, 2, 2, false>(a, splits, st);
     else if (tile == 2) rc = launch_conv<128, 64, 2, 2, false>(a, splits, st);
     else rc = launch_conv<64, 64, 2, 2, false>(a, splits, st);
   }

@@ -146,12 +146,15 @@ def conv_out_hw(H, W, KH, KW, stride, pad):
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64"}
 
 
-def conv_auto_plan(M, Cout, nchunks):
-    """default (tile, splits) when the caller does not autotune: 64x64 workgroup tiles (measured best or tied on every
-    encoder layer at batch 16 on MI355X), split-K until the grid has ~2048 workgroups (8 per CU)."""
+def conv_auto_plan(M, Cout, nchunks, cin=32):
+    """default (tile, splits) when the caller does not autotune (tools/tune_conv.py, batch 16, MI355X): 128x128 tiles with 8 waves
+    (tile 4) wherever Cout allows, split-K until the grid has ~900 workgroups; 64x64 tiles (tile 3) for Cout = 64 and the
+    8-channel first layer."""
+    if Cout % 128 == 0 and cin != 8:
+        tiles = -(-M // 128) * (Cout // 128)
+        return 4, max(1, min(6, int(round(900.0 / tiles)), nchunks))
     blocks = -(-M // 64) * (Cout // 64)
-    splits = max(1, min(8, int(round(2048.0 / blocks)), nchunks))
-    return 3, splits
+    return 3, max(1, min(8, int(round(2048.0 / blocks)), nchunks))
 
 
 def conv2d_fwd(x_nhwc, w_packed, bias, Cout, KH, KW, stride, pad, slope=0.1, splits=1, tile=0, out=None, workspace=None,

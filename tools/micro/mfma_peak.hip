@@ -22,11 +22,10 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, float 
 }
 
 template <int NACC>
-void run(int blocks_per_cu, int threads) {
+void run(int blocks_per_cu, int threads, int iters = 2000) {
   int cus = 256;
   float* out;
   hipMalloc(&out, (size_t)cus * blocks_per_cu * threads * 4);
-  int iters = 2000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   k<NACC><<<cus * blocks_per_cu, threads>>>(out, 10, 1.f, 1.f);
@@ -38,7 +37,7 @@ void run(int blocks_per_cu, int threads) {
   float ms; hipEventElapsedTime(&ms, e0, e1);
   double waves = (double)cus * blocks_per_cu * threads / 64;
   double flops = waves * iters * 16.0 * NACC * 32 * 32 * 2 * 2;
-  printf("NACC=%d blocks/CU=%d threads=%d (waves/SIMD=%.1f): %.3f ms  %.1f TF\n", NACC, blocks_per_cu, threads,
+  printf("NACC=%d blocks/CU=%d threads=%d iters=%d (waves/SIMD=%.1f): %.3f ms  %.1f TF\n", NACC, blocks_per_cu, threads, iters,
          blocks_per_cu * threads / 64 / 4.0, ms, flops / ms / 1e9);
   hipFree(out);
 }
@@ -46,5 +45,7 @@ void run(int blocks_per_cu, int threads) {
 int main() {
   run<1>(1, 256); run<1>(2, 256); run<1>(4, 256); run<1>(6, 256);
   run<2>(1, 256); run<2>(2, 256); run<4>(1, 256); run<4>(2, 256); run<4>(3, 256);
+  // sustained: the same loop for ~10 ms, ~100 ms, ~0.5 s (power management lowers the clock under a long MFMA burst)
+  run<4>(1, 256, 6000); run<4>(1, 256, 60000); run<4>(1, 256, 300000); run<4>(1, 256, 2000);
   return 0;
 }
