@@ -112,6 +112,18 @@ class deepIM_flownet(object):
         if not self.arg_shape_dict:
             self.infer_param_shapes(cfg)
         rng = np.random.RandomState(seed)
+        # a FlowNet / RGB-only checkpoint has a 6-channel first layer: the extra (mask / depth) input channels start at zero (:1009-1025)
+        w1 = arg_params.get("flow_conv1_weight")
+        need = self.arg_shape_dict["flow_conv1_weight"][1]
+        if w1 is not None and w1.shape[1] < need:
+            w1 = np.asarray(w1, dtype=np.float32)
+            pad = np.zeros((w1.shape[0], need - w1.shape[1]) + w1.shape[2:], dtype=np.float32)
+            arg_params["flow_conv1_weight"] = np.concatenate([w1, pad], axis=1)
+        # init_from_flownet: the pose / mask heads and the frozen upsamplers are re-initialised even if the file has them (:1031-1093)
+        if arg_params and getattr(cfg.network, "init_from_flownet", False):
+            for k in ("fc6_bias", "fc6_weight", "fc7_bias", "fc7_weight", "rot_bias", "rot_weight", "trans_bias", "trans_weight",
+                      "upsampling_weight", "mask_conv3_bias", "mask_conv3_weight", "mask_upsampling_weight"):
+                arg_params.pop(k, None)
         for k, shp in self.arg_shape_dict.items():
             if k in arg_params:
                 continue
