@@ -211,6 +211,10 @@ int dim_deconv4x4s2_tiny_bwd(const float* x, int x_cstride, const float* dy, int
                              float* dw_iohw, float* db, int N, int H, int W, int Cin, int Cout, int OH, int OW, int crop, void* stream);
 /* mx.optimizer.SGD: mom = momentum*mom - lr*(rescale_grad*g + wd*w); w += mom */
 int dim_sgd_momentum(float* w, const float* grad, float* mom, long n, float lr, float momentum, float wd, float rescale_grad, void* stream);
+/* mx.optimizer.Adam step (deepim/train.py:338-375 selects it with TRAIN.optimizer == "adam"): lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t)
+ * is computed by the caller from the update count t; mean / var are the two state tensors. */
+int dim_adam(float* w, const float* grad, float* mean, float* var, long n, float lr_t, float beta1, float beta2, float epsilon, float wd,
+             float rescale_grad, void* stream);
 /* FullyConnected weight (Out, C*H*W) [mx Flatten order c,h,w] -> [(h,w,c)][Out] so fc6 is dim_conv2d_fwd
  * with KH=H, KW=W on the NHWC feature map. */
 int dim_fc_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream);

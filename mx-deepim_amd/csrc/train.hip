@@ -346,6 +346,20 @@ __global__ void sgd_momentum_kernel(float* __restrict__ w, const float* __restri
   w[i] += m;
 }
 
+// mx.optimizer.Adam (adam_update): g' = rescale*g + wd*w; mean = b1*mean + (1-b1)*g'; var = b2*var + (1-b2)*g'^2;
+// w -= lr_t * mean / (sqrt(var) + eps), with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller
+__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ mean, float* __restrict__ var, long n,
+                            float lr_t, float beta1, float beta2, float eps, float wd, float rescale) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = rescale * g[i] + wd * w[i];
+  float m = beta1 * mean[i] + (1.f - beta1) * gi;
+  float v = beta2 * var[i] + (1.f - beta2) * gi * gi;
+  mean[i] = m;
+  var[i] = v;
+  w[i] -= lr_t * m / (sqrtf(v) + eps);
+}
+
 }  // namespace dim
 
 using namespace dim;
@@ -488,6 +502,15 @@ int dim_sgd_momentum(float* w, const float* grad, float* mom, long n, float lr, 
   hipLaunchKernelGGL(sgd_momentum_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), w, grad, mom, n, lr, momentum, wd,
                      rescale_grad);
   return check_launch("sgd_momentum");
+}
+
+int dim_adam(float* w, const float* grad, float* mean, float* var, long n, float lr_t, float beta1, float beta2, float epsilon, float wd,
+             float rescale_grad, void* stream) {
+  if (n == 0) return DIM_OK;
+  DIM_REQUIRE(w && grad && mean && var, "null pointer");
+  hipLaunchKernelGGL(adam_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), w, grad, mean, var, n, lr_t, beta1, beta2, epsilon,
+                     wd, rescale_grad);
+  return check_launch("adam");
 }
 
 }  // extern "C"

@@ -39,14 +39,20 @@ class MutableModule(object):
         sym = deepIM_flownet()
         shapes = sym.infer_param_shapes(cfg)
         # ---- flat master parameters / gradients / momentum, MXNet layouts, in the shape table's order
-        self.names = list(shapes.keys())
+        # grouped so that one optimizer launch covers a whole class: [weights (wd) | biases (wd_mult 0) | frozen (lr_mult 0)]
+        keys = list(shapes.keys())
+        self.names = ([n for n in keys if n not in FROZEN and n.endswith("_weight")] + [n for n in keys if n not in FROZEN and not n.endswith("_weight")]
+                      + [n for n in keys if n in FROZEN])
         self.shapes = shapes
         sizes = [int(np.prod(shapes[n])) for n in self.names]
         total = sum(sizes)
         self.flat_w = torch.empty(total, dtype=torch.float32, device=d)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=d)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=d)
+        self.flat_v = None  # second Adam state, allocated on first use
         self.w, self.g, self.m = {}, {}, {}
+        self.n_weight = sum(sz for n, sz in zip(self.names, sizes) if n not in FROZEN and n.endswith("_weight"))
+        self.n_bias = sum(sz for n, sz in zip(self.names, sizes) if n not in FROZEN and not n.endswith("_weight"))
         off = 0
         for n, sz in zip(self.names, sizes):
             self.w[n] = self.flat_w[off:off + sz].view(shapes[n])
@@ -257,16 +263,58 @@ class MutableModule(object):
 
     # ------------------------------------------------------------------------------------------------------------
     def update(self, lr):
-        """kvstore push/pull + SGD (module.py:666-688): sum gradients over ranks, then the same update on every rank."""
+        """kvstore push/pull + optimizer (module.py:666-688; train.py:338-385): sum gradients over ranks, then the same update on
+        every rank.  Two launches: weights (weight decay) and biases (MXNet sets wd_mult 0 for *_bias); frozen tensors are skipped.
+        `lr` is this update's learning rate (a WarmupMultiFactorScheduler value)."""
         cfg = self.cfg
         allreduce_sum_(self.flat_g, group=self.pg)
-        mom, wd = float(cfg.TRAIN.momentum), float(cfg.TRAIN.wd)
+        self.num_update += 1
+        nw, nb = self.n_weight, self.n_bias
+        seg = ((0, nw, True), (nw, nw + nb, False))
+        if str(cfg.TRAIN.optimizer).lower() == "adam":
+            # mx.optimizer.Adam defaults (train.py:339 passes only learning_rate): beta1 .9, beta2 .999, eps 1e-8, wd 0
+            if self.flat_v is None:
+                self.flat_v = torch.zeros_like(self.flat_m)
+            b1, b2, t = 0.9, 0.999, self.num_update
+            lr_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+            for a, b, _ in seg:
+                ops.adam(self.flat_w[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], lr_t, b1, b2, 1e-8, 0.0, 1.0)
+        else:
+            mom, wd = float(cfg.TRAIN.momentum), float(cfg.TRAIN.wd)
+            for a, b, decay in seg:
+                ops.sgd_momentum(self.flat_w[a:b], self.flat_g[a:b], self.flat_m[a:b], lr, mom, wd if decay else 0.0, 1.0)
+        self.repack(forward=True)
+
+    # optimizer state checkpoint (the reference pickles MXNet updater states: module_checkpoint(save_optimizer_states=True),
+    # train.py:314-316 -- that pickle needs mxnet to read, so the state travels as a plain .npz here)
+    def save_optimizer_states(self, fname):
+        st = {"num_update": np.int64(self.num_update)}
         for n in self.names:
             if n in FROZEN:
                 continue
-            ops.sgd_momentum(self.w[n], self.g[n], self.m[n], lr, mom, wd if n.endswith("_weight") else 0.0, 1.0)
-        self.num_update += 1
-        self.repack(forward=True)
+            st["mom:" + n] = self.m[n].cpu().numpy()
+        if self.flat_v is not None:
+            off = 0
+            for n in self.names:
+                sz = self.w[n].numel()
+                if n not in FROZEN:
+                    st["var:" + n] = self.flat_v[off:off + sz].view(self.shapes[n]).cpu().numpy()
+                off += sz
+        np.savez(fname, **st)
+
+    def load_optimizer_states(self, fname):
+        st = np.load(fname)
+        self.num_update = int(st["num_update"])
+        off = 0
+        for n in self.names:
+            sz = self.w[n].numel()
+            if "mom:" + n in st:
+                self.m[n].copy_(torch.as_tensor(st["mom:" + n]))
+            if "var:" + n in st:
+                if self.flat_v is None:
+                    self.flat_v = torch.zeros_like(self.flat_m)
+                self.flat_v[off:off + sz].view(self.shapes[n]).copy_(torch.as_tensor(st["var:" + n]))
+            off += sz
 
     def get_params(self):
         return {n: self.w[n].cpu().numpy() for n in self.names}
@@ -284,7 +332,10 @@ def fit_batch(module, data_batch, batch_updater, lr):
     for iter_idx in range(n_iter):
         preds = module.forward_backward(data_batch)
         outs.append({"rot_est_norm": preds["rot_est_norm"].clone(), "trans_est": preds["trans_est"].clone(),
-                     "loss_sums": module.loss_sums.clone()})
+                     "loss_sums": module.loss_sums.clone(),
+                     # what deepim/core/metric.py reads (Flow_L2Loss, PointMatchingLoss, MaskLoss)
+                     "flow_loss_sum": module.loss_sums[0].clone(), "point_matching_loss_sum": module.loss_sums[1].clone(),
+                     "mask_prob": module.mask_prob, "mask_gt": module.zoom_mask_gt})
         module.update(lr)
         if iter_idx != n_iter - 1:
             data_batch = batch_updater.forward(data_batch, preds, cfg)

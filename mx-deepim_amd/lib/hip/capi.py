@@ -59,6 +59,7 @@ SIGNATURES = {
     "dim_conv_small_cout_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_deconv4x4s2_tiny_bwd": (I, [P, I, P, I, I, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dim_sgd_momentum": (I, [P, P, P, L, F, F, F, F, P]),
+    "dim_adam": (I, [P, P, P, P, L, F, F, F, F, F, F, P]),
     "dim_deconv4x4s2_packed_weight_floats": (L, [I, I]),
     "dim_deconv4x4s2_pack_weight": (I, [P, P, I, I, P]),
     "dim_deconv4x4s2_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, P]),

@@ -416,6 +416,11 @@ def sgd_momentum(w, grad, mom, lr, momentum, wd, rescale_grad=1.0):
                                  float(rescale_grad), current_stream()))
 
 
+def adam(w, grad, mean, var, lr_t, beta1=0.9, beta2=0.999, epsilon=1e-8, wd=0.0, rescale_grad=1.0):
+    check(lib().dim_adam(dptr(w, f32), dptr(grad, f32), dptr(mean, f32), dptr(var, f32), w.numel(), float(lr_t), float(beta1), float(beta2),
+                         float(epsilon), float(wd), float(rescale_grad), current_stream()))
+
+
 def pose_to_KT(pose_src, pose_tgt, K, out=None):
     B = pose_src.shape[0]
     out = out if out is not None else _new((B, 3, 4), pose_src)

@@ -1,0 +1,67 @@
+"""Learning-rate schedule of the reference training driver (lib/utils/lr_scheduler.py:45-70, deepim/train.py:318-332).
+
+`WarmupMultiFactorScheduler` keeps MXNet's LRScheduler calling convention: the optimizer sets `base_lr` and calls the
+object with `num_update` (the number of optimizer steps so far) to get that step's learning rate."""
+from __future__ import print_function, division
+
+import logging
+
+
+class LRScheduler(object):
+    """mxnet.lr_scheduler.LRScheduler: holds base_lr (the optimizer overwrites it with its learning_rate)."""
+
+    def __init__(self, base_lr=0.01):
+        self.base_lr = base_lr
+
+    def __call__(self, num_update):
+        raise NotImplementedError("must override this")
+
+
+class WarmupMultiFactorScheduler(LRScheduler):
+    """base_lr * factor^(number of entries of `step` that num_update has passed); warmup_lr for the first warmup_step updates."""
+
+    def __init__(self, step, factor=1, warmup=False, warmup_lr=0, warmup_step=0):
+        super(WarmupMultiFactorScheduler, self).__init__()
+        assert isinstance(step, list) and len(step) >= 1
+        for i, _step in enumerate(step):
+            if i != 0 and step[i] <= step[i - 1]:
+                raise ValueError("Schedule step must be an increasing integer list")
+            if _step < 1:
+                raise ValueError("Schedule step must be greater or equal than 1 round")
+        if factor > 1.0:
+            raise ValueError("Factor must be no more than 1 to make lr reduce")
+        self.step = step
+        self.cur_step_ind = 0
+        self.factor = factor
+        self.count = 0
+        self.warmup = warmup
+        self.warmup_lr = warmup_lr
+        self.warmup_step = warmup_step
+
+    def __call__(self, num_update):
+        # `while`, not `if`: a resumed run may jump over several steps at once (reference :57)
+        if self.warmup and num_update < self.warmup_step:
+            return self.warmup_lr
+        while self.cur_step_ind <= len(self.step) - 1:
+            if num_update > self.step[self.cur_step_ind]:
+                self.count = self.step[self.cur_step_ind]
+                self.cur_step_ind += 1
+                self.base_lr *= self.factor
+                logging.info("Update[%d]: Change learning rate to %0.5e", num_update, self.base_lr)
+            else:
+                return self.base_lr
+        return self.base_lr
+
+
+def build_lr_schedule(base_lr, lr_step, begin_epoch, num_pairs, batch_size, warmup=False, warmup_lr=0, warmup_step=0, lr_factor=0.1):
+    """deepim/train.py:318-332: epochs already done (resume at begin_epoch) are folded into the starting lr, the rest become
+    iteration thresholds.  -> (lr, scheduler) with scheduler.base_lr = lr like mx.optimizer does at creation."""
+    lr_epoch = [float(epoch) for epoch in str(lr_step).split(",")]
+    lr_epoch_diff = [epoch - begin_epoch for epoch in lr_epoch if epoch > begin_epoch]
+    lr = base_lr * (lr_factor ** (len(lr_epoch) - len(lr_epoch_diff)))
+    lr_iters = [int(epoch * num_pairs / batch_size) for epoch in lr_epoch_diff]
+    if not lr_iters:  # every step already passed: constant lr (MXNet's fit would get an empty list and the assert above)
+        lr_iters = [1 << 62]
+    sched = WarmupMultiFactorScheduler(lr_iters, lr_factor, warmup, warmup_lr, warmup_step)
+    sched.base_lr = lr
+    return lr, sched

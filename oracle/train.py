@@ -109,3 +109,19 @@ def sgd_step(params, grads, moms, lr, momentum, wd):
         moms[k] = m
         params[k] = (w + m).astype(np.float32)
     return params, moms
+
+
+def adam_step(params, grads, means, variances, t, lr, beta1=0.9, beta2=0.999, epsilon=1e-8, wd=0.0, rescale_grad=1.0):
+    """mx.optimizer.Adam.update + adam_update op (the reference selects it with TRAIN.optimizer == 'adam', deepim/train.py:338-375):
+    lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t); g' = rescale*g + wd*w; mean, var EMAs; w -= lr_t*mean/(sqrt(var)+eps).  float32 like the op."""
+    lr_t = np.float32(lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
+    b1, b2 = np.float32(beta1), np.float32(beta2)
+    for k in params:
+        if k in ("upsampling_weight", "mask_upsampling_weight"):
+            continue
+        w = params[k].astype(np.float32)
+        g = np.float32(rescale_grad) * grads[k].astype(np.float32) + np.float32(wd) * w
+        means[k] = b1 * means[k].astype(np.float32) + (np.float32(1) - b1) * g
+        variances[k] = b2 * variances[k].astype(np.float32) + (np.float32(1) - b2) * g * g
+        params[k] = (w - lr_t * means[k] / (np.sqrt(variances[k]) + np.float32(epsilon))).astype(np.float32)
+    return params, means, variances

@@ -133,3 +133,46 @@ def test_batch_updater_and_fit_batch_vs_oracle(setup):
     assert torch.isfinite(mod.flat_w).all() and (mod.flat_w - before).abs().max() > 0
     assert not torch.equal(batch["src_pose"].cpu(), torch.as_tensor(bl["src_pose"]))  # src_pose advanced by the first iteration
     cfg.network.TRAIN_ITER_SIZE = 4
+
+
+def test_adam_two_steps_and_optimizer_state_checkpoint(setup, tmp_path):
+    """TRAIN.optimizer == 'adam' (train.py:338-375): two updates on the module's own gradients vs the float32 numpy restatement of
+    mx.optimizer.Adam, then an optimizer-state save / load round trip into a fresh module."""
+    from deepim.core.module import MutableModule
+
+    cfg, params, scene = setup
+    B = 2
+    batch = {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in scene["blobs"].items()}
+    old = cfg.TRAIN.optimizer
+    cfg.TRAIN.optimizer = "adam"
+    try:
+        mod = MutableModule(cfg, params, B)
+        p_ref = {k: v.copy() for k, v in params.items()}
+        means = {k: np.zeros(v.shape, np.float32) for k, v in params.items()}
+        var = {k: np.zeros(v.shape, np.float32) for k, v in params.items()}
+        for t in (1, 2):
+            mod.forward_backward(batch)
+            g = mod.get_grads()
+            p_ref, means, var = otrain.adam_step(p_ref, g, means, var, t, 1e-4)
+            mod.update(1e-4)
+            new = mod.get_params()
+            for k in p_ref:
+                if k in ("upsampling_weight", "mask_upsampling_weight"):
+                    np.testing.assert_array_equal(new[k], params[k])  # frozen
+                    continue
+                # |step| ~ lr; a few ulp of the f32 division / sqrt on top
+                assert np.abs(new[k] - p_ref[k]).max() <= 2e-3 * 1e-4 + 1e-9, (k, t)
+            # the oracle continues from the module's parameters so that step 2 sees identical gradients
+            p_ref = {k: v.copy() for k, v in new.items()}
+        f = str(tmp_path / "opt.npz")
+        mod.save_optimizer_states(f)
+        mod2 = MutableModule(cfg, mod.get_params(), B)
+        mod2.load_optimizer_states(f)
+        assert mod2.num_update == 2
+        np.testing.assert_array_equal(mod2.flat_m.cpu().numpy(), mod.flat_m.cpu().numpy())
+        np.testing.assert_array_equal(mod2.flat_v.cpu().numpy(), mod.flat_v.cpu().numpy())
+        mod.forward_backward(batch); mod.update(1e-4)
+        mod2.forward_backward(batch); mod2.update(1e-4)
+        np.testing.assert_array_equal(mod2.flat_w.cpu().numpy(), mod.flat_w.cpu().numpy())
+    finally:
+        cfg.TRAIN.optimizer = old
