@@ -140,3 +140,44 @@ class Refiner(object):
         else:
             self._loop()
         return self.poses_iter
+
+
+def pred_eval(config, refiner, batches, evaluator, result_file=None, logger=None):
+    """The outer loop of the reference's pred_eval (deepim/core/tester.py:418-676) on device-resident batches.
+
+    batches: iterable of dicts with the blobs Refiner.load takes plus "pose_observed" (B,3,4) ground truth.
+    Collects all_poses_est[cls][iter] / all_poses_gt[cls][iter] and the rotation / translation errors per iteration exactly as
+    the reference does (:497-560), writes the result cache [all_rot_err, all_trans_err, all_poses_est, all_poses_gt] with
+    pickle protocol 2 (:650-654) and runs evaluate_pose / evaluate_pose_add / evaluate_pose_arp_2d (:664-673).
+    evaluator: lib.dataset.evaluation.PoseEvaluator.  Returns the three result dicts."""
+    import pickle
+
+    from lib.utils.pose_error import calc_rt_dist_m
+
+    n_cls, n_it = len(evaluator.classes), int(config.TEST.test_iter)
+    all_rot_err = [[[] for _ in range(n_it)] for _ in range(n_cls)]
+    all_trans_err = [[[] for _ in range(n_it)] for _ in range(n_cls)]
+    all_poses_est = [[[] for _ in range(n_it)] for _ in range(n_cls)]
+    all_poses_gt = [[[] for _ in range(n_it)] for _ in range(n_cls)]
+    for batch in batches:
+        refiner.load(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"], batch["src_pose"],
+                     batch["class_index"])
+        poses = refiner.refine().cpu().numpy().astype(np.float64)     # ONE device->host copy per batch: (iter, B, 3, 4)
+        cls = torch.as_tensor(batch["class_index"]).cpu().numpy().astype(int)
+        gt = torch.as_tensor(batch["pose_observed"]).cpu().numpy().astype(np.float64)
+        for b in range(poses.shape[1]):
+            for it in range(n_it):
+                r_dist, t_dist = calc_rt_dist_m(poses[it, b], gt[b])
+                all_poses_est[cls[b]][it].append(poses[it, b])
+                all_poses_gt[cls[b]][it].append(gt[b])
+                all_rot_err[cls[b]][it].append(r_dist)
+                all_trans_err[cls[b]][it].append(t_dist)
+    if result_file:
+        with open(result_file, "wb") as f:
+            pickle.dump([np.array(all_rot_err, dtype=object), np.array(all_trans_err, dtype=object), all_poses_est, all_poses_gt], f,
+                        protocol=2)
+    out = {"pose": evaluator.evaluate_pose(config, all_poses_est, all_poses_gt, logger)}
+    out["add"] = evaluator.evaluate_pose_add(config, all_poses_est, all_poses_gt, output_dir=None, logger=logger)
+    out["arp_2d"] = evaluator.evaluate_pose_arp_2d(config, all_poses_est, all_poses_gt, output_dir=None, logger=logger)
+    out["all_rot_err"], out["all_trans_err"] = all_rot_err, all_trans_err
+    return out

@@ -6,7 +6,7 @@ only inputs and expected outputs are stored.
 
 Modules imported from /root/reference:
   lib/pair_matching/RT_transform.py  (numpy-2 alias shim for its module-level np.float uses, :246-247)
-  lib/pair_matching/flow.py (calc_flow), lib/utils/pose_error.py (add, adi),
+  lib/pair_matching/flow.py (calc_flow), lib/utils/pose_error.py (add, adi, arp_2d, re, te),
   lib/utils/get_min_rect.py, lib/utils/projection.py (se3_mul, se3_inverse)
 """
 import os
@@ -21,7 +21,7 @@ sys.path.insert(0, "/root/reference")
 
 from lib.pair_matching import RT_transform as RT  # noqa: E402
 from lib.pair_matching.flow import calc_flow  # noqa: E402
-from lib.utils.pose_error import add, adi  # noqa: E402
+from lib.utils.pose_error import add, adi, arp_2d, re, te  # noqa: E402
 from lib.utils.get_min_rect import get_min_rect  # noqa: E402
 from lib.utils.projection import se3_inverse, se3_mul  # noqa: E402
 
@@ -123,7 +123,7 @@ def flow_vectors():
 def pose_error_vectors():
     rng = np.random.default_rng(11)
     pts = rng.normal(size=(500, 3)) * 0.05
-    pe, pg, a, s = [], [], [], []
+    pe, pg, a, s, r2, rr, tt = [], [], [], [], [], [], []
     for i in range(16):
         g = rand_pose(rng)
         e = g.copy()
@@ -133,8 +133,11 @@ def pose_error_vectors():
         pe.append(e); pg.append(g)
         a.append(add(e[:, :3], e[:, 3], g[:, :3], g[:, 3], pts))
         s.append(adi(e[:, :3], e[:, 3], g[:, :3], g[:, 3], pts))
+        r2.append(arp_2d(e[:, :3], e[:, 3], g[:, :3], g[:, 3], pts, K))
+        rr.append(re(e[:, :3], g[:, :3]))
+        tt.append(te(e[:, 3], g[:, 3]))
     np.savez_compressed(os.path.join(HERE, "pose_error_golden.npz"), pts=pts, pose_est=np.array(pe), pose_gt=np.array(pg),
-                        add=np.array(a), adi=np.array(s))
+                        add=np.array(a), adi=np.array(s), arp_2d=np.array(r2), re=np.array(rr), te=np.array(tt), K=K)
 
 
 def min_rect_vectors():

@@ -201,3 +201,42 @@ def test_refine_modelnet_lit_vs_oracle(hip_lib):
     img = ref.batch["image_rendered"].cpu().numpy()
     on = ref.batch["mask_rendered"].cpu().numpy()[:, 0] > 0
     assert img[:, 0][on].std() > 2.0
+
+
+def test_pred_eval_collects_and_scores(setup, tmp_path):
+    """outer loop of pred_eval: result layout [cls][iter], result pickle, and the ADD(-S) clause of the metric -- our final poses
+    scored against the oracle's final poses as 'ground truth' are within 0.02 d for every pair."""
+    import pickle
+
+    from deepim.core.tester import Predictor, Refiner, pred_eval
+    from lib.dataset.evaluation import PoseEvaluator
+    from lib.render_hip.render_py_multi import Render_Py
+
+    _, params, scene = setup
+    cfg = make_test_config(test_iter=4)  # the config object is a process-wide singleton that other tests re-shape
+    B = 2
+    pred = Predictor(cfg, params, B)
+    rm = Render_Py(None, cfg.dataset.class_name, scene["K"], meshes=scene["models"])
+    ref = Refiner(cfg, pred, rm, B, capture_graph=True)
+    bl = scene["blobs"]
+    z3, o3 = np.zeros(3), np.ones(3)
+    oracle_final = []
+    for b in range(B):
+        blobs_b = {k: bl[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
+        o_poses, _ = orefine.refine_pair(params, scene["models"][int(bl["class_index"][b])], blobs_b, scene["K"], cfg.network.PIXEL_MEANS,
+                                         z3, o3, "CAMERA", test_iter=4)
+        oracle_final.append(o_poses[-1])
+    batch = dict(bl)
+    batch["pose_observed"] = np.array(oracle_final, dtype=np.float32)
+    pts = scene["models"][0][0].astype(np.float64)
+    diam = float(np.linalg.norm(pts.max(0) - pts.min(0)))
+    ev = PoseEvaluator(cfg.dataset.class_name, {cfg.dataset.class_name[0]: pts}, {cfg.dataset.class_name[0]: diam})
+    f = str(tmp_path / "results.pkl")
+    out = pred_eval(cfg, ref, [batch, batch], ev, result_file=f)
+    assert out["add"]["count_all"][0] == 4
+    last = out["add"]["per_class"][(cfg.dataset.class_name[0], 3)]
+    assert last["0.02"] == 100.0 and last["0.05"] == 100.0 and last["0.10"] == 100.0
+    assert out["arp_2d"]["per_class"][(cfg.dataset.class_name[0], 3)]["2"] == 100.0
+    assert max(out["all_rot_err"][0][3]) < 0.1 and max(out["all_trans_err"][0][3]) < 1e-3
+    rot_err, trans_err, poses_est, poses_gt = pickle.load(open(f, "rb"))
+    assert len(poses_est) == 1 and len(poses_est[0]) == 4 and len(poses_est[0][0]) == 4 and poses_est[0][0][0].shape == (3, 4)
