@@ -167,9 +167,10 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(LitArgs lit, const 
   bool in_img = x < W;
   if (in_img) {
     unsigned long long key = zbuf[(long)b * plane + (long)y * W + x];
-    if (key != 0xFFFFFFFFFFFFFFFFull) {
-      const int cls = class_index[b];
-      const int* mt = mesh_table + 4 * cls;
+    const int cls = class_index[b];
+    const int* mt = mesh_table + 4 * cls;
+    // (the face-id range test costs one compare and keeps a corrupt key from ever turning into a wild read)
+    if (key != 0xFFFFFFFFFFFFFFFFull && (unsigned)(key & 0xFFFFFFFFu) < (unsigned)mt[3]) {
       const int f = (int)(unsigned)(key & 0xFFFFFFFFu);
       z = __uint_as_float((unsigned)(key >> 32));
       const int* face = faces + 3 * (long)(mt[2] + f);
@@ -322,6 +323,13 @@ __global__ void modelnet_light_kernel(const float* __restrict__ poses, float dx,
   light_pos[3 * b + 2] = (float)(0.5 * (double)dz - (double)P[11]);
 }
 
+__global__ __launch_bounds__(256) void zbuf_clear_kernel(unsigned long long* __restrict__ zbuf, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (i + k < n) zbuf[i + k] = 0xFFFFFFFFFFFFFFFFull;
+}
+
 __global__ void bbox_init2_kernel(int* bbox, int n, int H, int W) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
@@ -352,8 +360,10 @@ static int raster_render_impl(const float* verts, const float* normals, const fl
   hipStream_t st = as_stream(stream);
   unsigned long long* zbuf = reinterpret_cast<unsigned long long*>(workspace);
   float* scr = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (long)B * H * W * 8);
-  hipError_t e = hipMemsetAsync(zbuf, 0xFF, (size_t)B * H * W * 8, st);
-  if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "zbuf memset: %s", hipGetErrorString(e));
+  // z-buffer clear as a KERNEL, not hipMemsetAsync: inside a captured hipGraph the memset node was seen overlapping the
+  // resolve pass of the same replay (keys half overwritten -> face ids out of range -> memory fault on the 2nd replay)
+  const long nkeys = (long)B * H * W;
+  hipLaunchKernelGGL(zbuf_clear_kernel, dim3(ceil_div(nkeys, 256 * 4)), dim3(256), 0, st, zbuf, nkeys);
   hipLaunchKernelGGL(raster_vertex_kernel, dim3(ceil_div(vmax, 256), B), dim3(256), 0, st, verts, mesh_table, class_index, poses,
                      K9[0], K9[4], K9[2], K9[5], vmax, scr);
   hipLaunchKernelGGL(raster_tri_kernel, dim3(ceil_div(fmax, 256), B), dim3(256), 0, st, faces, mesh_table, class_index, scr, vmax, H,
