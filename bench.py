@@ -167,8 +167,15 @@ def main():
         info = net.layer_info[name]
         for tag, e0, e1 in evs:
             if tag == "conv":  # the symbol rocprofv3 --kernel-trace reports for this launch
-                kname = "dim::conv_fwd_kernel<{}, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
-                flops, nbytes = info["flops"], info["min_bytes"]
+                if info.get("winograd"):  # batched GEMM of the Winograd path: the multiply-adds that launch really executes
+                    kname = "dim::conv_fwd_kernel<{}, false>".format(TILE_SYM[info["wino_tile"]])
+                    tiles = info["wino_flops"] / (2.0 * 16 * info["cin"] * info["N"])
+                    flops, nbytes = info["wino_flops"], 4.0 * 16 * (tiles * info["cin"] + info["cin"] * info["N"] + tiles * info["N"])
+                else:
+                    kname = "dim::conv_fwd_kernel<{}, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
+                    flops, nbytes = info["flops"], info["min_bytes"]
+            elif tag in ("wino_in", "wino_out"):
+                kname, flops, nbytes = "dim::wino_input_kernel" if tag == "wino_in" else "dim::wino_output_kernel", 0.0, 0.0
             else:
                 kname, flops, nbytes = "dim::splitk_reduce_kernel", 0.0, 0.0
             k = per_kernel.setdefault(kname, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "layers": []})

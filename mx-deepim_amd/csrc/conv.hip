@@ -41,6 +41,7 @@ struct ConvArgs {
   int accumulate;  // out += v (final pass only)
   unsigned x_bytes, w_bytes;  // extents of x / w for the buffer descriptors (loads past them return 0)
   int xcd_chunk;   // > 0: workgroup id -> tile remap that keeps consecutive tiles on one XCD (see conv_fwd_kernel)
+  long bx, bw, by; // batched launch (gridDim.y > 1): element strides of x / w / y between the problems (Winograd: 16 GEMMs)
 };
 
 template <int BM, int BN, int WM, int WN, bool CIN8>
@@ -101,8 +102,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   // zeros: one v_cndmask on a 32-bit offset, no pointer select, no exec juggling, and -- unlike the flat loads a pointer
   // select compiles to -- nothing that counts on lgkmcnt next to the LDS fragment reads); the weights take the chunk as
   // a scalar offset, so their per-lane offset is loop-invariant.
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const float* xb = a.x + (long)blockIdx.y * a.bx;  // blockIdx.y = problem of a batched launch (0 otherwise)
+  const float* wb = a.w + (long)blockIdx.y * a.bw;
+  float* yb = a.y + (long)blockIdx.y * a.by;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wb), 0, a.w_bytes, 0x00020000);
   const int w_voff = ((n0 + srow) * BK + q * 4) * 4;  // packed [chunk][Cout][32]
   const int wchunk_bytes = a.Cout * BK * 4;
 
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   const bool acc_out = final && a.accumulate;
   const int mrow = m0 + wm * (BM / WM) + 4 * khalf;
   if (!final || a.dense_out) {
-    float* out = (final ? a.y + a.out_coff : a.y + (long)split * a.M * a.Cout) + (long)mrow * ldc + ncol;
+    float* out = (final ? yb + a.out_coff : yb + (long)split * a.M * a.Cout) + (long)mrow * ldc + ncol;
     if (m0 + BM <= a.M) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
           int n = t / a.Ho;
           int oy = ho * a.osy + a.ooy, ox = wo * a.osx + a.oox;
           if ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW) {
-            float* o = a.y + a.out_coff + ((long)(n * a.OH + oy) * a.OW + ox) * ldc + ncol;
+            float* o = yb + a.out_coff + ((long)(n * a.OH + oy) * a.OW + ox) * ldc + ncol;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
               float v = acc[i][j][r] + bv[j];
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict_
 }
 
 template <int BM, int BN, int WM, int WN, bool CIN8>
-static int launch_conv(const ConvArgs& a, int splits, hipStream_t st) {
+static int launch_conv(const ConvArgs& a, int splits, hipStream_t st, int batch = 1) {
   constexpr size_t lds = (size_t)2 * (BM + BN) * (32 + 4) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -561,7 +565,7 @@ static int launch_conv(const ConvArgs& a, int splits, hipStream_t st) {
   ConvArgs b = a;
   static const int xcd_mode = getenv("DIM_CONV_XCD") ? atoi(getenv("DIM_CONV_XCD")) : 0;  // experiment switch
   b.xcd_chunk = (xcd_mode > 0 && tiles % 8 == 0 && tiles >= xcd_mode) ? tiles / 8 : 0;
-  dim3 grid(tiles, 1, splits);
+  dim3 grid(tiles, batch, splits);
   hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, CIN8>), grid, dim3(WM * WN * 64), lds, st, b);
   return check_launch("conv_fwd");
 }
@@ -630,6 +634,8 @@ struct ConvEx {
   int accumulate = 0;    // out += result (skip-connection gradients)
   int pad_w = -1;        // >= 0: horizontal padding differs from `pad` (sub-pixel phases of a strided dgrad)
   int Ho = 0, Wo = 0;    // > 0: explicit output grid instead of floor((H+2p-k)/s)+1 (asymmetric padding)
+  int batch = 1;         // > 1: `batch` independent problems, strides below (elements)
+  long bx = 0, bw = 0, by = 0;
 };
 
 static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
@@ -674,6 +680,9 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   DIM_REQUIRE(splits == 1 || !ex || (a.dense_out && a.out_cstride == Cout && a.out_coff == 0),
               "split-K writes a dense [M][Cout] result: not available with a strided / scattered output");
   a.y = splits > 1 ? workspace : y;
+  const int batch = ex ? ex->batch : 1;
+  a.bx = ex ? ex->bx : 0; a.bw = ex ? ex->bw : 0; a.by = ex ? ex->by : 0;
+  DIM_REQUIRE(batch == 1 || splits == 1, "batched launch does not combine with split-K");
   a.slope = slope;
   a.has_bias = bias != nullptr;
   hipStream_t st = as_stream(stream);
@@ -684,15 +693,16 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   if (Cin == 8) {
     DIM_REQUIRE(tile != 1 || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
     DIM_REQUIRE(tile != 4, "tile 4 (128x128, 8 waves) is not built for the 8-channel layer");
+    DIM_REQUIRE(batch == 1, "batched launch is not built for the 8-channel layer");
     if (tile == 1) rc = launch_conv<128, 128, 2, 2, true>(a, splits, st);
     else if (tile == 2) rc = launch_conv<128, 64, 2, 2, true>(a, splits, st);
     else rc = launch_conv<64, 64, 2, 2, true>(a, splits, st);
   } else {
     DIM_REQUIRE((tile != 1 && tile != 4) || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
-    if (tile == 4) rc = launch_conv<128, 128, 2, 4, false>(a, splits, st);
-    else if (tile == 1) rc = launch_conv<128, 128, 2, 2, false>(a, splits, st);
-    else if (tile == 2) rc = launch_conv<128, 64, 2, 2, false>(a, splits, st);
-    else rc = launch_conv<64, 64, 2, 2, false>(a, splits, st);
+    if (tile == 4) rc = launch_conv<128, 128, 2, 4, false>(a, splits, st, batch);
+    else if (tile == 1) rc = launch_conv<128, 128, 2, 2, false>(a, splits, st, batch);
+    else if (tile == 2) rc = launch_conv<128, 64, 2, 2, false>(a, splits, st, batch);
+    else rc = launch_conv<64, 64, 2, 2, false>(a, splits, st, batch);
   }
   if (rc != DIM_OK) return rc;
   if (splits > 1 && !partial_only) return dim_splitk_reduce(workspace, bias, y, (long)a.M, Cout, splits, slope, stream);
@@ -920,6 +930,201 @@ int dim_pose_head_fwd(const float* fc6, const float* fc7_w, const float* fc7_b, 
   hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(256), 0, as_stream(stream), fc6, fc7_w, fc7_b, rot_w, rot_b, trans_w,
                      trans_b, zoom_factor, se3, fc7_out);
   return check_launch("pose_head");
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ Winograd F(2x2, 3x3)
+// 3x3 / stride 1 / pad 1 layers (conv3_1, conv4_1, conv5_1, conv6_1 of deepIM_flownet.py:103-191) as
+//   V = B^T d B  (input tiles 4x4, stride 2)  ->  16 independent GEMMs  M_k = V_k (T x Cin) * U_k (Cin x Cout)  ->  Y = A^T M A
+// 2.25x fewer multiply-adds than the direct form; the GEMMs run as ONE batched launch of conv_fwd_kernel (a 1x1 "convolution"
+// over T tile-pixels, blockIdx.y = k).  Transforms are exact in the sense of using only +,- on the data (B, A have entries
+// 0, +-1); the weight transform G (entries 1, 1/2) is applied once at pack time.  f32 throughout.
+namespace dim {
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// V[k][t][c]: thread = (tile t, channel quad)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C,
+                                                         int in_cstride, int th, int tw, FastDiv div_cq, FastDiv div_tw, FastDiv div_th) {
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  const unsigned CQ = C >> 2;
+  const unsigned T = (unsigned)N * th * tw;
+  const unsigned t = fastdiv(idx, div_cq);
+  if (t >= T) return;
+  const unsigned cq = idx - t * CQ;
+  const unsigned r = fastdiv(t, div_tw);
+  const unsigned tx = t - r * tw;
+  const unsigned n = fastdiv(r, div_th);
+  const unsigned ty = r - n * th;
+  const int y0 = 2 * (int)ty - 1, x0 = 2 * (int)tx - 1;
+  const float* base = x + (long)n * H * W * in_cstride + cq * 4;
+  float4 d[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int yy = y0 + a, xx = x0 + b;
+      d[a][b] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                    ? *reinterpret_cast<const float4*>(base + ((long)yy * W + xx) * in_cstride)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  float4 tmp[4][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {  // B^T d
+    tmp[0][b] = f4sub(d[0][b], d[2][b]);
+    tmp[1][b] = f4add(d[1][b], d[2][b]);
+    tmp[2][b] = f4sub(d[2][b], d[1][b]);
+    tmp[3][b] = f4sub(d[1][b], d[3][b]);
+  }
+  const long plane = (long)T * C;
+  float* out = V + (long)t * C + cq * 4;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {  // (.) B
+    *reinterpret_cast<float4*>(out + (a * 4 + 0) * plane) = f4sub(tmp[a][0], tmp[a][2]);
+    *reinterpret_cast<float4*>(out + (a * 4 + 1) * plane) = f4add(tmp[a][1], tmp[a][2]);
+    *reinterpret_cast<float4*>(out + (a * 4 + 2) * plane) = f4sub(tmp[a][2], tmp[a][1]);
+    *reinterpret_cast<float4*>(out + (a * 4 + 3) * plane) = f4sub(tmp[a][1], tmp[a][3]);
+  }
+}
+
+// Y = A^T M A + bias, LeakyReLU; thread = (tile t, output-channel quad); writes the 2x2 outputs that fall inside H x W
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y,
+                                                          int N, int H, int W, int C, int out_cstride, int out_coff, int th, int tw,
+                                                          float slope, FastDiv div_cq, FastDiv div_tw, FastDiv div_th) {
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  const unsigned CQ = C >> 2;
+  const unsigned T = (unsigned)N * th * tw;
+  const unsigned t = fastdiv(idx, div_cq);
+  if (t >= T) return;
+  const unsigned cq = idx - t * CQ;
+  const unsigned r = fastdiv(t, div_tw);
+  const unsigned tx = t - r * tw;
+  const unsigned n = fastdiv(r, div_th);
+  const unsigned ty = r - n * th;
+  const long plane = (long)T * C;
+  const float* in = M + (long)t * C + cq * 4;
+  float4 m[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) m[a][b] = *reinterpret_cast<const float4*>(in + (a * 4 + b) * plane);
+  float4 r0[4], r1[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {  // A^T m
+    r0[b] = f4add(f4add(m[0][b], m[1][b]), m[2][b]);
+    r1[b] = f4sub(f4sub(m[1][b], m[2][b]), m[3][b]);
+  }
+  float4 o[2][2];
+  o[0][0] = f4add(f4add(r0[0], r0[1]), r0[2]);
+  o[0][1] = f4sub(f4sub(r0[1], r0[2]), r0[3]);
+  o[1][0] = f4add(f4add(r1[0], r1[1]), r1[2]);
+  o[1][1] = f4sub(f4sub(r1[1], r1[2]), r1[3]);
+  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int oy = 2 * (int)ty + a, ox = 2 * (int)tx + b;
+      if (oy < H && ox < W) {
+        float4 v = f4add(o[a][b], bv);
+        v.x = v.x > 0.f ? v.x : v.x * slope;
+        v.y = v.y > 0.f ? v.y : v.y * slope;
+        v.z = v.z > 0.f ? v.z : v.z * slope;
+        v.w = v.w > 0.f ? v.w : v.w * slope;
+        *reinterpret_cast<float4*>(y + (((long)n * H + oy) * W + ox) * out_cstride + out_coff + cq * 4) = v;
+      }
+    }
+}
+
+// U_k = G g G^T per (co, ci), written in the 1x1 packed layout of each of the 16 GEMMs: [k][ci/32][co][ci%32]
+__global__ void wino_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Cout * Cin) return;
+  const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
+  const float* g = w + ((long)co * Cin + ci) * 9;
+  float Gg[4][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    Gg[0][j] = g[j];
+    Gg[1][j] = 0.5f * (g[j] + g[3 + j] + g[6 + j]);
+    Gg[2][j] = 0.5f * (g[j] - g[3 + j] + g[6 + j]);
+    Gg[3][j] = g[6 + j];
+  }
+  const long per_k = (long)Cin * Cout;
+  float* o = wp + ((long)(ci >> 5) * Cout + co) * 32 + (ci & 31);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[(i * 4 + 0) * per_k] = Gg[i][0];
+    o[(i * 4 + 1) * per_k] = 0.5f * (Gg[i][0] + Gg[i][1] + Gg[i][2]);
+    o[(i * 4 + 2) * per_k] = 0.5f * (Gg[i][0] - Gg[i][1] + Gg[i][2]);
+    o[(i * 4 + 3) * per_k] = Gg[i][2];
+  }
+}
+
+}  // namespace dim
+
+extern "C" {
+
+long dim_winograd_packed_weight_floats(int Cout, int Cin) { return 16L * Cout * Cin; }
+
+long dim_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout) {
+  long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+  return 16 * T * ((long)Cin + Cout);
+}
+
+int dim_winograd_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream) {
+  DIM_REQUIRE(w_oihw && w_packed, "null weight pointer");
+  DIM_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "Cin %% 32 == 0 and Cout %% 64 == 0 required");
+  long total = (long)Cout * Cin;
+  hipLaunchKernelGGL(wino_pack_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin);
+  return check_launch("winograd_pack_weight");
+}
+
+int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
+                            int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, void** events4,
+                            void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(x && w_packed && y && workspace, "null pointer");
+  DIM_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "Cin %% 32 == 0 and Cout %% 64 == 0 required");
+  if (in_cstride == 0) in_cstride = Cin;
+  if (out_cstride == 0) out_cstride = Cout;
+  DIM_REQUIRE(in_cstride >= Cin && in_cstride % 4 == 0 && out_cstride >= out_coff + Cout && out_cstride % 4 == 0 && out_coff % 4 == 0,
+              "channel strides / offsets must be multiples of 4 and cover the channels");
+  const int th = (H + 1) / 2, tw = (W + 1) / 2;
+  const long T = (long)N * th * tw;
+  DIM_REQUIRE(T * (Cin > Cout ? Cin : Cout) / 4 < (1L << 32) && T < (1L << 31), "too many tiles");
+  float* V = workspace;
+  float* M = workspace + 16 * T * Cin;
+  hipStream_t st = as_stream(stream);
+  const FastDiv dtw = make_fastdiv((unsigned)tw), dth = make_fastdiv((unsigned)th);
+#define DIM_WINO_EVENT(I)                                                                  \
+  if (events4 && events4[I]) {                                                             \
+    hipError_t e = hipEventRecord(reinterpret_cast<hipEvent_t>(events4[I]), st);           \
+    if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipEventRecord: %s", hipGetErrorString(e)); \
+  }
+  DIM_WINO_EVENT(0)
+  hipLaunchKernelGGL(wino_input_kernel, dim3(ceil_div(T * (Cin / 4), 256)), dim3(256), 0, st, x, V, N, H, W, Cin, in_cstride, th, tw,
+                     make_fastdiv((unsigned)(Cin / 4)), dtw, dth);
+  int rc = check_launch("winograd_input");
+  if (rc != DIM_OK) return rc;
+  DIM_WINO_EVENT(1)
+  ConvEx ex = {};
+  ex.pad_w = -1;
+  ex.batch = 16;
+  ex.bx = T * Cin;
+  ex.bw = (long)Cin * Cout;
+  ex.by = T * Cout;
+  rc = conv2d_fwd_impl(V, w_packed, nullptr, M, nullptr, 1, 1, (int)T, Cin, Cout, 1, 1, 1, 0, 1.0f, 1, tile, 0, stream, &ex);
+  if (rc != DIM_OK) return rc;
+  DIM_WINO_EVENT(2)
+  hipLaunchKernelGGL(wino_output_kernel, dim3(ceil_div(T * (Cout / 4), 256)), dim3(256), 0, st, M, bias, y, N, H, W, Cout, out_cstride,
+                     out_coff, th, tw, slope, make_fastdiv((unsigned)(Cout / 4)), dtw, dth);
+  rc = check_launch("winograd_output");
+  DIM_WINO_EVENT(3)
+#undef DIM_WINO_EVENT
+  return rc;
 }
 
 }  // extern "C"

@@ -69,7 +69,7 @@ class MutableModule(object):
     # ------------------------------------------------------------------------------------------------------------
     def _init_forward(self, cfg, B):
         net = self.net
-        FlowNetHip.__init__(net, cfg, {n: self.w[n].cpu().numpy() for n in self.names}, B, device=str(self.device))
+        FlowNetHip.__init__(net, cfg, {n: self.w[n].cpu().numpy() for n in self.names}, B, device=str(self.device), winograd=False)
         net.params = self.w  # the executor reads biases / small weights straight from the master vector
         d = self.device
         H, W = 480, 640
