@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--cfg", default=os.path.join(PKG, "experiments", "deepim", "cfgs", "deepim_hip_LM_ape_test.yaml"))
     ap.add_argument("--subdiv", type=int, default=5, help="icosphere subdivisions of the synthetic mesh (5 = 20480 triangles)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-winograd", action="store_true", help="run conv3_1/conv4_1/conv5_1/conv6_1 through the direct kernel too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--autotune", action="store_true", help="time tile/split-K candidates per layer first (untimed); default: fixed plan")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="bounded CPU-baseline sample (pairs refined by the oracle)")
@@ -122,7 +123,7 @@ def main():
     models = syn.make_models(seed=2333, n_models=len(cfg.dataset.class_name), subdiv=args.subdiv)
     rm = Render_Py(None, cfg.dataset.class_name, cfg.dataset.INTRINSIC_MATRIX, zNear=cfg.dataset.ZNEAR, zFar=cfg.dataset.ZFAR,
                    device=dev, meshes=models)
-    pred = Predictor(cfg, params, B, device=dev)
+    pred = Predictor(cfg, params, B, device=dev, winograd=not args.no_winograd)
     batch = syn.build_device_batch(rm, B, seed=1000 + rank, n_classes=len(models), pixel_means=cfg.network.PIXEL_MEANS, device=dev)
     if args.autotune:  # untimed: choose tile / split-K per layer on this GPU before the graph is captured
         pred.net.zoom({k: batch[k] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")})
@@ -216,7 +217,7 @@ def main():
         "config": {"workload": "LINEMOD 'ape' batch={} per GPU, {} iters, fp32, FAST_TEST graph (zoom + FlowNetS encoder + FC heads) "
                                "+ SE3 compose + HIP rasteriser ({} triangles) + box_rendered mask update".format(
                                    B, test_iter, models[0][2].shape[0]),
-                   "pairs_per_gpu": B, "global_pairs": B * world, "test_iter": test_iter, "hipgraph": not args.no_graph,
+                   "pairs_per_gpu": B, "global_pairs": B * world, "test_iter": test_iter, "hipgraph": not args.no_graph, "winograd_3x3s1": not args.no_winograd,
                    "gflop_per_refinement": round(net.flops_per_forward() * test_iter / B / 1e9, 2), "status_flags": status,
                    "conv_plan": {k: list(v) for k, v in net.conv_plan.items()}},
         "roofline": roofline,

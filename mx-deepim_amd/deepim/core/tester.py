@@ -23,8 +23,8 @@ from deepim.symbols.deepIM_flownet import FlowNetHip
 class Predictor(object):
     """Reference: binds a MutableModule and calls forward (tester.py:27-56).  Here: owns a FlowNetHip."""
 
-    def __init__(self, config, arg_params, batch_size, device="cuda:0", conv_plan=None):
-        self.net = FlowNetHip(config, arg_params, batch_size, device=device, conv_plan=conv_plan)
+    def __init__(self, config, arg_params, batch_size, device="cuda:0", conv_plan=None, winograd=True):
+        self.net = FlowNetHip(config, arg_params, batch_size, device=device, conv_plan=conv_plan, winograd=winograd)
         self.data_names = ["image_observed", "image_rendered", "src_pose", "class_index", "mask_observed", "mask_rendered"]
 
     def predict(self, data_batch):
