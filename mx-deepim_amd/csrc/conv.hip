@@ -181,13 +181,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (kc_begin < kc_end) {
-    DIM_LOAD_CHUNK(kc_begin, true)
-    DIM_ADVANCE()
-    DIM_STORE_CHUNK(0)
-  }
-  __syncthreads();
-
   // fragment addressing: lane (half h, row r) reads 4 consecutive k = 8s + 4h + {0..3} of its row with one ds_read_b128;
   // MFMA #j of group s then contracts k = 8s + j (lanes 0-31) and k = 8s + 4 + j (lanes 32-63): every k of the chunk
   // is used exactly once, identically for A and B.
@@ -195,49 +188,70 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   const int khalf = lane >> 5;
   const int a_off = (wm * (BM / WM) + frow) * LDK + 4 * khalf;
   const int b_off = (wn * (BN / WN) + frow) * LDK + 4 * khalf;
+  float4 fa[2][TM], fb[2][TN];
+#define DIM_FRAG_READ(IDX, PA, PB, S)                                                                  \
+  {                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[IDX][i] = *reinterpret_cast<const float4*>((PA) + 32 * i * LDK + 8 * (S)); \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[IDX][j] = *reinterpret_cast<const float4*>((PB) + 32 * j * LDK + 8 * (S)); \
+  }
+#define DIM_MFMA_GROUP(IDX)                                                                             \
+  {                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].x, fb[IDX][j].x, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].y, fb[IDX][j].y, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].z, fb[IDX][j].z, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].w, fb[IDX][j].w, acc[i][j], 0, 0, 0); \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  }
+
+  // ---- software pipeline (per K chunk of 32 = four MFMA groups g0..g3):
+  //   g0 | g1 | [registers -> LDS for chunk k+1, then global loads for chunk k+2] | g2 | barrier | [fragments g0 of chunk k+1] | g3
+  // The LDS stores and the barrier sit INSIDE the MFMA sequence and the next chunk's first fragments are in flight during g3, so
+  // no wave ever reaches a point with nothing to feed the MFMA pipe.  (With stores + barrier + first fragment read at the chunk
+  // boundary the four workgroups of a CU ran in lock step and the pipe idled ~20 % of the time: PMC 74-78 % MFMA-busy.)
+  // The barrier only orders LDS traffic (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also wait for the global
+  // prefetch that has just been issued.  Hazards: buffer b^1 is written in the middle of chunk k; its last readers were the g3
+  // fragments of chunk k-1, which every wave has in registers before it passes that chunk's barrier.
+  if (kc_begin < kc_end) {
+    DIM_LOAD_CHUNK(kc_begin, true)
+    DIM_ADVANCE()
+    DIM_STORE_CHUNK(0)
+  }
+  __syncthreads();
+  {
+    const int kn = min(kc_begin + 1, a.nchunks - 1);
+    DIM_LOAD_CHUNK(kn, kc_begin + 1 < kc_end)
+    DIM_ADVANCE()
+  }
+  DIM_FRAG_READ(0, sA + a_off, sB + b_off, 0)
 
   int buf = 0;
   for (int kc = kc_begin; kc < kc_end; ++kc) {
     const float* cA = sA + buf * BM * LDK + a_off;
     const float* cB = sB + buf * BN * LDK + b_off;
-    float4 fa[2][TM], fb[2][TN];
-    // first fragments of this chunk go out before anything else: their LDS latency hides under the address arithmetic
-    // of the global prefetch below
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float4*>(cA + 32 * i * LDK);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float4*>(cB + 32 * j * LDK);
-    __builtin_amdgcn_sched_barrier(0);
-    // prefetch the next chunk into registers (the last iteration re-reads a clamped chunk: branch-free)
-    const int kn = min(kc + 1, a.nchunks - 1);
-    DIM_LOAD_CHUNK(kn, kc + 1 < kc_end)
-    DIM_ADVANCE()
-    __builtin_amdgcn_sched_barrier(0);  // keep the global prefetch AHEAD of the MFMA block (hipcc sinks it otherwise)
-#pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
-      const int cur = s & 1, nxt = cur ^ 1;
-      if (s + 1 < BK / 8) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const float4*>(cA + 32 * i * LDK + 8 * (s + 1));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const float4*>(cB + 32 * j * LDK + 8 * (s + 1));
-      }
-      __builtin_amdgcn_sched_barrier(0);  // reads of group s+1 issue BEFORE the MFMAs of group s ...
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
-        }
-      __builtin_amdgcn_sched_barrier(0);  // ... and nothing is sunk below them
-    }
+    const float* nA = sA + (buf ^ 1) * BM * LDK + a_off;
+    const float* nB = sB + (buf ^ 1) * BN * LDK + b_off;
+    DIM_FRAG_READ(1, cA, cB, 1)
+    DIM_MFMA_GROUP(0)
+    DIM_FRAG_READ(0, cA, cB, 2)
+    DIM_MFMA_GROUP(1)
     DIM_STORE_CHUNK(buf ^ 1)
-    __syncthreads();
+    {
+      const int kn = min(kc + 2, a.nchunks - 1);
+      DIM_LOAD_CHUNK(kn, kc + 2 < kc_end)
+      DIM_ADVANCE()
+    }
+    DIM_FRAG_READ(1, cA, cB, 3)
+    DIM_MFMA_GROUP(0)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    DIM_FRAG_READ(0, nA, nB, 0)
+    DIM_MFMA_GROUP(1)
     buf ^= 1;
   }
+#undef DIM_FRAG_READ
+#undef DIM_MFMA_GROUP
 #undef DIM_LOAD_A
 #undef DIM_LOAD_B
 #undef DIM_LOAD_CHUNK
