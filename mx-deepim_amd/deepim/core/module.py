@@ -69,7 +69,7 @@ class MutableModule(object):
     # ------------------------------------------------------------------------------------------------------------
     def _init_forward(self, cfg, B):
         net = self.net
-        FlowNetHip.__init__(net, cfg, {n: self.w[n].cpu().numpy() for n in self.names}, B, device=str(self.device), winograd=False)
+        FlowNetHip.__init__(net, cfg, {n: self.w[n].cpu().numpy() for n in self.names}, B, device=str(self.device), winograd=True)
         net.params = self.w  # the executor reads biases / small weights straight from the master vector
         d = self.device
         H, W = 480, 640
@@ -127,7 +127,10 @@ class MutableModule(object):
         net, w = self.net, self.w
         for name, cout, k, s, p in ENCODER:
             if forward:
-                net.packed[name] = ops.conv2d_pack_weight(w[name + "_weight"])
+                if name in net.wino:   # 3x3 / stride-1 layers run their forward through Winograd: re-transform the weights
+                    net.wino[name] = ops.winograd_pack_weight(w[name + "_weight"])
+                else:
+                    net.packed[name] = ops.conv2d_pack_weight(w[name + "_weight"])
             if name != "flow_conv1":
                 self.dgrad_packed[name] = ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p)
         if forward:

@@ -159,8 +159,7 @@ class FlowNetHip(object):
 
     def __init__(self, cfg, arg_params, batch_size, device="cuda:0", conv_plan=None, winograd=True):
         """winograd: run the 3x3 / stride-1 layers (conv3_1, conv4_1, conv5_1, conv6_1) through Winograd F(2x2,3x3)
-        (same f32 result within 1e-4 relative, 2.25x fewer multiply-adds).  The training executor passes False: it re-packs
-        weights after every update and its backward kernels are written against the direct form."""
+        (same f32 result within 1e-4 relative, 2.25x fewer multiply-adds).  False = direct kernel for every layer."""
         self.cfg = cfg
         self.B = batch_size
         self.device = torch.device(device)
