@@ -119,6 +119,16 @@ class MutableModule(object):
         self.bias_ws = torch.empty(ops.lib().dim_bias_grad_workspace_floats(B * 240 * 320, 64) + 1024 * 64, dtype=torch.float32, device=d)
         # dgrad-layout weights (refreshed by repack())
         self.dgrad_packed = {}
+        self.wino_dgrad = {}
+        self.wino_ws = None
+        if net.wino:
+            need, h, w, c = 4, 480, 640, 8
+            for name, cout, k, s, p in ENCODER:
+                if name in net.wino:
+                    need = max(need, ops.lib().dim_winograd_workspace_floats(B, h, w, cout, c))
+                h, w = ops.conv_out_hw(h, w, k, k, s, p)
+                c = cout
+            self.wino_ws = torch.empty(need, dtype=torch.float32, device=d)
         self.repack(forward=False)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -131,7 +141,9 @@ class MutableModule(object):
                     net.wino[name] = ops.winograd_pack_weight(w[name + "_weight"])
                 else:
                     net.packed[name] = ops.conv2d_pack_weight(w[name + "_weight"])
-            if name != "flow_conv1":
+            if name in net.wino:
+                self.wino_dgrad[name] = ops.winograd_pack_weight(w[name + "_weight"].flip(2, 3).transpose(0, 1).contiguous())
+            elif name != "flow_conv1":
                 self.dgrad_packed[name] = ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p)
         if forward:
             net.packed["fc6"] = ops.fc_pack_weight(w["fc6_weight"], 1024, 8, 10)
@@ -244,7 +256,14 @@ class MutableModule(object):
             ops.conv2d_unpack_weight(self.gpack, g[name + "_weight"])
             ops.bias_grad(dy, cout, g[name + "_bias"], workspace=self.bias_ws)
             if prev[name]:
-                ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False)
+                if name in self.wino_dgrad:
+                    # dX of a 3x3 / stride-1 / pad-1 convolution = the same kind of convolution of dZ with the flipped, transposed
+                    # kernel: Winograd F(2x2,3x3) like the forward (no bias, no activation)
+                    ops.conv2d_fwd_winograd(dy, cout, self.wino_dgrad[name], None, cin[name], slope=1.0,
+                                            tile=4 if (cin[name] % 128 == 0 and dy.shape[0] * dy.shape[1] * dy.shape[2] >= 4096) else 3,
+                                            out=self.dacts[prev[name]], workspace=self.wino_ws)
+                else:
+                    ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False)
         return g
 
     def _deconv_bwd(self, name, x, x_c, x_cpad, dz, dz_coff, cout, dx):
