@@ -212,12 +212,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ db, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// workgroup = 64 columns x 4 partial-row groups; LDS fold
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ db,
+                                                           int accumulate) {
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += partial[(long)k * C + c];
-  db[c] = accumulate ? db[c] + s : s;
+  if (c < C)
+    for (int k = rg; k < nsplit; k += 4) s += partial[(long)k * C + c];
+  __shared__ float red[4][64];
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    db[c] = accumulate ? db[c] + t : t;
+  }
 }
 
 // dz = dy * (y > 0 ? 1 : slope) elementwise on a channel range of NHWC rows (LeakyReLU backward)
@@ -305,16 +314,23 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   return DIM_OK;
 }
 
-long dim_bias_grad_workspace_floats(int M, int C) { return (long)ceil_div(M, 512) * C; }
+// rows per partial block: at least 512, and few enough blocks (<= 256 per column tile) that the final fold stays short
+static int bias_rows_per_block(int M) {
+  int r = ceil_div(M, 256);
+  return r < 512 ? 512 : r;
+}
+
+long dim_bias_grad_workspace_floats(int M, int C) { return (long)ceil_div(M, bias_rows_per_block(M)) * C; }
 
 int dim_bias_grad(const float* dz, float* db, float* workspace, int M, int C, int dz_cstride, int dz_coff, int accumulate, void* stream) {
   if (M == 0) return DIM_OK;
   DIM_REQUIRE(dz && db && workspace, "null pointer");
   DIM_REQUIRE(C % 4 == 0 && dz_cstride % 4 == 0 && dz_coff % 4 == 0, "bias_grad: channel counts/offsets must be multiples of 4");
-  int nsplit = ceil_div(M, 512);
+  const int rpb = bias_rows_per_block(M);
+  int nsplit = ceil_div(M, rpb);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C, 64), nsplit), dim3(256), 0, st, dz, M, C, dz_cstride, dz_coff, 512, workspace);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, workspace, nsplit, C, db, accumulate);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C, 64), nsplit), dim3(256), 0, st, dz, M, C, dz_cstride, dz_coff, rpb, workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, workspace, nsplit, C, db, accumulate);
   return check_launch("bias_grad");
 }
 
