@@ -1,0 +1,73 @@
+"""BASELINE configs[1] at full size (16 pairs per GPU, 4 iterations, 480x640) through size-independent properties: the oracle
+needs ~0.4 s per pair-iteration on the host, so it checks two of the sixteen pairs and the rest is covered by invariances."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import refine as orefine  # noqa: E402
+from scene import make_test_config  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def test_batch16_properties(hip_lib):
+    from deepim.core.tester import Predictor, Refiner
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+    from lib.render_hip.render_py_multi import Render_Py
+    from lib.utils import synthetic as syn
+
+    cfg = make_test_config(test_iter=4)
+    sym = deepIM_flownet()
+    sym.get_symbol(cfg, is_train=False)
+    params = sym.init_weights(cfg, {}, {}, seed=0)
+    rng = np.random.RandomState(1)
+    params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
+    params["rot_weight"][1:] = (rng.randn(3, 256) * 0.01).astype(np.float32)
+    B = 16
+    models = syn.make_models(seed=2333, n_models=1, subdiv=3)
+    rm = Render_Py(None, cfg.dataset.class_name, syn.LINEMOD_K, meshes=models)
+    batch = syn.build_device_batch(rm, B, seed=77)
+    load = [batch[k] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose", "class_index")]
+
+    pred = Predictor(cfg, params, B)
+    eager = Refiner(cfg, pred, rm, B, capture_graph=False)
+    eager.load(*load)
+    p_eager = eager.refine().cpu().numpy().copy()
+    assert np.isfinite(p_eager).all() and int(eager.status_iter.abs().sum()) == 0
+
+    # (1) hipGraph replay == eager, bit for bit, and replays are idempotent
+    graph = Refiner(cfg, pred, rm, B, capture_graph=True)
+    graph.load(*load)
+    p_g1 = graph.refine().cpu().numpy().copy()
+    p_g2 = graph.refine().cpu().numpy().copy()
+    np.testing.assert_array_equal(p_g1, p_eager)
+    np.testing.assert_array_equal(p_g2, p_g1)
+
+    # (2) every refined pose is a rigid transform: R^T R = I, det = +1
+    R = p_eager[..., :3].astype(np.float64)
+    np.testing.assert_allclose(np.einsum("ibkj,ibkl->ibjl", R, R), np.broadcast_to(np.eye(3), R.shape), atol=1e-5)
+    np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=1e-5)
+
+    # (3) samples are independent: permuting the batch permutes the result (different tiles / split-K slabs see each pair, so
+    #     equality is to f32 summation order, not bitwise); a 2-pair executor gives the same poses for pairs 3 and 11
+    perm = np.random.RandomState(5).permutation(B)
+    tperm = torch.as_tensor(perm, device=DEV)
+    eager.load(*[t[tperm] for t in load])
+    p_perm = eager.refine().cpu().numpy()
+    np.testing.assert_allclose(p_perm, p_eager[:, perm], atol=2e-4)
+    pred2 = Predictor(cfg, params, 2)
+    small = Refiner(cfg, pred2, rm, 2, capture_graph=False)
+    pick = torch.as_tensor([3, 11], device=DEV)
+    small.load(*[t[pick] for t in load])
+    np.testing.assert_allclose(small.refine().cpu().numpy(), p_eager[:, [3, 11]], atol=2e-4)
+
+    # (4) the oracle on two of the sixteen pairs (north_star bar 1e-3)
+    z3, o3 = np.zeros(3), np.ones(3)
+    host = {k: batch[k].cpu().numpy() for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
+    for b in (0, 9):
+        blobs_b = {k: v[b:b + 1] for k, v in host.items()}
+        o_poses, _ = orefine.refine_pair(params, models[0], blobs_b, syn.LINEMOD_K, cfg.network.PIXEL_MEANS, z3, o3, "CAMERA", test_iter=4)
+        for it in range(4):
+            np.testing.assert_allclose(p_eager[it, b], o_poses[it], atol=1e-3)
