@@ -35,6 +35,11 @@ const char* dim_last_error(void);
 /* library / device probe: fills name (<= n bytes), returns number of compute units or <0 */
 int dim_device_info(char* name, int n);
 
+/* Device-to-device copy of `nwords` 4-byte words as a plain kernel launch.  The refinement loop uses it instead of
+ * hipMemcpyAsync / hipMemsetAsync inside captured hipGraphs: a captured memset node was observed to overlap the kernel
+ * after it on replay (ROCm 7.2), so no copy / fill node is left in the graph (deepim/core/tester.py Refiner._loop). */
+int dim_copy_words(void* dst, const void* src, long nwords, void* stream);
+
 /* ---------------------------------------------------------------- zoom ops
  * bbox of {x > thr} (mode 0, C==1) or {sum_c (x_c + means3[c]) > thr} (mode 1, C==3):
  *   bbox[b] = {min_x, max_x, min_y, max_y}, empty = {W,-1,H,-1}.

@@ -17,9 +17,29 @@ int set_err(int code, const char* fmt, ...) {
   return code;
 }
 
+// device-to-device copy of 4-byte words as a KERNEL node (16-byte path when both pointers and the count allow it)
+__global__ __launch_bounds__(256) void copy_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, long nwords, int vec4) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec4) {
+    if (i * 4 < nwords) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  } else if (i < nwords) {
+    dst[i] = src[i];
+  }
+}
+
 }  // namespace dim
 
 extern "C" {
+
+int dim_copy_words(void* dst, const void* src, long nwords, void* stream) {
+  if (nwords == 0) return DIM_OK;
+  DIM_REQUIRE(dst && src, "null pointer");
+  const int vec4 = (nwords % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0);
+  const long n = vec4 ? nwords / 4 : nwords;
+  hipLaunchKernelGGL(dim::copy_words_kernel, dim3(dim::ceil_div(n, 256)), dim3(256), 0, dim::as_stream(stream),
+                     reinterpret_cast<unsigned*>(dst), reinterpret_cast<const unsigned*>(src), nwords, vec4);
+  return dim::check_launch("copy_words");
+}
 
 const char* dim_last_error(void) { return dim::err_buf(); }
 

@@ -97,18 +97,19 @@ class Refiner(object):
     def _loop(self):
         """tester.py:476-598 for a whole batch; everything enqueued on the current stream, no host sync."""
         cfg, net, b = self.cfg, self.net, self.batch
-        b["src_pose"].copy_(self.pose_init)
+        # every copy below is ops.copy (a kernel), never Tensor.copy_: no memcpy / memset node may sit in the captured graph
+        ops.copy(b["src_pose"], self.pose_init)
         for k, v in self.init.items():
-            b[k].copy_(v)
+            ops.copy(b[k], v)
         bbox = None
         for it in range(self.test_iter):
             out = net.forward_test(b, bbox_ren=bbox)
-            self.se3_iter[it].copy_(net.se3)
+            ops.copy(self.se3_iter[it], net.se3)
             if self.mask_pred_iter is not None:
-                self.mask_pred_iter[it].copy_(out["mask_observed_pred_output"])
+                ops.copy(self.mask_pred_iter[it], out["mask_observed_pred_output"])
             if self.flow_est_iter is not None:
-                self.flow_est_iter[it].copy_(out["flow_est_crop_output"])
-            self.status_iter[it].copy_(net.status)
+                ops.copy(self.flow_est_iter[it], out["flow_est_crop_output"])
+            ops.copy(self.status_iter[it], net.status)
             # pose_rendered_update = RT_transform(pose_rendered, se3[:-3], se3[-3:], ...)   (:525-532)
             ops.se3_compose(b["src_pose"], net.se3, cfg.network.ROT_COORD, self.T_means, self.T_stds, out=self.poses_iter[it])
             if it < self.test_iter - 1:
@@ -119,7 +120,7 @@ class Refiner(object):
                                                  **extra)
                 if cfg.network.INPUT_MASK and cfg.network.PRED_MASK and cfg.TEST.UPDATE_MASK == "box_rendered":
                     ops.box_mask(self.bbox, b["mask_observed"])  # data_pair.py:103-114
-                b["src_pose"].copy_(self.poses_iter[it])
+                ops.copy(b["src_pose"], self.poses_iter[it])
                 bbox = self.bbox
 
     def refine(self):

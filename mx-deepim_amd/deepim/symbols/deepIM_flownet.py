@@ -311,7 +311,7 @@ class FlowNetHip(object):
         p = self.params
         r10, r8, r6 = self.acts["conv6_1"], self.acts["conv5_1"], self.acts["conv4_1"]
         ops.conv_small_cout_fwd(r10, 1024, self.packed["Convolution1"], p["Convolution1_bias"], 2, out=self.flow6)
-        self.concat2[..., :512].copy_(r8)
+        self.concat2[..., :512].copy_(r8)  # strided: an elementwise kernel, not a memcpy node
         ops.deconv4x4s2_fwd(r10, 1024, self.packed["deconv5"], p["deconv5_bias"], self.concat2, 512, crop=1, slope=0.1, out_coff=512)
         ops.deconv4x4s2_tiny_fwd(self.flow6, 2, p["upsample_flow6to5_weight"], p["upsample_flow6to5_bias"], self.concat2, 2, crop=1,
                                  out_coff=1024)

@@ -157,6 +157,14 @@ def conv_auto_plan(M, Cout, nchunks, cin=32):
     return 3, max(1, min(8, int(round(2048.0 / blocks)), nchunks))
 
 
+def copy(dst, src):
+    """dst <- src (same shape, 4-byte dtype, contiguous CUDA tensors) as a kernel launch: graph-safe replacement for Tensor.copy_
+    (hipMemcpyAsync nodes inside captured graphs are avoided, see include/deepim_hip.h dim_copy_words)."""
+    assert dst.shape == src.shape and dst.dtype == src.dtype and dst.element_size() == 4, (dst.shape, src.shape, dst.dtype, src.dtype)
+    check(lib().dim_copy_words(dptr(dst), dptr(src), dst.numel(), current_stream()))
+    return dst
+
+
 def winograd_pack_weight(w_oihw):
     """(Cout,Cin,3,3) -> the 16 transformed 1x1 weight sets of the Winograd F(2x2,3x3) path"""
     Cout, Cin, KH, KW = w_oihw.shape
