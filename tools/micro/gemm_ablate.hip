@@ -16,9 +16,9 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ A, const floa
   for (int i = 0; i < TM; ++i)
     for (int j = 0; j < TN; ++j)
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float4 ra[2 * TM], rb[2 * TN];
-  for (int i = 0; i < 2 * TM; ++i) ra[i] = make_float4(1.f, 2.f, 3.f, 4.f);
-  for (int i = 0; i < 2 * TN; ++i) rb[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+  float4 ra[2 * TM], rb[2 * TN], ra2[2 * TM], rb2[2 * TN];
+  for (int i = 0; i < 2 * TM; ++i) ra[i] = ra2[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+  for (int i = 0; i < 2 * TN; ++i) rb[i] = rb2[i] = make_float4(1.f, 2.f, 3.f, 4.f);
   // init LDS
   for (int i = tid; i < 2 * (BM + BN) * LDK; i += 256) smem[i] = 1.0f + (i & 7);
   __syncthreads();
@@ -40,7 +40,17 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ A, const floa
       for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float4*>(cB + 32 * j * LDK);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (FLAGS & 4) {
+    if (FLAGS & 8) {  // two-deep: what was loaded one chunk ago moves to the store registers, new loads go out now
+#pragma unroll
+      for (int i = 0; i < 2 * TM; ++i) ra[i] = ra2[i];
+#pragma unroll
+      for (int i = 0; i < 2 * TN; ++i) rb[i] = rb2[i];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2 * TM; ++i) ra2[i] = *reinterpret_cast<const float4*>(ga + (long)i * 32 * lda + kc * 32);
+#pragma unroll
+      for (int i = 0; i < 2 * TN; ++i) rb2[i] = *reinterpret_cast<const float4*>(gb + (long)i * 32 * 32 + (long)kc * 32 * 64 * TN * gridDim.y);
+    } else if (FLAGS & 4) {
 #pragma unroll
       for (int i = 0; i < 2 * TM; ++i) ra[i] = *reinterpret_cast<const float4*>(ga + (long)i * 32 * lda + kc * 32);
 #pragma unroll
@@ -118,7 +128,7 @@ void run(int mt, int nt, int nchunks) {
 
 int main() {
   // conv3_1-like: M=76800, N=256, K=2304
-  run<0, 1, 1>(1200, 4, 72); run<1, 1, 1>(1200, 4, 72); run<3, 1, 1>(1200, 4, 72); run<7, 1, 1>(1200, 4, 72); run<5, 1, 1>(1200, 4, 72);
-  run<0, 2, 2>(600, 2, 72); run<1, 2, 2>(600, 2, 72); run<3, 2, 2>(600, 2, 72); run<7, 2, 2>(600, 2, 72);
+  run<0, 1, 1>(1200, 4, 72); run<1, 1, 1>(1200, 4, 72); run<3, 1, 1>(1200, 4, 72); run<7, 1, 1>(1200, 4, 72); run<15, 1, 1>(1200, 4, 72);
+  run<0, 2, 2>(600, 2, 72); run<1, 2, 2>(600, 2, 72); run<3, 2, 2>(600, 2, 72); run<7, 2, 2>(600, 2, 72); run<15, 2, 2>(600, 2, 72);
   return 0;
 }
