@@ -71,3 +71,49 @@ def test_batch16_properties(hip_lib):
         o_poses, _ = orefine.refine_pair(params, models[0], blobs_b, syn.LINEMOD_K, cfg.network.PIXEL_MEANS, z3, o3, "CAMERA", test_iter=4)
         for it in range(4):
             np.testing.assert_allclose(p_eager[it, b], o_poses[it], atol=1e-3)
+
+
+def test_full_graph_batch16_and_many_meshes(hip_lib):
+    """BASELINE configs[3] / [4] shapes: 16 pairs per GPU through the FULL test graph (decoder + mask + flow heads every iteration),
+    classes drawn from 24 resident meshes.  Properties: graph == eager bit for bit, heads finite and non-trivial, two pairs vs the oracle."""
+    from deepim.core.tester import Predictor, Refiner
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+    from lib.render_hip.render_py_multi import Render_Py
+    from lib.utils import synthetic as syn
+
+    cfg = make_test_config(test_iter=2)
+    cfg.TEST.FAST_TEST = False
+    n_cls = 24
+    cfg.dataset.class_name = ["obj{:02d}".format(i) for i in range(n_cls)]
+    sym = deepIM_flownet()
+    sym.get_symbol(cfg, is_train=False)
+    params = sym.init_weights(cfg, {}, {}, seed=2)
+    rng = np.random.RandomState(3)
+    params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
+    params["mask_conv3_weight"] = (rng.randn(1, 770, 3, 3) * 0.05).astype(np.float32)
+    B = 16
+    models = syn.make_models(seed=77, n_models=n_cls, subdiv=2)
+    rm = Render_Py(None, cfg.dataset.class_name, syn.LINEMOD_K, meshes=models)
+    batch = syn.build_device_batch(rm, B, seed=5, n_classes=n_cls)
+    assert len(set(batch["class_index"].cpu().numpy().tolist())) >= 8
+    load = [batch[k] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose", "class_index")]
+    pred = Predictor(cfg, params, B)
+    eager = Refiner(cfg, pred, rm, B, capture_graph=False)
+    eager.load(*load)
+    p_e = eager.refine().cpu().numpy().copy()
+    m_e, f_e = eager.mask_pred_iter.cpu().numpy().copy(), eager.flow_est_iter.cpu().numpy().copy()
+    graph = Refiner(cfg, pred, rm, B, capture_graph=True)
+    graph.load(*load)
+    np.testing.assert_array_equal(graph.refine().cpu().numpy(), p_e)
+    np.testing.assert_array_equal(graph.mask_pred_iter.cpu().numpy(), m_e)
+    np.testing.assert_array_equal(graph.flow_est_iter.cpu().numpy(), f_e)
+    assert np.isfinite(f_e).all() and np.abs(f_e).max() > 0.1 and set(np.unique(m_e)) <= {0.0, 1.0} and 0.0 < m_e.mean() < 1.0
+    host = {k: batch[k].cpu().numpy() for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
+    cls = batch["class_index"].cpu().numpy()
+    for b in (2, 13):
+        blobs_b = {k: v[b:b + 1] for k, v in host.items()}
+        o_poses, _ = orefine.refine_pair(params, models[int(cls[b])], blobs_b, syn.LINEMOD_K, cfg.network.PIXEL_MEANS, np.zeros(3), np.ones(3),
+                                         "CAMERA", test_iter=2, fast_test=False)
+        for it in range(2):
+            np.testing.assert_allclose(p_e[it, b], o_poses[it], atol=1e-3)
+    cfg.TEST.FAST_TEST = True
