@@ -58,7 +58,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                       // [2][BM][LDK]   pixel-major, k contiguous
-  float* sB = smem + 2 * BM * LDK;        // [2][BN][LDK]   channel-major, k contiguous
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -139,8 +138,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
               (!CIN8 || kw + (q >> 1) < a.KW);                                                                      \
     REG = buf_load16(rx, ok ? a_pix[I] + tap_off : -1, 0);                                                          \
   }
-#define DIM_LOAD_B(REG, I) \
-  if (I < B_PER_T) REG = buf_load16(rw, w_voff + I * RP * BK * 4, w_soff);
+#define DIM_LOAD_B(REG, I)
   // PF_OK = false on the one prefetch past the last chunk: its (kh,kw,c0) counters already point one channel slice beyond
   // the tensor, so the (unused) activation read is dropped like a padding tap
 #define DIM_LOAD_CHUNK(KC, PF_OK)                                  \
@@ -163,12 +161,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   }
 #define DIM_STORE_A(REG, I) \
   if (I < A_PER_T) *reinterpret_cast<float4*>(dA + (srow + RP * I) * LDK + q * 4) = REG;
-#define DIM_STORE_B(REG, I) \
-  if (I < B_PER_T) *reinterpret_cast<float4*>(dB + (srow + RP * I) * LDK + q * 4) = REG;
+#define DIM_STORE_B(REG, I)
 #define DIM_STORE_CHUNK(BUF)                          \
   {                                                   \
     float* dA = sA + (BUF) * BM * LDK;                \
-    float* dB = sB + (BUF) * BN * LDK;                \
     DIM_STORE_A(ra0, 0) DIM_STORE_A(ra1, 1) DIM_STORE_A(ra2, 2) DIM_STORE_A(ra3, 3) \
     DIM_STORE_B(rb0, 0) DIM_STORE_B(rb1, 1) DIM_STORE_B(rb2, 2) DIM_STORE_B(rb3, 3) \
   }
@@ -187,21 +183,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   const int frow = lane & 31;
   const int khalf = lane >> 5;
   const int a_off = (wm * (BM / WM) + frow) * LDK + 4 * khalf;
-  const int b_off = (wn * (BN / WN) + frow) * LDK + 4 * khalf;
-  float4 fa[2][TM], fb[2][TN];
+  float4 fa[2][TM];
 #define DIM_FRAG_READ(IDX, PA, PB, S)                                                                  \
   {                                                                                                    \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[IDX][i] = *reinterpret_cast<const float4*>((PA) + 32 * i * LDK + 8 * (S)); \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[IDX][j] = *reinterpret_cast<const float4*>((PB) + 32 * j * LDK + 8 * (S)); \
   }
-#define DIM_MFMA_GROUP(IDX)                                                                             \
+  // the weights never pass through LDS: every wave fetches its own B fragments (lane (row n, k half) = 16 contiguous bytes of the
+  // packed [chunk][Cout][32] array) one whole chunk ahead; fbq[set][group][tile]
+  float4 fbq[2][4][TN];
+  const int bf_voff = ((n0 + wn * (BN / WN) + frow) * BK + 4 * khalf) * 4;
+#define DIM_LOAD_BFRAG(SET, KC)                                                                         \
+  {                                                                                                    \
+    const int bsoff = (KC) * wchunk_bytes;                                                             \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) _Pragma("unroll") for (int j = 0; j < TN; ++j)        \
+      fbq[SET][g][j] = buf_load16(rw, bf_voff + (32 * j * BK + 8 * g) * 4, bsoff);                      \
+  }
+#define DIM_MFMA_GROUP(IDX, SET, G)                                                                     \
   {                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {     \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].x, fb[IDX][j].x, acc[i][j], 0, 0, 0); \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].y, fb[IDX][j].y, acc[i][j], 0, 0, 0); \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].z, fb[IDX][j].z, acc[i][j], 0, 0, 0); \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].w, fb[IDX][j].w, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].x, fbq[SET][G][j].x, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].y, fbq[SET][G][j].y, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].z, fbq[SET][G][j].z, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].w, fbq[SET][G][j].w, acc[i][j], 0, 0, 0); \
     }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   }
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
     DIM_LOAD_CHUNK(kc_begin, true)
     DIM_ADVANCE()
     DIM_STORE_CHUNK(0)
+    DIM_LOAD_BFRAG(0, kc_begin)
   }
   __syncthreads();
   {
@@ -225,31 +230,37 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
     DIM_LOAD_CHUNK(kn, kc_begin + 1 < kc_end)
     DIM_ADVANCE()
   }
-  DIM_FRAG_READ(0, sA + a_off, sB + b_off, 0)
+  DIM_FRAG_READ(0, sA + a_off, 0, 0)
 
-  int buf = 0;
-  for (int kc = kc_begin; kc < kc_end; ++kc) {
-    const float* cA = sA + buf * BM * LDK + a_off;
-    const float* cB = sB + buf * BN * LDK + b_off;
-    const float* nA = sA + (buf ^ 1) * BM * LDK + a_off;
-    const float* nB = sB + (buf ^ 1) * BN * LDK + b_off;
-    DIM_FRAG_READ(1, cA, cB, 1)
-    DIM_MFMA_GROUP(0)
-    DIM_FRAG_READ(0, cA, cB, 2)
-    DIM_MFMA_GROUP(1)
-    DIM_STORE_CHUNK(buf ^ 1)
-    {
-      const int kn = min(kc + 2, a.nchunks - 1);
-      DIM_LOAD_CHUNK(kn, kc + 2 < kc_end)
-      DIM_ADVANCE()
-    }
-    DIM_FRAG_READ(1, cA, cB, 3)
-    DIM_MFMA_GROUP(0)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    DIM_FRAG_READ(0, nA, nB, 0)
-    DIM_MFMA_GROUP(1)
-    buf ^= 1;
+#define DIM_CHUNK_BODY(SET, KCUR)                                                    \
+  {                                                                                  \
+    const float* cA = sA + buf * BM * LDK + a_off;                                   \
+    const float* nA = sA + (buf ^ 1) * BM * LDK + a_off;                             \
+    DIM_LOAD_BFRAG(1 - SET, min((KCUR) + 1, a.nchunks - 1))                          \
+    DIM_FRAG_READ(1, cA, 0, 1)                                                      \
+    DIM_MFMA_GROUP(0, SET, 0)                                                        \
+    DIM_FRAG_READ(0, cA, 0, 2)                                                      \
+    DIM_MFMA_GROUP(1, SET, 1)                                                        \
+    DIM_STORE_CHUNK(buf ^ 1)                                                         \
+    {                                                                                \
+      const int kn = min((KCUR) + 2, a.nchunks - 1);                                 \
+      DIM_LOAD_CHUNK(kn, (KCUR) + 2 < kc_end)                                        \
+      DIM_ADVANCE()                                                                  \
+    }                                                                                \
+    DIM_FRAG_READ(1, cA, 0, 3)                                                      \
+    DIM_MFMA_GROUP(0, SET, 2)                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                  \
+    DIM_FRAG_READ(0, nA, 0, 0)                                                      \
+    DIM_MFMA_GROUP(1, SET, 3)                                                        \
+    buf ^= 1;                                                                        \
   }
+  int buf = 0;
+  for (int kc = kc_begin; kc < kc_end; kc += 2) {
+    DIM_CHUNK_BODY(0, kc)
+    if (kc + 1 < kc_end) DIM_CHUNK_BODY(1, kc + 1)
+  }
+#undef DIM_CHUNK_BODY
+#undef DIM_LOAD_BFRAG
 #undef DIM_FRAG_READ
 #undef DIM_MFMA_GROUP
 #undef DIM_LOAD_A
@@ -567,7 +578,7 @@ __global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict_
 
 template <int BM, int BN, int WM, int WN, bool CIN8>
 static int launch_conv(const ConvArgs& a, int splits, hipStream_t st, int batch = 1) {
-  constexpr size_t lds = (size_t)2 * (BM + BN) * (32 + 4) * sizeof(float);
+  constexpr size_t lds = (size_t)2 * BM * (32 + 4) * sizeof(float);  // A tiles only: the weights go global -> registers
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<BM, BN, WM, WN, CIN8>),

@@ -26,6 +26,12 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ A, const floa
   const float* gb = B + ((long)blockIdx.y * BN + srow) * 32 + q * 4;
   const int a_off = (wm * 32 * TM + (lane & 31)) * LDK + 4 * (lane >> 5);
   const int b_off = (wn * 32 * TN + (lane & 31)) * LDK + 4 * (lane >> 5);
+  // FLAGS & 16: B fragments straight from global memory (packed [chunk][N][32]) into registers, no LDS staging for B
+  const float* gbf = B + ((long)blockIdx.y * BN + wn * 32 * TN + (lane & 31)) * 32 + 4 * (lane >> 5);
+  const long bchunk = (long)32 * 64 * TN * gridDim.y;
+  float4 fbd[4][TN], fbn[4][TN];
+  for (int s4 = 0; s4 < 4; ++s4)
+    for (int j = 0; j < TN; ++j) fbd[s4][j] = fbn[s4][j] = make_float4(1.f, 1.f, 1.f, 1.f);
   int buf = 0;
   float4 fa[2][TM], fb[2][TN];
   for (int i = 0; i < TM; ++i) fa[0][i] = fa[1][i] = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -36,10 +42,18 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ A, const floa
     if (FLAGS & 1) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float4*>(cA + 32 * i * LDK);
+      if (!(FLAGS & 16)) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float4*>(cB + 32 * j * LDK);
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float4*>(cB + 32 * j * LDK);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (FLAGS & 16) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fbn[s4][j] = *reinterpret_cast<const float4*>(gbf + (long)(kc + 1 < nchunks ? kc + 1 : kc) * bchunk + (long)j * 32 * 32 + 8 * s4);
+    }
     if (FLAGS & 8) {  // two-deep: what was loaded one chunk ago moves to the store registers, new loads go out now
 #pragma unroll
       for (int i = 0; i < 2 * TM; ++i) ra[i] = ra2[i];
@@ -63,18 +77,21 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ A, const floa
       if ((FLAGS & 1) && s + 1 < 4) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const float4*>(cA + 32 * i * LDK + 8 * (s + 1));
+        if (!(FLAGS & 16)) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const float4*>(cB + 32 * j * LDK + 8 * (s + 1));
+          for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const float4*>(cB + 32 * j * LDK + 8 * (s + 1));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
+          const float4 bq = (FLAGS & 16) ? fbd[s][j] : fb[cur][j];
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, bq.x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, bq.y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, bq.z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, bq.w, acc[i][j], 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
       if ((FLAGS & 2) && s == 2) {
@@ -82,14 +99,22 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ A, const floa
         float* dB = sB + (buf ^ 1) * BN * LDK;
 #pragma unroll
         for (int i = 0; i < 2 * TM; ++i) *reinterpret_cast<float4*>(dA + (srow + 32 * i) * LDK + q * 4) = ra[i];
+        if (!(FLAGS & 16)) {
 #pragma unroll
-        for (int i = 0; i < 2 * TN; ++i) *reinterpret_cast<float4*>(dB + (srow + 32 * i) * LDK + q * 4) = rb[i];
+          for (int i = 0; i < 2 * TN; ++i) *reinterpret_cast<float4*>(dB + (srow + 32 * i) * LDK + q * 4) = rb[i];
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (FLAGS & 2) {
       __syncthreads();
       buf ^= 1;
+    }
+    if (FLAGS & 16) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fbd[s4][j] = fbn[s4][j];
     }
   }
   float sacc = 0.f;
@@ -128,7 +153,7 @@ void run(int mt, int nt, int nchunks) {
 
 int main() {
   // conv3_1-like: M=76800, N=256, K=2304
-  run<0, 1, 1>(1200, 4, 72); run<1, 1, 1>(1200, 4, 72); run<3, 1, 1>(1200, 4, 72); run<7, 1, 1>(1200, 4, 72); run<15, 1, 1>(1200, 4, 72);
-  run<0, 2, 2>(600, 2, 72); run<1, 2, 2>(600, 2, 72); run<3, 2, 2>(600, 2, 72); run<7, 2, 2>(600, 2, 72); run<15, 2, 2>(600, 2, 72);
+  run<0, 1, 1>(1200, 4, 72); run<1, 1, 1>(1200, 4, 72); run<3, 1, 1>(1200, 4, 72); run<7, 1, 1>(1200, 4, 72); run<15, 1, 1>(1200, 4, 72); run<23, 1, 1>(1200, 4, 72); run<31, 1, 1>(1200, 4, 72);
+  run<0, 2, 2>(600, 2, 72); run<1, 2, 2>(600, 2, 72); run<3, 2, 2>(600, 2, 72); run<7, 2, 2>(600, 2, 72); run<15, 2, 2>(600, 2, 72); run<23, 2, 2>(600, 2, 72); run<31, 2, 2>(600, 2, 72);
   return 0;
 }
