@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--cfg", default=os.path.join(PKG, "experiments", "deepim", "cfgs", "deepim_hip_LM_ape_test.yaml"))
     ap.add_argument("--subdiv", type=int, default=5, help="icosphere subdivisions of the synthetic mesh (5 = 20480 triangles)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                    "multi-rank path on a box with fewer GPUs than ranks, together with DIM_BENCH_DEVICE)")
     ap.add_argument("--no-winograd", action="store_true", help="run conv3_1/conv4_1/conv5_1/conv6_1 through the direct kernel too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--autotune", action="store_true", help="time tile/split-K candidates per layer first (untimed); default: fixed plan")
@@ -97,14 +99,18 @@ def main():
         raise SystemExit("--gpus {} but WORLD_SIZE {}".format(args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the refinement path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:{}".format(local_rank)
+    dev_index = int(os.environ.get("DIM_BENCH_DEVICE", local_rank))  # rehearsal only: several ranks on one card
+    torch.cuda.set_device(dev_index)
+    dev = "cuda:{}".format(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from deepim.config.config import config as cfg, update_config
     from deepim.core.tester import Predictor, Refiner
