@@ -48,11 +48,16 @@ def train_net(args):
     dev_id = gpu_ids[int(os.environ.get("LOCAL_RANK", "0")) % len(gpu_ids)] if world > 1 else gpu_ids[0]
     torch.cuda.set_device(dev_id)
     device = "cuda:{}".format(dev_id)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        backend = os.environ.get("DIM_DIST_BACKEND", "nccl")  # gloo only to rehearse several ranks on one card
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     logger, final_output_path = create_logger(config.output_path, args.cfg, config.dataset.image_set, args.temp)
     prefix = os.path.join(final_output_path, config.TRAIN.model_prefix)
@@ -115,6 +120,14 @@ def train_net(args):
             name = save_checkpoint(prefix, epoch + 1, mod.get_params(), {})
             mod.save_optimizer_states("%s-%04d.states.npz" % (prefix, epoch + 1))
             print("saved {}".format(name))
+    if dist is not None:
+        # every rank applied the same summed gradient to the same weights: the replicas must be bit-identical
+        digest = torch.stack([mod.flat_w.double().sum(), mod.flat_w.double().abs().sum()]).cpu()
+        all_d = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(all_d, digest)
+        assert all(torch.equal(all_d[0], d) for d in all_d), "parameter replicas diverged across ranks: {}".format(all_d)
+        if rank == 0:
+            print("replicas identical on {} ranks (digest {:.9e})".format(world, float(all_d[0][0])))
     return mod
 
 
