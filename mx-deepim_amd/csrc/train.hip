@@ -200,19 +200,30 @@ __global__ __launch_bounds__(256) void upsample16_bwd_kernel(const float* __rest
 }
 
 // small-Cout conv backward, data: dX[pix][ci] (+)= sum_{co,kh,kw} dY[pix - tap][co] * W[co][ci][kh][kw]   (stride 1)
-// one thread per (pixel, 4 channels); w in MXNet layout (Cout,Cin,KH,KW)
-__global__ void conv_small_cout_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int H,
-                                             int W, int Cin, int dx_cstride, int Cout, int KH, int KW, int pad, int accumulate) {
+// one thread per (pixel, 4 channels).  wt = the weight transposed to [tap][co][CinPad4] (ci contiguous: one float4 per (tap, co);
+// reading the MXNet layout directly was a 9-float-stride gather per channel)
+__global__ void small_cout_transpose_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int CinPad, int taps) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  int c4n = (Cin + 3) / 4;
+  if (idx >= (long)taps * Cout * CinPad) return;
+  int ci = (int)(idx % CinPad);
+  long t = idx / CinPad;
+  int co = (int)(t % Cout), tap = (int)(t / Cout);
+  wt[idx] = ci < Cin ? w[((long)co * Cin + ci) * taps + tap] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void conv_small_cout_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wt,
+                                                                    float* __restrict__ dx, int N, int H, int W, int Cin, int CinPad,
+                                                                    int dx_cstride, int Cout, int KH, int KW, int pad, int accumulate) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4n = CinPad / 4;
   long total = (long)N * H * W * c4n;
   if (idx >= total) return;
-  int c0 = (int)(idx % c4n) * 4;
+  const int c0 = (int)(idx % c4n) * 4;
   long pix = idx / c4n;
   int x = (int)(pix % W);
   int y = (int)((pix / W) % H);
   int n = (int)(pix / ((long)W * H));
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int kh = 0; kh < KH; ++kh) {
     int oy = y + pad - kh;
     if ((unsigned)oy >= (unsigned)H) continue;
@@ -220,43 +231,71 @@ __global__ void conv_small_cout_dgrad_kernel(const float* __restrict__ dy, const
       int ox = x + pad - kw;
       if ((unsigned)ox >= (unsigned)W) continue;
       const float* g = dy + ((long)(n * H + oy) * W + ox) * Cout;
+      const float* wrow = wt + ((long)(kh * KW + kw) * Cout) * CinPad + c0;
       for (int co = 0; co < Cout; ++co) {
-        float gv = g[co];
-        for (int j = 0; j < 4; ++j)
-          if (c0 + j < Cin) acc[j] = fmaf(gv, w[(((long)co * Cin + c0 + j) * KH + kh) * KW + kw], acc[j]);
+        const float gv = g[co];
+        const float4 wv = *reinterpret_cast<const float4*>(wrow + (long)co * CinPad);
+        acc.x = fmaf(gv, wv.x, acc.x);
+        acc.y = fmaf(gv, wv.y, acc.y);
+        acc.z = fmaf(gv, wv.z, acc.z);
+        acc.w = fmaf(gv, wv.w, acc.w);
       }
     }
   }
   float* o = dx + pix * dx_cstride + c0;
+  const float av[4] = {acc.x, acc.y, acc.z, acc.w};
   for (int j = 0; j < 4; ++j)
-    if (c0 + j < Cin) o[j] = accumulate ? o[j] + acc[j] : acc[j];
+    if (c0 + j < Cin) o[j] = accumulate ? o[j] + av[j] : av[j];
 }
 
 // small-Cout conv backward, weights: dW[co][ci][kh][kw] = sum_pix dY[pix][co] * X[pix + tap][ci]; db[co] = sum_pix dY[pix][co]
-// stage 1: grid (pixel chunks of 128, KH*KW, Cout); thread = ci (strided), X rows are contiguous over ci (coalesced), dY broadcast;
-//          partial[chunk][co][tap][ci] (deterministic, no atomics);  stage 2 sums the chunks.
+//   = sum over X pixels q of X[q][ci] * dY[q - tap][co]: each X row is read ONCE per workgroup (coalesced over ci) and scattered to
+//   the KH*KW*Cout accumulators of the thread; the dY values of the q - tap neighbours are wave-uniform scalars.
+// stage 1: grid (pixel chunks, ceil(Cin/256)); partial[chunk][co][tap][ci] (deterministic, no atomics);  stage 2 sums the chunks.
+template <int COUT, int TAPS>
 __global__ __launch_bounds__(256) void conv_small_cout_wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                             float* __restrict__ partial, float* __restrict__ partial_b,
-                                                                            int N, int H, int W, int Cin, int in_cstride, int Cout, int KH,
-                                                                            int KW, int pad, int chunk_px) {
-  const int chunk = blockIdx.x, tap = blockIdx.y, kh = tap / KW, kw = tap % KW, co = blockIdx.z;
+                                                                            int N, int H, int W, int Cin, int in_cstride, int KH, int KW,
+                                                                            int pad, int chunk_px) {
+  const int chunk = blockIdx.x;
+  const int ci = blockIdx.y * 256 + threadIdx.x;
   const long P = (long)N * H * W;
   const long p0 = (long)chunk * chunk_px, p1 = min(P, p0 + chunk_px);
-  float sb = 0.f;
-  for (int ci = threadIdx.x; ci < Cin; ci += blockDim.x) {
-    float s = 0.f;
-    for (long p = p0; p < p1; ++p) {
-      int xx = (int)(p % W);
-      int y = (int)((p / W) % H);
-      int iy = y - pad + kh, ix = xx - pad + kw;
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        s = fmaf(dy[p * Cout + co], x[(p + (long)(kh - pad) * W + (kw - pad)) * in_cstride + ci], s);
+  float acc[TAPS][COUT];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[t][c] = 0.f;
+  // dW[tap] pairs output pixel p with input pixel q = p + (tap - pad): walk the INPUT pixels q that any p of the chunk touches
+  // would double-count across chunks, so walk output pixels p and read X at the 9 shifted rows -- but only the rows of this
+  // thread's ci, and with the dY scalars hoisted: X[p + shift] is re-read 9x from L1/L2 within the chunk, never from HBM.
+  for (long p = p0; p < p1; ++p) {
+    const int xx = (int)(p % W);
+    const int y = (int)((p / W) % H);
+    float g[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) g[c] = dy[p * COUT + c];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int kh = t / KW, kw = t - kh * KW;
+      const int iy = y - pad + kh, ix = xx - pad + kw;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && ci < Cin) {
+        const float xv = x[(p + (long)(kh - pad) * W + (kw - pad)) * in_cstride + ci];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[t][c] = fmaf(g[c], xv, acc[t][c]);
+      }
     }
-    partial[(((long)chunk * Cout + co) * KH * KW + tap) * Cin + ci] = s;
   }
-  if (tap == 0 && threadIdx.x == 0) {
-    for (long p = p0; p < p1; ++p) sb += dy[p * Cout + co];
-    partial_b[(long)chunk * Cout + co] = sb;
+  if (ci < Cin) {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) partial[(((long)chunk * COUT + c) * TAPS + t) * Cin + ci] = acc[t][c];
+  }
+  if (blockIdx.y == 0 && threadIdx.x < COUT) {
+    float sb = 0.f;
+    for (long p = p0; p < p1; ++p) sb += dy[p * COUT + threadIdx.x];
+    partial_b[(long)chunk * COUT + threadIdx.x] = sb;
   }
 }
 
@@ -456,7 +495,8 @@ int dim_upsample16_bwd(const float* dout_nchw, const float* w_c1_32_32, float* d
 
 long dim_conv_small_cout_bwd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW) {
   long nchunk = ceil_div((long)N * H * W, 128);
-  return nchunk * ((long)Cout * KH * KW * Cin + Cout);
+  long cin_pad = (Cin + 3) / 4 * 4;
+  return nchunk * ((long)Cout * KH * KW * Cin + Cout) + 4 + (long)KH * KW * Cout * cin_pad;  // chunk partials + transposed weight
 }
 
 int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw, float* dx, float* dw_oihw, float* db, float* workspace,
@@ -464,17 +504,28 @@ int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw
                             int accumulate_dx, void* stream) {
   if (N == 0) return DIM_OK;
   DIM_REQUIRE(x && dy && w_oihw && dw_oihw && workspace, "null pointer");
+  DIM_REQUIRE(KH * KW == 9 && (Cout == 1 || Cout == 2), "small-Cout backward is built for 3x3 kernels with 1 or 2 output channels");
   hipStream_t st = as_stream(stream);
-  if (dx) {
-    long total = (long)N * H * W * ((Cin + 3) / 4);
-    hipLaunchKernelGGL(conv_small_cout_dgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, dy, w_oihw, dx, N, H, W, Cin, dx_cstride,
-                       Cout, KH, KW, pad, accumulate_dx);
-  }
   const int nchunk = ceil_div((long)N * H * W, 128);
+  const int CinPad = (Cin + 3) / 4 * 4;
   float* partial = workspace;
   float* partial_b = workspace + (long)nchunk * Cout * KH * KW * Cin;
-  hipLaunchKernelGGL(conv_small_cout_wgrad_partial_kernel, dim3(nchunk, KH * KW, Cout), dim3(256), 0, st, x, dy, partial, partial_b, N, H,
-                     W, Cin, in_cstride, Cout, KH, KW, pad, 128);
+  float* wt = workspace + (((long)nchunk * Cout * KH * KW * Cin + (long)nchunk * Cout + 3) / 4) * 4;  // 16-byte aligned
+  if (dx) {
+    DIM_REQUIRE(dx_cstride % 4 == 0, "dx_cstride must be a multiple of 4");
+    long wtot = (long)KH * KW * Cout * CinPad;
+    hipLaunchKernelGGL(small_cout_transpose_weight_kernel, dim3(ceil_div(wtot, 256)), dim3(256), 0, st, w_oihw, wt, Cout, Cin, CinPad, KH * KW);
+    long total = (long)N * H * W * (CinPad / 4);
+    hipLaunchKernelGGL(conv_small_cout_dgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, dy, wt, dx, N, H, W, Cin, CinPad,
+                       dx_cstride, Cout, KH, KW, pad, accumulate_dx);
+  }
+  dim3 grid(nchunk, ceil_div(Cin, 256));
+  if (Cout == 2)
+    hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<2, 9>), grid, dim3(256), 0, st, x, dy, partial, partial_b, N, H, W, Cin,
+                       in_cstride, KH, KW, pad, 128);
+  else
+    hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<1, 9>), grid, dim3(256), 0, st, x, dy, partial, partial_b, N, H, W, Cin,
+                       in_cstride, KH, KW, pad, 128);
   long per = (long)Cout * KH * KW * Cin;
   hipLaunchKernelGGL(conv_small_cout_wgrad_final_kernel, dim3(ceil_div(per, 256)), dim3(256), 0, st, partial, partial_b, dw_oihw, db,
                      nchunk, Cin, Cout, KH, KW);
