@@ -493,8 +493,10 @@ int dim_upsample16_bwd(const float* dout_nchw, const float* w_c1_32_32, float* d
   return check_launch("upsample16_bwd");
 }
 
+static const int kSmallCoutChunkPx = 32;  // output pixels per workgroup of the wgrad partial pass (600 x 4 workgroups at 16x30x40)
+
 long dim_conv_small_cout_bwd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW) {
-  long nchunk = ceil_div((long)N * H * W, 128);
+  long nchunk = ceil_div((long)N * H * W, kSmallCoutChunkPx);
   long cin_pad = (Cin + 3) / 4 * 4;
   return nchunk * ((long)Cout * KH * KW * Cin + Cout) + 4 + (long)KH * KW * Cout * cin_pad;  // chunk partials + transposed weight
 }
@@ -506,7 +508,7 @@ int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw
   DIM_REQUIRE(x && dy && w_oihw && dw_oihw && workspace, "null pointer");
   DIM_REQUIRE(KH * KW == 9 && (Cout == 1 || Cout == 2), "small-Cout backward is built for 3x3 kernels with 1 or 2 output channels");
   hipStream_t st = as_stream(stream);
-  const int nchunk = ceil_div((long)N * H * W, 128);
+  const int nchunk = ceil_div((long)N * H * W, kSmallCoutChunkPx);
   const int CinPad = (Cin + 3) / 4 * 4;
   float* partial = workspace;
   float* partial_b = workspace + (long)nchunk * Cout * KH * KW * Cin;
@@ -522,10 +524,10 @@ int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw
   dim3 grid(nchunk, ceil_div(Cin, 256));
   if (Cout == 2)
     hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<2, 9>), grid, dim3(256), 0, st, x, dy, partial, partial_b, N, H, W, Cin,
-                       in_cstride, KH, KW, pad, 128);
+                       in_cstride, KH, KW, pad, kSmallCoutChunkPx);
   else
     hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<1, 9>), grid, dim3(256), 0, st, x, dy, partial, partial_b, N, H, W, Cin,
-                       in_cstride, KH, KW, pad, 128);
+                       in_cstride, KH, KW, pad, kSmallCoutChunkPx);
   long per = (long)Cout * KH * KW * Cin;
   hipLaunchKernelGGL(conv_small_cout_wgrad_final_kernel, dim3(ceil_div(per, 256)), dim3(256), 0, st, partial, partial_b, dw_oihw, db,
                      nchunk, Cin, Cout, KH, KW);
