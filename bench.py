@@ -172,7 +172,9 @@ def main():
     TILE_SYM = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 128, 2, 4"}
     for name, evs in events.items():
         info = net.layer_info[name]
-        for tag, e0, e1 in evs:
+        for ev in evs:
+            tag, e0, e1 = ev[:3]
+            n_launch = ev[3] if len(ev) > 3 else 1  # auto mode: two conv launches (+ a reduce) inside one event pair
             if tag == "conv":  # the symbol rocprofv3 --kernel-trace reports for this launch
                 if info.get("winograd"):  # batched GEMM of the Winograd path: the multiply-adds that launch really executes
                     kname = "dim::conv_fwd_kernel<{}, false>".format(TILE_SYM[info["wino_tile"]])
@@ -189,7 +191,7 @@ def main():
             k["ms"] += e0.elapsed_time(e1)
             k["flops"] += flops
             k["bytes"] += nbytes
-            k["launches"] += 1
+            k["launches"] += n_launch
             if name not in k["layers"]:
                 k["layers"].append(name)
     dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])

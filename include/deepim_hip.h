@@ -142,6 +142,11 @@ int dim_splitk_reduce(const float* slabs, const float* bias, float* y, long M, i
  * `out_coff` of rows `out_cstride` wide (concat buffers), and -- when osy > 0 -- scattered to
  * (oy,ox) = (ho*osy + ooy, wo*osx + oox) inside an OH x OW map (used for the phases of a deconvolution + Crop). */
 /* Ho/Wo > 0: explicit output grid (asymmetric padding); pad_w >= 0: horizontal padding differs from pad; accumulate: y += result */
+/* splits == 0 in dim_conv2d_fwd = "auto": all workgroups of a launch are equal, so a launch takes ceil(tiles / CUs) tile-times
+ * on the busiest CU (1200 tiles on 256 CUs = 4.69 -> 5: 6 % of the chip idles).  Auto runs k*CUs tiles as one launch and the rest
+ * as a split-K launch of proportionally shorter workgroups + reduce.  Needs workspace = dim_conv2d_workspace_floats(..., splits=0).
+ * dim_conv2d_tail_plan reports the plan for a shape: first tile of the tail and its split count (1 = single launch). */
+int dim_conv2d_tail_plan(int M, int Cout, int Cin, int KH, int KW, int tile, int* tail_begin_tile, int* tail_splits);
 int dim_conv2d_fwd_ex(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int in_cstride,
                       int Cout, int KH, int KW, int stride, int pad, float slope, int tile, int out_cstride, int out_coff, int OH,
                       int OW, int osy, int osx, int ooy, int oox, int Ho, int Wo, int pad_w, int accumulate, void* stream);

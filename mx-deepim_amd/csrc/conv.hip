@@ -42,6 +42,9 @@ struct ConvArgs {
   unsigned x_bytes, w_bytes;  // extents of x / w for the buffer descriptors (loads past them return 0)
   int xcd_chunk;   // > 0: workgroup id -> tile remap that keeps consecutive tiles on one XCD (see conv_fwd_kernel)
   long bx, bw, by; // batched launch (gridDim.y > 1): element strides of x / w / y between the problems (Winograd: 16 GEMMs)
+  int tile_off;    // first tile of this launch (tail launch of an "auto" workload)
+  int slab_row0;   // split-K slabs hold rows [slab_row0, M)
+  long slab_stride;  // elements between the slabs of consecutive splits
 };
 
 template <int BM, int BN, int WM, int WN, bool CIN8>
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   // dealt round-robin to the 8 XCDs (each with its own L2), so with xcd_chunk = tiles/8 the id is remapped such that XCD k
   // walks tiles [k*chunk, (k+1)*chunk) in order: the A tile is fetched into ONE L2 and re-used there by its N tiles, and
   // neighbouring pixel tiles (which share the 3x3 halo rows) follow on the same XCD.
-  int id = blockIdx.x;
+  int id = blockIdx.x + a.tile_off;
   if (a.xcd_chunk > 0) id = (id & 7) * a.xcd_chunk + (id >> 3);
   const int ntiles_n = a.Cout / BN;
   const int mtile = id / ntiles_n;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   const bool acc_out = final && a.accumulate;
   const int mrow = m0 + wm * (BM / WM) + 4 * khalf;
   if (!final || a.dense_out) {
-    float* out = (final ? yb + a.out_coff : yb + (long)split * a.M * a.Cout) + (long)mrow * ldc + ncol;
+    float* out = (final ? yb + a.out_coff + (long)mrow * ldc : yb + (long)split * a.slab_stride + (long)(mrow - a.slab_row0) * ldc) + ncol;
     if (m0 + BM <= a.M) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict_
 }
 
 template <int BM, int BN, int WM, int WN, bool CIN8>
-static int launch_conv(const ConvArgs& a, int splits, hipStream_t st, int batch = 1) {
+static int launch_conv(const ConvArgs& a, int splits, hipStream_t st, int batch = 1, int tile_begin = 0, int tile_count = -1) {
   constexpr size_t lds = (size_t)2 * BM * (32 + 4) * sizeof(float);  // A tiles only: the weights go global -> registers
   static bool attr_set = false;
   if (!attr_set) {
@@ -589,8 +592,10 @@ static int launch_conv(const ConvArgs& a, int splits, hipStream_t st, int batch 
   const int tiles = ceil_div(a.M, BM) * (a.Cout / BN);
   ConvArgs b = a;
   static const int xcd_mode = getenv("DIM_CONV_XCD") ? atoi(getenv("DIM_CONV_XCD")) : 0;  // experiment switch
-  b.xcd_chunk = (xcd_mode > 0 && tiles % 8 == 0 && tiles >= xcd_mode) ? tiles / 8 : 0;
-  dim3 grid(tiles, batch, splits);
+  const bool whole = tile_begin == 0 && (tile_count < 0 || tile_count == tiles);
+  b.xcd_chunk = (whole && xcd_mode > 0 && tiles % 8 == 0 && tiles >= xcd_mode) ? tiles / 8 : 0;
+  b.tile_off = tile_begin;
+  dim3 grid(tile_count < 0 ? tiles : tile_count, batch, splits);
   hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, CIN8>), grid, dim3(WM * WN * 64), lds, st, b);
   return check_launch("conv_fwd");
 }
@@ -637,10 +642,59 @@ int dim_fc_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, i
   return check_launch("pack_fc_weight");
 }
 
+// splits == 0 ("auto", see dim_conv2d_fwd): room for the split tail (fewer than one tile per CU on a 304-CU part at most, <= 8 slabs)
+static const long kTailWorkspaceFloats = 8L * 304 * 128 * 128;
+
 long dim_conv2d_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int splits) {
-  if (splits <= 1) return 0;
   int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  if (splits == 0) {
+    long full = 8L * N * Ho * Wo * Cout;
+    return full < kTailWorkspaceFloats ? full : kTailWorkspaceFloats;
+  }
+  if (splits <= 1) return 0;
   return (long)splits * N * Ho * Wo * Cout;
+}
+
+// Plan of the "auto" mode.  All workgroups of a launch are equal, so the launch takes ceil(tiles / CUs) tile-times on the busiest
+// CU while the average CU has tiles / CUs of work: conv3 at batch 16 = 1200 tiles on 256 CUs = 4.69 -> 5, i.e. 6 % of the machine
+// idles.  The plan runs k*CUs tiles (k whole tiles per CU) as one launch and the remaining `tail` tiles as a second, split-K
+// launch of tail*s workgroups of 1/s the length, s chosen to minimise ceil(tail*s / CUs) / s; the slabs are summed by
+// dim_splitk_reduce.  -> first tile of the tail (a multiple of nt, so the tail is a row range) and s (1 = single launch).
+static void conv_tail_plan(int M, int Cout, int nchunks, int tile, int* tail_begin, int* tail_splits) {
+  const int BM = tile == 3 ? 64 : 128, BN = (tile == 3 || tile == 2) ? 64 : 128;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+      n_cu = 256;
+  }
+  const int mt = ceil_div(M, BM), nt = Cout / BN, tiles = mt * nt;
+  *tail_begin = tiles;
+  *tail_splits = 1;
+  const int k = tiles / n_cu;
+  if (k < 1) return;                       // small layers: plain split-K chosen by the caller
+  const int full = (k * n_cu) / nt * nt;
+  const int tail = tiles - full;
+  if (tail == 0) return;
+  const double single = (double)ceil_div(tiles, n_cu);
+  double best = 1e30;
+  int best_s = 1;
+  for (int s = 2; s <= 8 && s * 4 <= nchunks; ++s) {
+    if ((long)s * (M - full / nt * BM) * Cout > kTailWorkspaceFloats) break;
+    double t = (double)ceil_div((long)tail * s, n_cu) / s + 0.02 * s;  // 2 % of a tile-time per slab: extra prologues, slab traffic, reduce
+    if (t < best) { best = t; best_s = s; }
+  }
+  if (k + best < single * 0.98) {
+    *tail_begin = full;
+    *tail_splits = best_s;
+  }
+}
+
+int dim_conv2d_tail_plan(int M, int Cout, int Cin, int KH, int KW, int tile, int* tail_begin_tile, int* tail_splits) {
+  DIM_REQUIRE(tail_begin_tile && tail_splits, "null pointer");
+  if (tile == 0) tile = (Cout % 128 == 0 && Cin != 8 && M >= 128) ? 4 : 3;
+  conv_tail_plan(M, Cout, (Cin == 8) ? KH * 2 : KH * KW * (Cin / 32), tile, tail_begin_tile, tail_splits);
+  return DIM_OK;
 }
 
 int dim_splitk_reduce(const float* slabs, const float* bias, float* y, long M, int Cout, int splits, float slope, void* stream) {
@@ -697,6 +751,7 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   a.nchunks = (Cin == 8) ? KH * 2 : KH * KW * (Cin / 32);
   DIM_REQUIRE((long)a.nchunks * Cout * 32 * 4 < (1L << 31), "packed weights too large for 32-bit byte offsets");
   a.w_bytes = (unsigned)((long)a.nchunks * Cout * 32 * 4);
+  const bool auto_split = splits == 0;
   if (splits < 1) splits = 1;
   if (splits > a.nchunks) splits = a.nchunks;
   a.chunks_per_split = (a.nchunks + splits - 1) / splits;
@@ -705,6 +760,9 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   DIM_REQUIRE(splits == 1 || !ex || (a.dense_out && a.out_cstride == Cout && a.out_coff == 0),
               "split-K writes a dense [M][Cout] result: not available with a strided / scattered output");
   a.y = splits > 1 ? workspace : y;
+  a.tile_off = 0;
+  a.slab_row0 = 0;
+  a.slab_stride = (long)N * a.Ho * a.Wo * Cout;
   const int batch = ex ? ex->batch : 1;
   a.bx = ex ? ex->bx : 0; a.bw = ex ? ex->bw : 0; a.by = ex ? ex->by : 0;
   DIM_REQUIRE(batch == 1 || splits == 1, "batched launch does not combine with split-K");
@@ -714,21 +772,43 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   if (tile == 0) {
     tile = (Cout % 128 == 0 && Cin != 8 && a.M >= 128) ? 4 : 3;  // same rule as lib/hip/ops.py conv_auto_plan
   }
-  int rc;
-  if (Cin == 8) {
-    DIM_REQUIRE(tile != 1 || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
-    DIM_REQUIRE(tile != 4, "tile 4 (128x128, 8 waves) is not built for the 8-channel layer");
-    DIM_REQUIRE(batch == 1, "batched launch is not built for the 8-channel layer");
-    if (tile == 1) rc = launch_conv<128, 128, 2, 2, true>(a, splits, st);
-    else if (tile == 2) rc = launch_conv<128, 64, 2, 2, true>(a, splits, st);
-    else rc = launch_conv<64, 64, 2, 2, true>(a, splits, st);
-  } else {
-    DIM_REQUIRE((tile != 1 && tile != 4) || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
-    if (tile == 4) rc = launch_conv<128, 128, 2, 4, false>(a, splits, st, batch);
-    else if (tile == 1) rc = launch_conv<128, 128, 2, 2, false>(a, splits, st, batch);
-    else if (tile == 2) rc = launch_conv<128, 64, 2, 2, false>(a, splits, st, batch);
-    else rc = launch_conv<64, 64, 2, 2, false>(a, splits, st, batch);
+  DIM_REQUIRE((tile != 1 && tile != 4) || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
+  DIM_REQUIRE(Cin != 8 || tile != 4, "tile 4 (128x128, 8 waves) is not built for the 8-channel layer");
+  DIM_REQUIRE(Cin != 8 || batch == 1, "batched launch is not built for the 8-channel layer");
+  auto launch = [&](const ConvArgs& args, int nsplit, int t0, int tn) -> int {
+    if (Cin == 8) {
+      if (tile == 1) return launch_conv<128, 128, 2, 2, true>(args, nsplit, st, 1, t0, tn);
+      if (tile == 2) return launch_conv<128, 64, 2, 2, true>(args, nsplit, st, 1, t0, tn);
+      return launch_conv<64, 64, 2, 2, true>(args, nsplit, st, 1, t0, tn);
+    }
+    if (tile == 4) return launch_conv<128, 128, 2, 4, false>(args, nsplit, st, batch, t0, tn);
+    if (tile == 1) return launch_conv<128, 128, 2, 2, false>(args, nsplit, st, batch, t0, tn);
+    if (tile == 2) return launch_conv<128, 64, 2, 2, false>(args, nsplit, st, batch, t0, tn);
+    return launch_conv<64, 64, 2, 2, false>(args, nsplit, st, batch, t0, tn);
+  };
+  // "auto" (splits == 0): whole tiles per CU in one launch, the remainder as a split-K launch + reduce (conv_tail_plan)
+  if (auto_split && batch == 1 && workspace && a.dense_out && a.out_cstride == Cout && a.out_coff == 0 && !a.accumulate && !partial_only) {
+    int tail_begin = 0, ts = 1;
+    conv_tail_plan(a.M, Cout, a.nchunks, tile, &tail_begin, &ts);
+    if (ts >= 2) {
+      const int BMt = tile == 3 ? 64 : 128, BNt = (tile == 3 || tile == 2) ? 64 : 128;
+      const int nt = Cout / BNt, tiles = ceil_div(a.M, BMt) * nt;
+      const int row0 = tail_begin / nt * BMt;
+      int rc = launch(a, 1, 0, tail_begin);
+      if (rc != DIM_OK) return rc;
+      ConvArgs t = a;
+      t.y = workspace;
+      t.slab_row0 = row0;
+      t.slab_stride = (long)(a.M - row0) * Cout;
+      t.chunks_per_split = (a.nchunks + ts - 1) / ts;
+      const int nsplit = (a.nchunks + t.chunks_per_split - 1) / t.chunks_per_split;
+      DIM_REQUIRE(nsplit * t.slab_stride <= kTailWorkspaceFloats, "tail workspace bound exceeded");
+      rc = launch(t, nsplit, tail_begin, tiles - tail_begin);
+      if (rc != DIM_OK) return rc;
+      return dim_splitk_reduce(workspace, bias, y + (long)row0 * Cout, (long)(a.M - row0), Cout, nsplit, slope, stream);
+    }
   }
+  int rc = launch(a, splits, 0, -1);
   if (rc != DIM_OK) return rc;
   if (splits > 1 && !partial_only) return dim_splitk_reduce(workspace, bias, y, (long)a.M, Cout, splits, slope, stream);
   return DIM_OK;

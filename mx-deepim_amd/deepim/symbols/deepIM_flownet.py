@@ -197,7 +197,7 @@ class FlowNetHip(object):
             self.conv_plan[name] = (tile, splits)
             self.layer_info[name] = dict(M=B * ho * wo, K=c * k * k, N=cout, flops=2 * B * ho * wo * cout * c * k * k, tile=tile,
                                          splits=splits, cin=c, min_bytes=4 * (B * h * w * c + cout * c * k * k + B * ho * wo * cout))
-            if splits > 1:
+            if splits != 1:
                 max_ws = max(max_ws, ops.lib().dim_conv2d_workspace_floats(B, h, w, c, cout, k, k, s, p, splits))
             if name in self.wino:
                 # GEMM rows = tiles; 128x128 workgroup tiles once there are enough of them, 64x64 for the small maps

@@ -150,11 +150,23 @@ def conv_auto_plan(M, Cout, nchunks, cin=32):
     """default (tile, splits) when the caller does not autotune (tools/tune_conv.py, batch 16, MI355X): 128x128 tiles with 8 waves
     (tile 4) wherever Cout allows, split-K until the grid has ~900 workgroups; 64x64 tiles (tile 3) for Cout = 64 and the
     8-channel first layer."""
+    n_cu = 256
+
+    def best_split(tiles, smax):
+        # all workgroups of a launch are equal: the busiest CU gets ceil(tiles*s / CUs) of them, each 1/s of a tile-time long
+        # (+2 % of a tile-time per slab for the extra prologues, slab traffic and the reduce)
+        cands = [(-(-tiles * s // n_cu) / float(s) + 0.02 * s, s) for s in range(1, smax + 1) if s * 4 <= nchunks or s == 1]
+        return min(cands)[1]
+
     if Cout % 128 == 0 and cin != 8:
         tiles = -(-M // 128) * (Cout // 128)
-        return 4, max(1, min(6, int(round(900.0 / tiles)), nchunks))
+        if tiles >= n_cu:
+            return 4, 0      # auto: whole tiles per CU + split tail (dim_conv2d_fwd, splits == 0)
+        return 4, best_split(tiles, 8)
     blocks = -(-M // 64) * (Cout // 64)
-    return 3, max(1, min(8, int(round(2048.0 / blocks)), nchunks))
+    if blocks >= n_cu:
+        return 3, 0
+    return 3, best_split(blocks, 8)
 
 
 def copy(dst, src):
@@ -199,12 +211,15 @@ def conv2d_fwd_winograd(x_nhwc, Cin, w_packed, bias, Cout, slope=0.1, tile=0, ou
 
 def conv2d_fwd(x_nhwc, w_packed, bias, Cout, KH, KW, stride, pad, slope=0.1, splits=1, tile=0, out=None, workspace=None,
                events=None):
-    """events: optional list; when given, (kernel_tag, start_event, end_event) tuples are appended with HIP events recorded on the
-    launch stream around the conv kernel and (split-K) around the reduce kernel separately."""
+    """splits: 1 = one launch; > 1 = split-K through `workspace`; 0 = auto (whole tiles per CU in one launch, the remaining tiles
+    as a split-K launch + reduce; needs `workspace`, see dim_conv2d_fwd / dim_conv2d_tail_plan).
+    events: optional list; when given, (kernel_tag, start_event, end_event) tuples are appended with HIP events recorded on the
+    launch stream around the conv kernel and (split-K) around the reduce kernel separately (auto mode: one tuple for everything,
+    tag "conv", with a 4th element = number of conv-kernel launches inside)."""
     N, H, W, Cin = x_nhwc.shape
     Ho, Wo = conv_out_hw(H, W, KH, KW, stride, pad)
     out = out if out is not None else _new((N, Ho, Wo, Cout), x_nhwc)
-    if splits > 1 and workspace is None:
+    if splits != 1 and workspace is None:
         workspace = _new((lib().dim_conv2d_workspace_floats(N, H, W, Cin, Cout, KH, KW, stride, pad, splits),), x_nhwc)
     if events is not None:
         def ev():
@@ -223,7 +238,14 @@ def conv2d_fwd(x_nhwc, w_packed, bias, Cout, KH, KW, stride, pad, slope=0.1, spl
         else:
             check(lib().dim_conv2d_fwd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), dptr(workspace, f32), N,
                                        H, W, Cin, Cout, KH, KW, stride, pad, float(slope), splits, tile, current_stream()))
-            events.append(("conv", e0, ev()))
+            n_launch = 1
+            if splits == 0:
+                import ctypes
+
+                tb, ts = ctypes.c_int(0), ctypes.c_int(1)
+                check(lib().dim_conv2d_tail_plan(N * Ho * Wo, Cout, Cin, KH, KW, tile, ctypes.byref(tb), ctypes.byref(ts)))
+                n_launch = 2 if ts.value >= 2 else 1
+            events.append(("conv", e0, ev(), n_launch))
         return out
     check(lib().dim_conv2d_fwd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), dptr(workspace, f32), N, H, W,
                                Cin, Cout, KH, KW, stride, pad, float(slope), splits, tile, current_stream()))

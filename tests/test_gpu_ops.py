@@ -411,3 +411,33 @@ def test_conv3x3_winograd_vs_f64(hip_lib, shape):
     o = out.cpu().numpy()
     assert np.abs(o[..., 32:32 + Cout] - ref).max() <= 1e-4 * np.abs(ref).max() + 2e-5
     assert np.all(o[..., :32] == 7.0) and np.all(o[..., 32 + Cout:] == 7.0)
+
+
+@pytest.mark.parametrize("shape,tile", [((16, 60, 80, 64, 256, 3, 1, 1), 4), ((9, 120, 160, 32, 128, 3, 2, 1), 4), ((6, 96, 128, 32, 64, 3, 1, 1), 3)])
+def test_conv_auto_split_tail_vs_f64(hip_lib, shape, tile):
+    """splits = 0: whole tiles per CU in one launch + split-K tail (dim_conv2d_tail_plan confirms the two-launch path) vs float64"""
+    import ctypes
+
+    import torch.nn.functional as F
+    from lib.hip import ops
+
+    N, H, W, Cin, Cout, k, s, p = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (1.0 / np.sqrt(k * k * Cin))
+    b = torch.randn((Cout,), generator=g) * 0.1
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p), 0.1).permute(0, 2, 3, 1).numpy()
+    Ho, Wo = ref.shape[1:3]
+    tb, ts = ctypes.c_int(0), ctypes.c_int(1)
+    ops.check(ops.lib().dim_conv2d_tail_plan(N * Ho * Wo, Cout, Cin, k, k, tile, ctypes.byref(tb), ctypes.byref(ts)))
+    assert ts.value >= 2 and tb.value > 0, (tb.value, ts.value)
+    xd = x.permute(0, 2, 3, 1).contiguous().to("cuda:0")
+    wp = ops.conv2d_pack_weight(w.to("cuda:0"))
+    ws = torch.full((ops.lib().dim_conv2d_workspace_floats(N, H, W, Cin, Cout, k, k, s, p, 0),), float("nan"), device="cuda:0")
+    y = ops.conv2d_fwd(xd, wp, b.to("cuda:0"), Cout, k, k, s, p, slope=0.1, splits=0, tile=tile, workspace=ws).cpu().numpy()
+    assert np.isfinite(y).all()
+    assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max() + 2e-5
+    y1 = ops.conv2d_fwd(xd, wp, b.to("cuda:0"), Cout, k, k, s, p, slope=0.1, splits=1, tile=tile).cpu().numpy()
+    bm, bn = (128, 128) if tile == 4 else (64, 64)
+    head = tb.value // (Cout // bn) * bm                           # rows of the un-split part: bit-identical to the single launch
+    np.testing.assert_array_equal(y.reshape(-1, Cout)[:head], y1.reshape(-1, Cout)[:head])

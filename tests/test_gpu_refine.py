@@ -78,7 +78,12 @@ def test_refine_4iter_vs_oracle(setup, graph):
         o_poses, o_se3 = orefine.refine_pair(params, scene["models"][int(bl["class_index"][b])], blobs_b, scene["K"],
                                              cfg.network.PIXEL_MEANS, z3, o3, "CAMERA", test_iter=4)
         for it in range(4):
-            np.testing.assert_allclose(ref.se3_iter[it, b].cpu().numpy(), o_se3[it], atol=1e-3)
+            # the test graph emits the UN-normalised quaternion (|q| ~ 12 with this initialisation; RT_transform.py:143 normalises
+            # on use): compare the rotation it encodes and the translation at the north_star bar, not the raw scale
+            got = ref.se3_iter[it, b].cpu().numpy()
+            np.testing.assert_allclose(got[:4] / np.linalg.norm(got[:4]), o_se3[it][:4] / np.linalg.norm(o_se3[it][:4]), atol=1e-3)
+            np.testing.assert_allclose(got[4:], o_se3[it][4:], atol=1e-3)
+            np.testing.assert_allclose(got, o_se3[it], rtol=2e-3, atol=1e-3)
             np.testing.assert_allclose(poses[it, b], o_poses[it], atol=1e-3)
             # ADD of our final pose vs the oracle's final pose ("ADD(-S) vs reference" clause): far below 0.02*d
             e = pose_error.add(poses[it, b][:, :3].astype(np.float64), poses[it, b][:, 3].astype(np.float64), o_poses[it][:, :3],

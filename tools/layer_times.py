@@ -29,8 +29,8 @@ torch.cuda.synchronize()
 tot = 0.0
 for name, evs in events.items():
     info = net.layer_info[name]
-    conv = [e0.elapsed_time(e1) for tag, e0, e1 in evs if tag == "conv"]
-    red = [e0.elapsed_time(e1) for tag, e0, e1 in evs if tag != "conv"]
+    conv = [ev[1].elapsed_time(ev[2]) for ev in evs if ev[0] == "conv"]
+    red = [ev[1].elapsed_time(ev[2]) for ev in evs if ev[0] != "conv"]
     ms = sum(conv) / reps
     tot += ms + sum(red) / reps
     print("%-11s tile=%d splits=%d  conv %.4f ms  %.1f TF   reduce %.4f ms" % (name, info["tile"], info["splits"], ms, info["flops"] / ms / 1e9, sum(red) / reps))
