@@ -143,13 +143,14 @@ def conv_out_hw(H, W, KH, KW, stride, pad):
     return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
 
 
-TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64"}
+TILE_NAMES = {1: "128x128 (4 waves)", 2: "128x64", 3: "64x64", 4: "128x128 (8 waves)"}
 
 
 def conv_auto_plan(M, Cout, nchunks, cin=32):
     """default (tile, splits) when the caller does not autotune (tools/tune_conv.py, batch 16, MI355X): 128x128 tiles with 8 waves
-    (tile 4) wherever Cout allows, split-K until the grid has ~900 workgroups; 64x64 tiles (tile 3) for Cout = 64 and the
-    8-channel first layer."""
+    (tile 4) wherever Cout allows, 64x64 tiles (tile 3) for Cout = 64 and the 8-channel first layer.  splits: 0 (auto: whole tiles
+    per CU + split-K tail, decided inside the library) when every CU gets at least one tile, otherwise the split-K count that
+    minimises the busiest CU's share."""
     n_cu = 256
 
     def best_split(tiles, smax):
