@@ -299,23 +299,30 @@ __global__ __launch_bounds__(256) void conv_small_cout_wgrad_partial_kernel(cons
   }
 }
 
-__global__ void conv_small_cout_wgrad_final_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b, float* __restrict__ dw,
-                                                   float* __restrict__ db, int nchunk, int Cin, int Cout, int KH, int KW) {
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long per = (long)Cout * KH * KW * Cin;
-  if (idx < per) {
-    int ci = (int)(idx % Cin);
-    long t = idx / Cin;
-    int tap = (int)(t % (KH * KW));
-    int co = (int)(t / (KH * KW));
-    float s = 0.f;
-    for (int c = 0; c < nchunk; ++c) s += partial[(long)c * per + idx];
-    dw[((long)co * Cin + ci) * KH * KW + tap] = s;
+// workgroup = 64 outputs x 4 chunk groups (the chunk count is in the hundreds: a serial loop per output took 100 us)
+__global__ __launch_bounds__(256) void conv_small_cout_wgrad_final_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b,
+                                                                          float* __restrict__ dw, float* __restrict__ db, int nchunk, int Cin,
+                                                                          int Cout, int KH, int KW) {
+  const int ol = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long idx = (long)blockIdx.x * 64 + ol;
+  const long per = (long)Cout * KH * KW * Cin;
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (idx < per)
+    for (int c = grp; c < nchunk; c += 4) s += partial[(long)c * per + idx];
+  red[grp][ol] = s;
+  __syncthreads();
+  if (grp == 0 && idx < per) {
+    const int ci = (int)(idx % Cin);
+    const long t = idx / Cin;
+    const int tap = (int)(t % (KH * KW));
+    const int co = (int)(t / (KH * KW));
+    dw[((long)co * Cin + ci) * KH * KW + tap] = (red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol]);
   }
-  if (idx < Cout && db) {
+  if (blockIdx.x == 0 && db && threadIdx.x < Cout) {
     float sb = 0.f;
-    for (int c = 0; c < nchunk; ++c) sb += partial_b[(long)c * Cout + idx];
-    db[idx] = sb;
+    for (int c = 0; c < nchunk; ++c) sb += partial_b[(long)c * Cout + threadIdx.x];
+    db[threadIdx.x] = sb;
   }
 }
 
@@ -529,7 +536,7 @@ int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw
     hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<1, 9>), grid, dim3(256), 0, st, x, dy, partial, partial_b, N, H, W, Cin,
                        in_cstride, KH, KW, pad, kSmallCoutChunkPx);
   long per = (long)Cout * KH * KW * Cin;
-  hipLaunchKernelGGL(conv_small_cout_wgrad_final_kernel, dim3(ceil_div(per, 256)), dim3(256), 0, st, partial, partial_b, dw_oihw, db,
+  hipLaunchKernelGGL(conv_small_cout_wgrad_final_kernel, dim3(ceil_div(per, 64)), dim3(256), 0, st, partial, partial_b, dw_oihw, db,
                      nchunk, Cin, Cout, KH, KW);
   return check_launch("conv_small_cout_bwd");
 }
