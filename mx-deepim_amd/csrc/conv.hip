@@ -8,9 +8,10 @@
 // first layer, four horizontally adjacent taps x 8 channels (= 32 contiguous floats in HBM).
 //
 // Block = 4 (or 8) waves; wave tile = (BM/WM) x (BN/WN) in 32x32 MFMA tiles.
-// LDS: A chunk [BM][32+4] and B chunk [BN][32+4], both k-contiguous: staged with one ds_write_b128 per float4 and read
-//      back as ds_read_b128 = four k-steps of MFMA operands per LDS instruction (the k order inside a chunk is permuted
-//      identically for A and B); two buffers, register prefetch of chunk k+1 under the MFMAs of chunk k.
+// LDS: the A (pixel) chunk [BM][32+4], k-contiguous: staged with one ds_write_b128 per float4 and read back as ds_read_b128 =
+//      four k-steps of MFMA operands per LDS instruction; two buffers, software-pipelined (see the loop).  The B operand
+//      (weights) never passes through LDS: the packed layout is the fragment layout, every wave loads its own fragments from
+//      L2 one chunk ahead (the k order inside a chunk is permuted identically for A and B).
 // Epilogue: bias + LeakyReLU fused; with gridDim.z > 1 (split-K) raw partials go to a slab
 // and dim_splitk_reduce finishes (deterministic, no atomics).
 #include <cstdlib>
@@ -56,8 +57,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   constexpr int TM = BM / WM / 32;  // MFMA tiles per wave along M
   constexpr int TN = BN / WN / 32;
   constexpr int A_PER_T = BM / RP;  // float4 loads per thread for the A chunk
-  constexpr int B_PER_T = BN / RP;
-  static_assert((WM * WN == 4 || WM * WN == 8) && A_PER_T >= 1 && A_PER_T <= 4 && B_PER_T >= 1 && B_PER_T <= 4, "staging plan");
+  static_assert((WM * WN == 4 || WM * WN == 8) && A_PER_T >= 1 && A_PER_T <= 4, "staging plan");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                       // [2][BM][LDK]   pixel-major, k contiguous
@@ -109,8 +109,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   float* yb = a.y + (long)blockIdx.y * a.by;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wb), 0, a.w_bytes, 0x00020000);
-  const int w_voff = ((n0 + srow) * BK + q * 4) * 4;  // packed [chunk][Cout][32]
-  const int wchunk_bytes = a.Cout * BK * 4;
+  const int wchunk_bytes = a.Cout * BK * 4;  // packed [chunk][Cout][32]
 
   // chunk -> (kh, kw, c0) counters
   int kh, kw, c0;
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
     kw = tap - kh * a.KW;
   }
 
-  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // named registers (arrays + lambdas ended up in scratch)
+  float4 ra0, ra1, ra2, ra3;  // staging registers of the A chunk, named (arrays + lambdas ended up in scratch)
 
   // tap_off is wave-uniform (scalar): one vector add per load.  (It cannot ride in the instruction's scalar offset: that
   // one is excluded from the range check, and a_pix alone is negative = out of range in the top/left padding.)
@@ -141,16 +140,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
               (!CIN8 || kw + (q >> 1) < a.KW);                                                                      \
     REG = buf_load16(rx, ok ? a_pix[I] + tap_off : -1, 0);                                                          \
   }
-#define DIM_LOAD_B(REG, I)
   // PF_OK = false on the one prefetch past the last chunk: its (kh,kw,c0) counters already point one channel slice beyond
   // the tensor, so the (unused) activation read is dropped like a padding tap
-#define DIM_LOAD_CHUNK(KC, PF_OK)                                  \
+#define DIM_LOAD_CHUNK(PF_OK)                                      \
   {                                                                \
     const bool pf_ok = (PF_OK);                                    \
     const int tap_off = ((kh * a.W + kw) * a.in_cstride + c0) * 4; \
     DIM_LOAD_A(ra0, 0) DIM_LOAD_A(ra1, 1) DIM_LOAD_A(ra2, 2) DIM_LOAD_A(ra3, 3) \
-    const int w_soff = (KC) * wchunk_bytes;                        \
-    DIM_LOAD_B(rb0, 0) DIM_LOAD_B(rb1, 1) DIM_LOAD_B(rb2, 2) DIM_LOAD_B(rb3, 3) \
   }
 #define DIM_ADVANCE()                        \
   if (CIN8) {                                \
@@ -164,12 +160,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   }
 #define DIM_STORE_A(REG, I) \
   if (I < A_PER_T) *reinterpret_cast<float4*>(dA + (srow + RP * I) * LDK + q * 4) = REG;
-#define DIM_STORE_B(REG, I)
 #define DIM_STORE_CHUNK(BUF)                          \
   {                                                   \
     float* dA = sA + (BUF) * BM * LDK;                \
     DIM_STORE_A(ra0, 0) DIM_STORE_A(ra1, 1) DIM_STORE_A(ra2, 2) DIM_STORE_A(ra3, 3) \
-    DIM_STORE_B(rb0, 0) DIM_STORE_B(rb1, 1) DIM_STORE_B(rb2, 2) DIM_STORE_B(rb3, 3) \
   }
 
   f32x16 acc[TM][TN];
@@ -222,17 +216,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   // prefetch that has just been issued.  Hazards: buffer b^1 is written in the middle of chunk k; its last readers were the g3
   // fragments of chunk k-1, which every wave has in registers before it passes that chunk's barrier.
   if (kc_begin < kc_end) {
-    DIM_LOAD_CHUNK(kc_begin, true)
+    DIM_LOAD_CHUNK(true)
     DIM_ADVANCE()
     DIM_STORE_CHUNK(0)
     DIM_LOAD_BFRAG(0, kc_begin)
   }
   __syncthreads();
-  {
-    const int kn = min(kc_begin + 1, a.nchunks - 1);
-    DIM_LOAD_CHUNK(kn, kc_begin + 1 < kc_end)
-    DIM_ADVANCE()
-  }
+  DIM_LOAD_CHUNK(kc_begin + 1 < kc_end)
+  DIM_ADVANCE()
   DIM_FRAG_READ(0, sA + a_off, 0, 0)
 
 #define DIM_CHUNK_BODY(SET, KCUR)                                                    \
@@ -245,11 +236,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
     DIM_FRAG_READ(0, cA, 0, 2)                                                      \
     DIM_MFMA_GROUP(1, SET, 1)                                                        \
     DIM_STORE_CHUNK(buf ^ 1)                                                         \
-    {                                                                                \
-      const int kn = min((KCUR) + 2, a.nchunks - 1);                                 \
-      DIM_LOAD_CHUNK(kn, (KCUR) + 2 < kc_end)                                        \
-      DIM_ADVANCE()                                                                  \
-    }                                                                                \
+    DIM_LOAD_CHUNK((KCUR) + 2 < kc_end)                                              \
+    DIM_ADVANCE()                                                                    \
     DIM_FRAG_READ(1, cA, 0, 3)                                                      \
     DIM_MFMA_GROUP(0, SET, 2)                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                  \
@@ -267,11 +255,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
 #undef DIM_FRAG_READ
 #undef DIM_MFMA_GROUP
 #undef DIM_LOAD_A
-#undef DIM_LOAD_B
 #undef DIM_LOAD_CHUNK
 #undef DIM_ADVANCE
 #undef DIM_STORE_A
-#undef DIM_STORE_B
 #undef DIM_STORE_CHUNK
 
   // ---- epilogue.  D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
