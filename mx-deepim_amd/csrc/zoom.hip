@@ -214,10 +214,13 @@ __device__ inline float fetch(const float* p, int o) {
 // `add` is the per-plane constant added before sampling and removed afterwards (pixel mean).
 template <int PRE>
 __device__ inline float sample(const float* plane, const Tap& t, float add) {
-  float tl = t.v00 ? __fadd_rn(fetch<PRE>(plane, t.o00), add) : 0.f;
-  float tr = t.v01 ? __fadd_rn(fetch<PRE>(plane, t.o01), add) : 0.f;
-  float bl = t.v10 ? __fadd_rn(fetch<PRE>(plane, t.o10), add) : 0.f;
-  float br = t.v11 ? __fadd_rn(fetch<PRE>(plane, t.o11), add) : 0.f;
+  // the offsets are clamped into the plane, so the four loads are unconditional (independent, all in flight together) and the
+  // zero padding is a select afterwards; with the loads inside the conditionals every corner was a branch + its own vmcnt wait
+  const float f00 = fetch<PRE>(plane, t.o00), f01 = fetch<PRE>(plane, t.o01), f10 = fetch<PRE>(plane, t.o10), f11 = fetch<PRE>(plane, t.o11);
+  float tl = t.v00 ? __fadd_rn(f00, add) : 0.f;
+  float tr = t.v01 ? __fadd_rn(f01, add) : 0.f;
+  float bl = t.v10 ? __fadd_rn(f10, add) : 0.f;
+  float br = t.v11 ? __fadd_rn(f11, add) : 0.f;
   const float wx1 = __fsub_rn(1.f, t.wx0), wy1 = __fsub_rn(1.f, t.wy0);
   float r = __fmul_rn(__fmul_rn(tl, t.wy0), t.wx0);
   r = __fadd_rn(r, __fmul_rn(__fmul_rn(tr, t.wy0), wx1));
