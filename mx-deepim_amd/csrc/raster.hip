@@ -371,12 +371,13 @@ static int raster_render_impl(const float* verts, const float* normals, const fl
   if (bbox) hipLaunchKernelGGL(bbox_init2_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, bbox, B, H, W);
   float p0 = plane_means3 ? plane_means3[0] : 0.f, p1 = plane_means3 ? plane_means3[1] : 0.f, p2 = plane_means3 ? plane_means3[2] : 0.f;
   LitArgs lit = {verts, normals, poses, light_pos, light_int, ratio};
+  const int bx = (W % 256 != 0 && W % 128 == 0) ? 128 : 256;  // W = 640: 5 x 128 threads per row leave no idle lanes
   if (normals)
-    hipLaunchKernelGGL(raster_resolve_kernel<true>, dim3(ceil_div(W, 256), H, B), dim3(256), 0, st, lit, uvs, faces, mesh_table, textures,
+    hipLaunchKernelGGL(raster_resolve_kernel<true>, dim3(ceil_div(W, bx), H, B), dim3(bx), 0, st, lit, uvs, faces, mesh_table, textures,
                        tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, mask_thr, image, depth, mask, bgr,
                        bbox);
   else
-    hipLaunchKernelGGL(raster_resolve_kernel<false>, dim3(ceil_div(W, 256), H, B), dim3(256), 0, st, lit, uvs, faces, mesh_table,
+    hipLaunchKernelGGL(raster_resolve_kernel<false>, dim3(ceil_div(W, bx), H, B), dim3(bx), 0, st, lit, uvs, faces, mesh_table,
                        textures, tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, mask_thr, image, depth, mask,
                        bgr, bbox);
   return check_launch("raster_render");
