@@ -56,11 +56,11 @@ def make_test_config(test_iter=4):
     return config
 
 
-def make_train_scene(B=2, seed=2333, subdiv=3, npts=3000):
+def make_train_scene(B=2, seed=2333, subdiv=3, npts=3000, n_models=1):
     """train-graph blobs: the test scene + mask_gt_observed, flow labels (depth->flow restatement), point clouds."""
     from oracle import se3 as ose3
 
-    sc = make_scene(B=B, seed=seed, subdiv=subdiv)
+    sc = make_scene(B=B, seed=seed, subdiv=subdiv, n_models=n_models)
     bl, K = sc["blobs"], sc["K"]
     rng = np.random.default_rng(seed + 5)
     mg, d_src, d_tgt, KT, pm, po = [], [], [], [], [], []

@@ -176,3 +176,37 @@ def test_adam_two_steps_and_optimizer_state_checkpoint(setup, tmp_path):
         np.testing.assert_array_equal(mod2.flat_w.cpu().numpy(), mod.flat_w.cpu().numpy())
     finally:
         cfg.TRAIN.optimizer = old
+
+
+def test_batch_updater_multiclass(hip_lib):
+    """BASELINE configs[2] shape at test size: several object classes in one training batch -- the between-iteration update renders
+    every sample with ITS mesh and re-labels it (pose residual, flow, masks) like the per-sample loop of the reference does."""
+    from lib.pair_matching.batch_updater_py_multi import batchUpdaterPyMulti
+    from lib.render_hip.render_py_multi import Render_Py
+    from oracle import refine as orefine
+
+    cfg = make_train_config()
+    cfg.dataset.class_name = ["ape", "can", "cat"]
+    B = 3
+    scene = make_train_scene(B=B, seed=4321, subdiv=3, n_models=3)
+    bl = scene["blobs"]
+    assert len(set(bl["class_index"].tolist())) >= 2
+    rm = Render_Py(None, cfg.dataset.class_name, scene["K"], meshes=scene["models"])
+    upd = batchUpdaterPyMulti(cfg, 480, 640, render_machine=rm)
+    batch = {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in bl.items()}
+    q = torch.tensor([[0.999, 0.02, -0.03, 0.01], [0.98, -0.1, 0.05, 0.12], [0.99, 0.05, 0.08, -0.06]], device=DEV)
+    preds = {"rot_est_norm": q / q.norm(dim=1, keepdim=True),
+             "trans_est": torch.tensor([[0.01, -0.02, 0.03], [-0.015, 0.01, -0.05], [0.02, 0.02, 0.01]], device=DEV)}
+    new = upd.forward(batch, preds)
+    z3, o3 = np.zeros(3), np.ones(3)
+    ref = orefine.update_train_batch(bl, {"rot_est": preds["rot_est_norm"].cpu().numpy(), "trans_est": preds["trans_est"].cpu().numpy()},
+                                     scene["models"], scene["K"], cfg.network.PIXEL_MEANS, z3, o3)
+    np.testing.assert_allclose(new["src_pose"].cpu().numpy(), ref["src_pose"], atol=2e-6)
+    np.testing.assert_allclose(new["rot"].cpu().numpy(), ref["rot"], atol=5e-6)
+    np.testing.assert_allclose(new["trans"].cpu().numpy(), ref["trans"], atol=5e-6)
+    assert (new["mask_rendered"].cpu().numpy() != ref["mask_rendered"]).sum() <= 12
+    img_bad = (np.abs(new["image_rendered"].cpu().numpy() - ref["image_rendered"]).max(axis=1) > 1e-3).sum()
+    assert img_bad <= 48, img_bad
+    fw, rfw = new["flow_weights"].cpu().numpy(), ref["flow_weights"]
+    assert (fw != rfw).sum() <= 300 and fw.sum() > 1000
+    cfg.dataset.class_name = ["ape"]
