@@ -121,7 +121,9 @@ int dim_raster_render_lit(const float* verts, const float* normals, const float*
 /* deepim/core/tester.py:204-225 (and batch_updater_py_multi.py:233-255): light_pos[b] = 0.5*(dx,dy,dz) + (tx,-ty,-tz) of poses[b]. */
 int dim_modelnet_light_position(const float* poses, float dx, float dy, float dz, float* light_pos, int B, void* stream);
 /* mask[b] = rectangle [y0:y1, x0:x1] (end-exclusive) of bbox[b]  (data_pair.py:103-114, UPDATE_MASK box_rendered) */
-int dim_box_mask(const int* bbox, float* mask, int B, int H, int W, void* stream);
+/* bbox_of_mask (optional, (B,4)): bbox {min_x,max_x,min_y,max_y} of the rectangle just written, in dim_mask_bbox's convention --
+ * the next iteration's ZoomMask then needs no scan of mask_observed. */
+int dim_box_mask(const int* bbox, float* mask, int B, int H, int W, int* bbox_of_mask, void* stream);
 
 /* ---------------------------------------------------------------- convolution stack (NHWC, f32 MFMA)
  * weights: pack once from the reference layout (Cout,Cin,KH,KW).  Cin must be 8 or a multiple of 32,

@@ -298,12 +298,21 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(LitArgs lit, const 
 
 // mask[b] = filled rectangle [y0:y1, x0:x1] (END-EXCLUSIVE: lib/pair_matching/data_pair.py:103-114)
 // of bbox[b]; empty bbox -> all zeros (the reference would raise in np.min; status reports it).
-__global__ __launch_bounds__(256) void box_mask_kernel(const int* __restrict__ bbox, float* __restrict__ mask, int H, int W) {
+__global__ __launch_bounds__(256) void box_mask_kernel(const int* __restrict__ bbox, float* __restrict__ mask, int H, int W,
+                                                       int* __restrict__ bbox_of_mask) {
   const int b = blockIdx.z, y = blockIdx.y;
   const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (x4 >= W) return;
   const int* bb = bbox + 4 * b;
   const int xs = bb[0], xe = bb[1], ys = bb[2], ye = bb[3];
+  if (bbox_of_mask && y == 0 && x4 == 0) {
+    // bbox {min_x,max_x,min_y,max_y} of the rectangle written below, so that the next ZoomMask need not scan the mask for it:
+    // rows [ys, ye) x columns [xs, xe) clipped to the image; empty -> {W,-1,H,-1} like dim_mask_bbox
+    const int x0 = max(xs, 0), x1 = min(xe, W) - 1, y0 = max(ys, 0), y1 = min(ye, H) - 1;
+    const bool any = bb[1] >= 0 && x1 >= x0 && y1 >= y0;
+    int* o = bbox_of_mask + 4 * b;
+    o[0] = any ? x0 : W; o[1] = any ? x1 : -1; o[2] = any ? y0 : H; o[3] = any ? y1 : -1;
+  }
   bool row = (bb[1] >= 0) && y >= ys && y < ye;
   float4 v;
   v.x = (row && x4 + 0 >= xs && x4 + 0 < xe) ? 1.f : 0.f;
@@ -412,11 +421,12 @@ int dim_modelnet_light_position(const float* poses, float dx, float dy, float dz
   return check_launch("modelnet_light_position");
 }
 
-int dim_box_mask(const int* bbox, float* mask, int B, int H, int W, void* stream) {
+int dim_box_mask(const int* bbox, float* mask, int B, int H, int W, int* bbox_of_mask, void* stream) {
   if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(bbox && mask, "null pointer");
   DIM_REQUIRE(W % 4 == 0, "W must be a multiple of 4");
-  hipLaunchKernelGGL(box_mask_kernel, dim3(ceil_div(W / 4, 256), H, B), dim3(256), 0, as_stream(stream), bbox, mask, H, W);
+  hipLaunchKernelGGL(box_mask_kernel, dim3(ceil_div(W / 4, 256), H, B), dim3(256), 0, as_stream(stream), bbox, mask, H, W,
+                     bbox_of_mask);
   return check_launch("box_mask");
 }
 

@@ -61,6 +61,7 @@ class Refiner(object):
         self.poses_iter = torch.zeros((self.test_iter, B, 3, 4), dtype=torch.float32, device=d)
         self.se3_iter = torch.zeros((self.test_iter, B, 7), dtype=torch.float32, device=d)
         self.bbox = torch.zeros((B, 4), dtype=torch.int32, device=d)
+        self.bbox_obs = torch.zeros((B, 4), dtype=torch.int32, device=d)
         self.depth = torch.zeros((B, 1, H, W), dtype=torch.float32, device=d)
         self.status_iter = torch.zeros((self.test_iter, B), dtype=torch.int32, device=d)
         # per-iteration head outputs of the full (not FAST_TEST) graph, read by the reference at tester.py:485-491
@@ -98,30 +99,34 @@ class Refiner(object):
         """tester.py:476-598 for a whole batch; everything enqueued on the current stream, no host sync."""
         cfg, net, b = self.cfg, self.net, self.batch
         # every copy below is ops.copy (a kernel), never Tensor.copy_: no memcpy / memset node may sit in the captured graph
-        ops.copy(b["src_pose"], self.pose_init)
         for k, v in self.init.items():
             ops.copy(b[k], v)
-        bbox = None
+        bbox_ren = bbox_obs = None
+        pose = self.pose_init
+        box_update = cfg.network.INPUT_MASK and cfg.network.PRED_MASK and cfg.TEST.UPDATE_MASK == "box_rendered"
         for it in range(self.test_iter):
-            out = net.forward_test(b, bbox_ren=bbox)
-            ops.copy(self.se3_iter[it], net.se3)
+            # se3 and status land directly in their per-iteration rows; the pose of the previous iteration is read where it lies
+            out = net.forward_test(b, bbox_ren=bbox_ren, bbox_obs=bbox_obs, src_pose=pose, se3_out=self.se3_iter[it],
+                                   status_out=self.status_iter[it])
             if self.mask_pred_iter is not None:
                 ops.copy(self.mask_pred_iter[it], out["mask_observed_pred_output"])
             if self.flow_est_iter is not None:
                 ops.copy(self.flow_est_iter[it], out["flow_est_crop_output"])
-            ops.copy(self.status_iter[it], net.status)
             # pose_rendered_update = RT_transform(pose_rendered, se3[:-3], se3[-3:], ...)   (:525-532)
-            ops.se3_compose(b["src_pose"], net.se3, cfg.network.ROT_COORD, self.T_means, self.T_stds, out=self.poses_iter[it])
+            ops.se3_compose(pose, self.se3_iter[it], cfg.network.ROT_COORD, self.T_means, self.T_stds, out=self.poses_iter[it])
             if it < self.test_iter - 1:
                 # render(render_machine, pose_rendered_update, cls_idx) + update_data_batch  (:563-590)
                 extra = {"light_intensity": self.light_int[it]} if self.lit else {}
                 self.render_machine.render_batch(b["class_index"], self.poses_iter[it], image=b["image_rendered"], depth=self.depth,
                                                  mask=b["mask_rendered"], bbox=self.bbox, plane_means=net.plane_means, mask_thr=0.2,
                                                  **extra)
-                if cfg.network.INPUT_MASK and cfg.network.PRED_MASK and cfg.TEST.UPDATE_MASK == "box_rendered":
-                    ops.box_mask(self.bbox, b["mask_observed"])  # data_pair.py:103-114
-                ops.copy(b["src_pose"], self.poses_iter[it])
-                bbox = self.bbox
+                if box_update:
+                    # data_pair.py:103-114; the rectangle's own bbox comes back with it, so ZoomMask does not scan the mask again
+                    ops.box_mask(self.bbox, b["mask_observed"], bbox_of_mask=self.bbox_obs)
+                    bbox_obs = self.bbox_obs
+                pose = self.poses_iter[it]
+                bbox_ren = self.bbox
+        ops.copy(b["src_pose"], pose)  # the blob ends up as the reference leaves it: the pose the last forward used
 
     def refine(self):
         """run test_iter iterations on the loaded batch; returns poses_iter (test_iter,B,3,4) (device)."""

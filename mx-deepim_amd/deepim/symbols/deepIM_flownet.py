@@ -240,13 +240,16 @@ class FlowNetHip(object):
         torch.cuda.synchronize(d)
 
     # ---- pieces -------------------------------------------------------------------------------
-    def zoom(self, batch, bbox_ren=None, nchw_out=None):
+    def zoom(self, batch, bbox_ren=None, nchw_out=None, bbox_obs=None, src_pose=None, status=None):
         """ZoomMask + ZoomImageWithFactor + Concat (reference :783-806, :53-60).  At test time
-        mask_gt_observed IS mask_observed (:779).  bbox_ren may come pre-computed from the rasteriser."""
-        ops.mask_bbox(batch["mask_observed"], 0.3, out=self.bbox_obs)
+        mask_gt_observed IS mask_observed (:779).  bbox_ren may come pre-computed from the rasteriser, bbox_obs from dim_box_mask
+        (the refinement loop knows the rectangle it has just written); src_pose / status override the blob / the status buffer."""
+        if bbox_obs is None:
+            bbox_obs = ops.mask_bbox(batch["mask_observed"], 0.3, out=self.bbox_obs)
         if bbox_ren is None:
             bbox_ren = ops.mask_bbox(batch["mask_rendered"], 0.2, out=self.bbox_ren)
-        ops.zoom_factor(self.bbox_obs, bbox_ren, batch["src_pose"], self.K, self.H, self.W, out=self.zoom_factor, status=self.status)
+        ops.zoom_factor(bbox_obs, bbox_ren, batch["src_pose"] if src_pose is None else src_pose, self.K, self.H, self.W,
+                        out=self.zoom_factor, status=self.status if status is None else status)
         ops.zoom_net_input(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"],
                            self.zoom_factor, self.plane_means, X=self.X, nchw_out=nchw_out)
         return self.X
@@ -302,8 +305,9 @@ class FlowNetHip(object):
             x = out
         return dict(self.conv_plan)
 
-    def head(self):
-        return ops.pose_head_fwd(self.fc6.view(self.B, 256), self.params, self.zoom_factor, se3=self.se3, fc7_out=self.fc7)
+    def head(self, se3=None):
+        return ops.pose_head_fwd(self.fc6.view(self.B, 256), self.params, self.zoom_factor, se3=self.se3 if se3 is None else se3,
+                                 fc7_out=self.fc7)
 
     def decoder(self):
         """get_convs :213-299: Convolution1, deconv5 (+Crop, LeakyReLU), upsample_flow6to5, Concat2, Convolution2, deconv4,
@@ -341,13 +345,15 @@ class FlowNetHip(object):
             out["flow_est_crop_output"] = self.flow_est
         return out
 
-    def forward_test(self, batch, bbox_ren=None):
+    def forward_test(self, batch, bbox_ren=None, bbox_obs=None, src_pose=None, se3_out=None, status_out=None):
         """One test-graph forward.  FAST_TEST graph: zoom + encoder + FC heads; otherwise also decoder + flow / mask heads
-        (reference :840-843, :913).  Returns the output dict the refinement loop reads (tester.py:483-491)."""
-        self.zoom(batch, bbox_ren=bbox_ren)
+        (reference :840-843, :913).  Returns the output dict the refinement loop reads (tester.py:483-491).
+        The optional arguments let the refinement loop hand in what it already has on the device (boxes, the pose of the previous
+        iteration) and receive se3 / status straight in its per-iteration buffers -- no copies between iterations."""
+        self.zoom(batch, bbox_ren=bbox_ren, bbox_obs=bbox_obs, src_pose=src_pose, status=status_out)
         self.encoder()
-        self.head()
-        out = {"se3_output": self.se3, "zoom_factor": self.zoom_factor}
+        se3 = self.head(se3=se3_out)
+        out = {"se3_output": se3, "zoom_factor": self.zoom_factor}
         cfg = self.cfg
         if self.has_decoder and not cfg.TEST.FAST_TEST and (cfg.network.PRED_MASK or cfg.network.PRED_FLOW):
             self.decoder()

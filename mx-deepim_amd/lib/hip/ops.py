@@ -118,9 +118,11 @@ def depth_to_flow(depth_src, depth_tgt, KT, Kinv, flow=None, valid=None):
     return flow, valid
 
 
-def box_mask(bbox, mask):
+def box_mask(bbox, mask, bbox_of_mask=None):
+    """mask <- filled rectangle of bbox (end-exclusive); bbox_of_mask (B,4) int32: optional bbox of that rectangle"""
     B, _, H, W = mask.shape
-    check(lib().dim_box_mask(dptr(bbox, i32), dptr(mask, f32), B, H, W, current_stream()))
+    check(lib().dim_box_mask(dptr(bbox, i32), dptr(mask, f32), B, H, W, dptr(bbox_of_mask, i32) if bbox_of_mask is not None else None,
+                             current_stream()))
     return mask
 
 

@@ -312,6 +312,19 @@ def test_box_mask_end_exclusive(ops):
     np.testing.assert_array_equal(m.cpu().numpy(), ref)
 
 
+def test_box_mask_reports_the_bbox_a_scan_would_find(ops):
+    """dim_box_mask's bbox_of_mask output replaces the next iteration's ZoomMask scan of mask_observed: it must equal
+    dim_mask_bbox of the mask just written, including empty and degenerate rectangles."""
+    bbox = torch.tensor([[10, 20, 30, 50], [5, 5, 7, 9], [640, -1, 480, -1], [0, 640, 0, 480], [3, 4, 479, 480], [7, 9, 12, 12]],
+                        dtype=torch.int32, device=DEV)
+    m = torch.empty((6, 1, 480, 640), device=DEV)
+    got = torch.full((6, 4), -7, dtype=torch.int32, device=DEV)
+    ops.box_mask(bbox, m, bbox_of_mask=got)
+    scan = ops.mask_bbox(m, 0.3)
+    assert got.tolist() == scan.tolist()
+    assert got[0].tolist() == [10, 19, 30, 49] and got[2].tolist() == [640, -1, 480, -1]
+
+
 # ------------------------------------------------------------------ convolution
 CONV_CASES = [
     # N, H, W, Cin, Cout, k, s, p, tile, splits

@@ -121,9 +121,12 @@ def test_refine_full_graph_multiclass_vs_oracle(hip_lib):
     ref.load(*load)
     snaps, orig = [], pred.net.forward_test
 
-    def hooked(batch, bbox_ren=None):
-        snaps.append({k: v.cpu().numpy().copy() for k, v in batch.items()})
-        return orig(batch, bbox_ren=bbox_ren)
+    def hooked(batch, **kw):
+        snap = {k: v.cpu().numpy().copy() for k, v in batch.items()}
+        if kw.get("src_pose") is not None:  # the loop hands the current pose over without copying it into the batch
+            snap["src_pose"] = kw["src_pose"].cpu().numpy().copy()
+        snaps.append(snap)
+        return orig(batch, **kw)
 
     pred.net.forward_test = hooked
     poses = ref.refine().cpu().numpy().copy()
