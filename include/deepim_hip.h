@@ -153,18 +153,19 @@ int dim_conv2d_fwd_ex(const float* x, const float* w_packed, const float* bias, 
                       int Cout, int KH, int KW, int stride, int pad, float slope, int tile, int out_cstride, int out_coff, int OH,
                       int OW, int osy, int osx, int ooy, int oox, int Ho, int Wo, int pad_w, int accumulate, void* stream);
 
-/* Winograd F(2x2,3x3) form of the 3x3 / stride 1 / pad 1 layers (conv3_1, conv4_1, conv5_1, conv6_1 of
- * deepim/symbols/deepIM_flownet.py:103-191): same result as dim_conv2d_fwd up to f32 rounding (tests: 1e-4 relative),
- * 2.25x fewer multiply-adds.  Weights are transformed once (dim_winograd_pack_weight from the (Cout,Cin,3,3) array);
+/* Winograd form of the 3x3 / stride 1 / pad 1 layers (conv3_1, conv4_1, conv5_1, conv6_1 of
+ * deepim/symbols/deepIM_flownet.py:103-191): same result as dim_conv2d_fwd up to f32 rounding (tests: 1e-4 relative).
+ * m = output tile edge: 2 = F(2x2,3x3), 16 GEMMs, 2.25x fewer multiply-adds; 4 = F(4x4,3x3), 36 GEMMs, 4x fewer (Cook-Toom points
+ * {0, 1, -1, 2, -1/2, inf}).  Weights are transformed once (dim_winograd_pack_weight from the (Cout,Cin,3,3) array, same m);
  * workspace = dim_winograd_workspace_floats floats.  in_cstride / out_cstride 0 = dense; y = LeakyReLU_slope(conv + bias). */
-long dim_winograd_packed_weight_floats(int Cout, int Cin);
-long dim_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout);
-int dim_winograd_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream);
+long dim_winograd_packed_weight_floats(int Cout, int Cin, int m);
+long dim_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int m);
+int dim_winograd_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int m, void* stream);
 /* events4: NULL, or four hipEvent_t recorded on the stream before the input transform, before / after the batched GEMM and after
  * the output transform (how bench.py times the GEMM launch separately from the transforms). */
 int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
-                            int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, void** events4,
-                            void* stream);
+                            int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, int m,
+                            void** events4, void* stream);
 /* dim_conv2d_pack_weight with the output channels zero-padded to CoutPad (multiple of 64) */
 int dim_conv2d_pack_weight_padded(const float* w_oihw, float* w_packed, int Cout, int CoutPad, int Cin, int KH, int KW, void* stream);
 /* Decoder (deepIM_flownet.py:213-299): y[..., out_coff:out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x, k=4, s=2, p=0) + bias,

@@ -1154,40 +1154,203 @@ __global__ void wino_pack_weight_kernel(const float* __restrict__ w, float* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------ Winograd F(4x4, 3x3)
+// Same scheme with 6x6 input tiles at stride 4 and 36 GEMMs: 4x fewer multiply-adds than the direct form (F(2x2): 2.25x) and
+// 2.25 T-tile planes per input pixel instead of 4, i.e. less transform traffic as well.  Cook-Toom points {0, 1, -1, 2, -1/2, inf}:
+// mixing a large and a small point keeps the f32 error at ~2e-6 rms / 2e-5 max of the output scale (the usual {0,+-1,+-2}: 4e-5 max).
+//   B^T = [1 3/2 -2 -3/2 1 0; 0 -1 -5/2 -1/2 1 0; 0 1 1/2 -5/2 1 0; 0 -1/2 -1 1/2 1 0; 0 2 -1 -2 1 0; 0 1 3/2 -2 -3/2 1]
+//   G   = [1 0 0; -1/3 -1/3 -1/3; 1/3 -1/3 1/3; 1/15 2/15 4/15; -16/15 8/15 -4/15; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -1/2 0; 0 1 1 4 1/4 0; 0 1 -1 8 -1/8 1]
+constexpr int kWino4Vec = 2;  // channels per thread of the F(4x4) transforms
+
+template <int VEC>
+struct WinoVec {
+  typedef float type __attribute__((ext_vector_type(VEC)));
+};
+
+#define DIM_WINO4_BT(O, D, S)                                                          \
+  {                                                                                    \
+    O[0 * S] = D[0] + 1.5f * D[1] - 2.f * D[2] - 1.5f * D[3] + D[4];                    \
+    O[1 * S] = D[4] - D[1] - 2.5f * D[2] - 0.5f * D[3];                                 \
+    O[2 * S] = D[4] + D[1] + 0.5f * D[2] - 2.5f * D[3];                                 \
+    O[3 * S] = D[4] - 0.5f * D[1] - D[2] + 0.5f * D[3];                                 \
+    O[4 * S] = D[4] + 2.f * D[1] - D[2] - 2.f * D[3];                                   \
+    O[5 * S] = D[1] + 1.5f * D[2] - 2.f * D[3] - 1.5f * D[4] + D[5];                    \
+  }
+
+// V[k][t][c], k = 6a + b: thread = (tile t, VEC channels)
+template <int VEC>
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C,
+                                                          int in_cstride, int th, int tw, FastDiv div_cq, FastDiv div_tw, FastDiv div_th) {
+#pragma clang fp contract(fast)
+  typedef typename WinoVec<VEC>::type vf;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  const unsigned CQ = C / VEC;
+  const unsigned T = (unsigned)N * th * tw;
+  const unsigned t = fastdiv(idx, div_cq);
+  if (t >= T) return;
+  const unsigned cq = idx - t * CQ;
+  const unsigned r = fastdiv(t, div_tw);
+  const unsigned tx = t - r * tw;
+  const unsigned n = fastdiv(r, div_th);
+  const unsigned ty = r - n * th;
+  const int y0 = 4 * (int)ty - 1, x0 = 4 * (int)tx - 1;
+  const float* base = x + (long)n * H * W * in_cstride + cq * VEC;
+  vf tmp[36];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {  // B^T d, one tile column at a time
+    const int xx = x0 + b;
+    const bool okx = (unsigned)xx < (unsigned)W;
+    const int xc = okx ? xx : 0;
+    vf d[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      // load from a clamped address, then select: a conditional load would compile to a branch with a wait per load
+      const int yy = y0 + a;
+      const bool ok = okx && (unsigned)yy < (unsigned)H;
+      const int yc = (unsigned)yy < (unsigned)H ? yy : 0;
+      vf v = *reinterpret_cast<const vf*>(base + ((long)yc * W + xc) * in_cstride);
+      d[a] = ok ? v : (vf)(0.f);
+    }
+    vf* o = tmp + b;
+    DIM_WINO4_BT(o, d, 6)
+  }
+  const long plane = (long)T * C;
+  float* out = V + (long)t * C + cq * VEC;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {  // (.) B
+    vf o[6];
+    const vf* d = tmp + 6 * a;
+    DIM_WINO4_BT(o, d, 1)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) *reinterpret_cast<vf*>(out + (a * 6 + b) * plane) = o[b];
+  }
+}
+
+#define DIM_WINO4_AT(O, M, S)                                       \
+  {                                                                 \
+    const vf s1 = M[1] + M[2], d1 = M[1] - M[2];                    \
+    O[0 * S] = M[0] + s1 + M[3] + M[4];                             \
+    O[1 * S] = d1 + 2.f * M[3] - 0.5f * M[4];                       \
+    O[2 * S] = s1 + 4.f * M[3] + 0.25f * M[4];                      \
+    O[3 * S] = d1 + 8.f * M[3] - 0.125f * M[4] + M[5];              \
+  }
+
+// Y = A^T M A + bias, LeakyReLU; thread = (tile t, VEC output channels); writes the 4x4 outputs that fall inside H x W
+template <int VEC>
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y,
+                                                           int N, int H, int W, int C, int out_cstride, int out_coff, int th, int tw,
+                                                           float slope, FastDiv div_cq, FastDiv div_tw, FastDiv div_th) {
+#pragma clang fp contract(fast)
+  typedef typename WinoVec<VEC>::type vf;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  const unsigned CQ = C / VEC;
+  const unsigned T = (unsigned)N * th * tw;
+  const unsigned t = fastdiv(idx, div_cq);
+  if (t >= T) return;
+  const unsigned cq = idx - t * CQ;
+  const unsigned r = fastdiv(t, div_tw);
+  const unsigned tx = t - r * tw;
+  const unsigned n = fastdiv(r, div_th);
+  const unsigned ty = r - n * th;
+  const long plane = (long)T * C;
+  const float* in = M + (long)t * C + cq * VEC;
+  vf rr[24];  // A^T m: rr[4 rows][6 columns]
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    vf m[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const vf*>(in + (a * 6 + b) * plane);
+    vf* o = rr + b;
+    DIM_WINO4_AT(o, m, 6)
+  }
+  vf bv = (vf)(0.f);
+  if (bias) bv = *reinterpret_cast<const vf*>(bias + cq * VEC);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    vf o[4];
+    const vf* m = rr + 6 * a;
+    DIM_WINO4_AT(o, m, 1)
+    const int oy = 4 * (int)ty + a;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ox = 4 * (int)tx + b;
+      if (oy < H && ox < W) {
+        vf v = o[b] + bv;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        *reinterpret_cast<vf*>(y + (((long)n * H + oy) * W + ox) * out_cstride + out_coff + cq * VEC) = v;
+      }
+    }
+  }
+}
+
+// U_k = G g G^T per (co, ci) in the 1x1 packed layout of each of the 36 GEMMs: [k][ci/32][co][ci%32]; f64 inside (runs once)
+__global__ void wino4_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Cout * Cin) return;
+  const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
+  const float* g = w + ((long)co * Cin + ci) * 9;
+  const double G[6][3] = {{1., 0., 0.},
+                          {-1. / 3, -1. / 3, -1. / 3},
+                          {1. / 3, -1. / 3, 1. / 3},
+                          {1. / 15, 2. / 15, 4. / 15},
+                          {-16. / 15, 8. / 15, -4. / 15},
+                          {0., 0., 1.}};
+  double Gg[6][3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Gg[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
+  const long per_k = (long)Cin * Cout;
+  float* o = wp + ((long)(ci >> 5) * Cout + co) * 32 + (ci & 31);
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) o[(i * 6 + j) * per_k] = (float)(Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2]);
+}
+
 }  // namespace dim
 
 extern "C" {
 
-long dim_winograd_packed_weight_floats(int Cout, int Cin) { return 16L * Cout * Cin; }
+long dim_winograd_packed_weight_floats(int Cout, int Cin, int m) { return (long)(m + 2) * (m + 2) * Cout * Cin; }
 
-long dim_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout) {
-  long T = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
-  return 16 * T * ((long)Cin + Cout);
+long dim_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int m) {
+  if (m != 2 && m != 4) return 0;
+  long T = (long)N * ((H + m - 1) / m) * ((W + m - 1) / m);
+  return (long)(m + 2) * (m + 2) * T * ((long)Cin + Cout);
 }
 
-int dim_winograd_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream) {
+int dim_winograd_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int m, void* stream) {
   DIM_REQUIRE(w_oihw && w_packed, "null weight pointer");
+  DIM_REQUIRE(m == 2 || m == 4, "output tile m must be 2 or 4");
   DIM_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "Cin %% 32 == 0 and Cout %% 64 == 0 required");
   long total = (long)Cout * Cin;
-  hipLaunchKernelGGL(wino_pack_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_pack_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin);
+  else
+    hipLaunchKernelGGL(wino4_pack_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin);
   return check_launch("winograd_pack_weight");
 }
 
 int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
-                            int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, void** events4,
-                            void* stream) {
+                            int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, int m,
+                            void** events4, void* stream) {
   if (N == 0) return DIM_OK;
   DIM_REQUIRE(x && w_packed && y && workspace, "null pointer");
+  DIM_REQUIRE(m == 2 || m == 4, "output tile m must be 2 or 4");
   DIM_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "Cin %% 32 == 0 and Cout %% 64 == 0 required");
   if (in_cstride == 0) in_cstride = Cin;
   if (out_cstride == 0) out_cstride = Cout;
   DIM_REQUIRE(in_cstride >= Cin && in_cstride % 4 == 0 && out_cstride >= out_coff + Cout && out_cstride % 4 == 0 && out_coff % 4 == 0,
               "channel strides / offsets must be multiples of 4 and cover the channels");
-  const int th = (H + 1) / 2, tw = (W + 1) / 2;
+  const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
+  const int nk = (m + 2) * (m + 2);
   const long T = (long)N * th * tw;
-  DIM_REQUIRE(T * (Cin > Cout ? Cin : Cout) / 4 < (1L << 32) && T < (1L << 31), "too many tiles");
+  DIM_REQUIRE(T * (Cin > Cout ? Cin : Cout) / 2 < (1L << 32) && T < (1L << 31), "too many tiles");
   float* V = workspace;
-  float* M = workspace + 16 * T * Cin;
+  float* M = workspace + nk * T * Cin;
   hipStream_t st = as_stream(stream);
   const FastDiv dtw = make_fastdiv((unsigned)tw), dth = make_fastdiv((unsigned)th);
 #define DIM_WINO_EVENT(I)                                                                  \
@@ -1196,22 +1359,30 @@ int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* 
     if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipEventRecord: %s", hipGetErrorString(e)); \
   }
   DIM_WINO_EVENT(0)
-  hipLaunchKernelGGL(wino_input_kernel, dim3(ceil_div(T * (Cin / 4), 256)), dim3(256), 0, st, x, V, N, H, W, Cin, in_cstride, th, tw,
-                     make_fastdiv((unsigned)(Cin / 4)), dtw, dth);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_input_kernel, dim3(ceil_div(T * (Cin / 4), 256)), dim3(256), 0, st, x, V, N, H, W, Cin, in_cstride, th, tw,
+                       make_fastdiv((unsigned)(Cin / 4)), dtw, dth);
+  else
+    hipLaunchKernelGGL(wino4_input_kernel<kWino4Vec>, dim3(ceil_div(T * (Cin / kWino4Vec), 256)), dim3(256), 0, st, x, V, N, H, W, Cin,
+                       in_cstride, th, tw, make_fastdiv((unsigned)(Cin / kWino4Vec)), dtw, dth);
   int rc = check_launch("winograd_input");
   if (rc != DIM_OK) return rc;
   DIM_WINO_EVENT(1)
   ConvEx ex = {};
   ex.pad_w = -1;
-  ex.batch = 16;
+  ex.batch = nk;
   ex.bx = T * Cin;
   ex.bw = (long)Cin * Cout;
   ex.by = T * Cout;
   rc = conv2d_fwd_impl(V, w_packed, nullptr, M, nullptr, 1, 1, (int)T, Cin, Cout, 1, 1, 1, 0, 1.0f, 1, tile, 0, stream, &ex);
   if (rc != DIM_OK) return rc;
   DIM_WINO_EVENT(2)
-  hipLaunchKernelGGL(wino_output_kernel, dim3(ceil_div(T * (Cout / 4), 256)), dim3(256), 0, st, M, bias, y, N, H, W, Cout, out_cstride,
-                     out_coff, th, tw, slope, make_fastdiv((unsigned)(Cout / 4)), dtw, dth);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_output_kernel, dim3(ceil_div(T * (Cout / 4), 256)), dim3(256), 0, st, M, bias, y, N, H, W, Cout, out_cstride,
+                       out_coff, th, tw, slope, make_fastdiv((unsigned)(Cout / 4)), dtw, dth);
+  else
+    hipLaunchKernelGGL(wino4_output_kernel<kWino4Vec>, dim3(ceil_div(T * (Cout / kWino4Vec), 256)), dim3(256), 0, st, M, bias, y, N, H, W,
+                       Cout, out_cstride, out_coff, th, tw, slope, make_fastdiv((unsigned)(Cout / kWino4Vec)), dtw, dth);
   rc = check_launch("winograd_output");
   DIM_WINO_EVENT(3)
 #undef DIM_WINO_EVENT

@@ -127,7 +127,7 @@ class MutableModule(object):
             need, h, w, c = 4, 480, 640, 8
             for name, cout, k, s, p in ENCODER:
                 if name in net.wino:
-                    need = max(need, ops.lib().dim_winograd_workspace_floats(B, h, w, cout, c))
+                    need = max(need, ops.lib().dim_winograd_workspace_floats(B, h, w, cout, c, net.wino_m[name]))
                 h, w = ops.conv_out_hw(h, w, k, k, s, p)
                 c = cout
             self.wino_ws = torch.empty(need, dtype=torch.float32, device=d)
@@ -140,11 +140,11 @@ class MutableModule(object):
         for name, cout, k, s, p in ENCODER:
             if forward:
                 if name in net.wino:   # 3x3 / stride-1 layers run their forward through Winograd: re-transform the weights
-                    net.wino[name] = ops.winograd_pack_weight(w[name + "_weight"])
+                    net.wino[name] = ops.winograd_pack_weight(w[name + "_weight"], m=net.wino_m[name])
                 else:
                     net.packed[name] = ops.conv2d_pack_weight(w[name + "_weight"])
             if name in net.wino:
-                self.wino_dgrad[name] = ops.winograd_pack_weight(w[name + "_weight"].flip(2, 3).transpose(0, 1).contiguous())
+                self.wino_dgrad[name] = ops.winograd_pack_weight(w[name + "_weight"].flip(2, 3).transpose(0, 1).contiguous(), m=net.wino_m[name])
             elif name != "flow_conv1":
                 self.dgrad_packed[name] = ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p)
         if forward:
@@ -260,10 +260,12 @@ class MutableModule(object):
             if prev[name]:
                 if name in self.wino_dgrad:
                     # dX of a 3x3 / stride-1 / pad-1 convolution = the same kind of convolution of dZ with the flipped, transposed
-                    # kernel: Winograd F(2x2,3x3) like the forward (no bias, no activation)
+                    # kernel: Winograd like the forward (no bias, no activation)
+                    wm = self.net.wino_m[name]
+                    wtiles = dy.shape[0] * (-(-dy.shape[1] // wm)) * (-(-dy.shape[2] // wm))
                     ops.conv2d_fwd_winograd(dy, cout, self.wino_dgrad[name], None, cin[name], slope=1.0,
-                                            tile=4 if (cin[name] % 128 == 0 and dy.shape[0] * dy.shape[1] * dy.shape[2] >= 4096) else 3,
-                                            out=self.dacts[prev[name]], workspace=self.wino_ws)
+                                            tile=4 if (cin[name] % 128 == 0 and wtiles >= 1024) else 3,
+                                            out=self.dacts[prev[name]], workspace=self.wino_ws, m=wm)
                 else:
                     ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False)
         return g

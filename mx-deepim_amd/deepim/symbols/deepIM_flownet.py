@@ -30,6 +30,11 @@ ENCODER = [
 ]
 
 
+# Winograd output tile edge per 3x3 / stride-1 layer (4 where not listed; measured at B = 16: F(4x4) wins on all four, also on the
+# 8x10 map of conv6_1 despite 20 % tile padding: 0.108 vs 0.128 ms)
+WINO_M_DEFAULT = {}
+
+
 def input_channels(cfg):
     """Concat arity of get_convs (reference :33-66): 6 RGB (+2 depth) (+2 masks iff INPUT_MASK and PRED_MASK)."""
     c = 6
@@ -157,9 +162,10 @@ class FlowNetHip(object):
 
     H, W = 480, 640
 
-    def __init__(self, cfg, arg_params, batch_size, device="cuda:0", conv_plan=None, winograd=True):
-        """winograd: run the 3x3 / stride-1 layers (conv3_1, conv4_1, conv5_1, conv6_1) through Winograd F(2x2,3x3)
-        (same f32 result within 1e-4 relative, 2.25x fewer multiply-adds).  False = direct kernel for every layer."""
+    def __init__(self, cfg, arg_params, batch_size, device="cuda:0", conv_plan=None, winograd=True, wino_m=None, wino_tile=None):
+        """winograd: run the 3x3 / stride-1 layers (conv3_1, conv4_1, conv5_1, conv6_1) through Winograd F(4x4,3x3) / F(2x2,3x3)
+        (same f32 result within 1e-4 relative, 4x / 2.25x fewer multiply-adds).  False = direct kernel for every layer.
+        wino_m / wino_tile: optional {layer: output tile edge 2|4} / {layer: GEMM workgroup tile 3|4} overrides."""
         self.cfg = cfg
         self.B = batch_size
         self.device = torch.device(device)
@@ -172,11 +178,13 @@ class FlowNetHip(object):
         for name, cout, k, s, p in ENCODER:
             self.packed[name] = ops.conv2d_pack_weight(self.params[name + "_weight"])
         self.packed["fc6"] = ops.fc_pack_weight(self.params["fc6_weight"], 1024, 8, 10)
-        self.wino = {}
+        self.wino, self.wino_m = {}, {}
         if winograd:
             for name, cout, k, s, p in ENCODER:
                 if k == 3 and s == 1 and p == 1:
-                    self.wino[name] = ops.winograd_pack_weight(self.params[name + "_weight"])
+                    # output tile edge: F(4x4,3x3) (4x fewer multiply-adds) by default
+                    self.wino_m[name] = int((wino_m or {}).get(name, WINO_M_DEFAULT.get(name, 4)))
+                    self.wino[name] = ops.winograd_pack_weight(self.params[name + "_weight"], m=self.wino_m[name])
         self.K = np.asarray(cfg.dataset.INTRINSIC_MATRIX, dtype=np.float32).reshape(3, 3)
         self.plane_means = np.asarray(cfg.network.PIXEL_MEANS, dtype=np.float32).reshape(3)[::-1].copy()
         # tile / split-K plan per layer: (tile, splits); 0 = library heuristic
@@ -201,10 +209,11 @@ class FlowNetHip(object):
                 max_ws = max(max_ws, ops.lib().dim_conv2d_workspace_floats(B, h, w, c, cout, k, k, s, p, splits))
             if name in self.wino:
                 # GEMM rows = tiles; 128x128 workgroup tiles once there are enough of them, 64x64 for the small maps
-                tiles = B * ((h + 1) // 2) * ((w + 1) // 2)
-                self.layer_info[name].update(winograd=True, wino_tile=4 if (cout % 128 == 0 and tiles >= 1024) else 3,
-                                             wino_flops=2 * 16 * tiles * c * cout)
-                max_ws = max(max_ws, ops.lib().dim_winograd_workspace_floats(B, h, w, c, cout))
+                m = self.wino_m[name]
+                tiles = B * (-(-h // m)) * (-(-w // m))
+                wt = (wino_tile or {}).get(name, 4 if (cout % 128 == 0 and tiles >= 1024) else 3)
+                self.layer_info[name].update(winograd=True, wino_m=m, wino_tile=wt, wino_flops=2 * (m + 2) ** 2 * tiles * c * cout)
+                max_ws = max(max_ws, ops.lib().dim_winograd_workspace_floats(B, h, w, c, cout, m))
             h, w, c = ho, wo, cout
         assert (h, w, c) == (8, 10, 1024)
         tile, splits = self.conv_plan["fc6"]
@@ -261,7 +270,7 @@ class FlowNetHip(object):
             if name in self.wino:
                 x = ops.conv2d_fwd_winograd(x, x.shape[-1], self.wino[name], self.params[name + "_bias"], cout, slope=0.1,
                                             tile=self.layer_info[name]["wino_tile"], out=self.acts[name], workspace=self.workspace,
-                                            events=None if events is None else events.setdefault(name, []))
+                                            events=None if events is None else events.setdefault(name, []), m=self.wino_m[name])
                 continue
             tile, splits = self.conv_plan[name]
             x = ops.conv2d_fwd(x, self.packed[name], self.params[name + "_bias"], cout, k, k, s, p, slope=0.1, splits=splits, tile=tile,

@@ -59,10 +59,10 @@ SIGNATURES = {
     "dim_conv_small_cout_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_deconv4x4s2_tiny_bwd": (I, [P, I, P, I, I, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dim_conv2d_tail_plan": (I, [I, I, I, I, I, I, P, P]),
-    "dim_winograd_packed_weight_floats": (L, [I, I]),
-    "dim_winograd_workspace_floats": (L, [I, I, I, I, I]),
-    "dim_winograd_pack_weight": (I, [P, P, I, I, P]),
-    "dim_conv2d_fwd_winograd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P, P]),
+    "dim_winograd_packed_weight_floats": (L, [I, I, I]),
+    "dim_winograd_workspace_floats": (L, [I, I, I, I, I, I]),
+    "dim_winograd_pack_weight": (I, [P, P, I, I, I, P]),
+    "dim_conv2d_fwd_winograd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, P, P]),
     "dim_copy_words": (I, [P, P, L, P]),
     "dim_sgd_momentum": (I, [P, P, P, L, F, F, F, F, P]),
     "dim_adam": (I, [P, P, P, P, L, F, F, F, F, F, F, P]),

@@ -180,17 +180,18 @@ def copy(dst, src):
     return dst
 
 
-def winograd_pack_weight(w_oihw):
-    """(Cout,Cin,3,3) -> the 16 transformed 1x1 weight sets of the Winograd F(2x2,3x3) path"""
+def winograd_pack_weight(w_oihw, m=2):
+    """(Cout,Cin,3,3) -> the (m+2)^2 transformed 1x1 weight sets of the Winograd F(m x m, 3x3) path, m = 2 or 4"""
     Cout, Cin, KH, KW = w_oihw.shape
     assert KH == 3 and KW == 3
-    out = _new((lib().dim_winograd_packed_weight_floats(Cout, Cin),), w_oihw)
-    check(lib().dim_winograd_pack_weight(dptr(w_oihw, f32), dptr(out, f32), Cout, Cin, current_stream()))
+    out = _new((lib().dim_winograd_packed_weight_floats(Cout, Cin, m),), w_oihw)
+    check(lib().dim_winograd_pack_weight(dptr(w_oihw, f32), dptr(out, f32), Cout, Cin, m, current_stream()))
     return out
 
 
-def conv2d_fwd_winograd(x_nhwc, Cin, w_packed, bias, Cout, slope=0.1, tile=0, out=None, out_coff=0, workspace=None, events=None):
-    """3x3 / stride 1 / pad 1 convolution through Winograd F(2x2,3x3); x may carry padded channels (in_cstride = x.shape[-1]).
+def conv2d_fwd_winograd(x_nhwc, Cin, w_packed, bias, Cout, slope=0.1, tile=0, out=None, out_coff=0, workspace=None, events=None, m=2):
+    """3x3 / stride 1 / pad 1 convolution through Winograd F(m x m, 3x3) (m = 2 or 4, the m the weights were packed with);
+    x may carry padded channels (in_cstride = x.shape[-1]).
     events: optional list; ("wino_in" | "conv" | "wino_out", start, end) HIP-event triples of the three launches are appended."""
     import ctypes
 
@@ -202,11 +203,11 @@ def conv2d_fwd_winograd(x_nhwc, Cin, w_packed, bias, Cout, slope=0.1, tile=0, ou
         ev_arr = (ctypes.c_void_p * 4)(*[e.cuda_event for e in evs])
     N, H, W, in_cs = x_nhwc.shape
     out = out if out is not None else _new((N, H, W, Cout), x_nhwc)
-    need = lib().dim_winograd_workspace_floats(N, H, W, Cin, Cout)
+    need = lib().dim_winograd_workspace_floats(N, H, W, Cin, Cout, m)
     if workspace is None or workspace.numel() < need:
         workspace = _new((need,), x_nhwc)
     check(lib().dim_conv2d_fwd_winograd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), dptr(workspace, f32), N, H, W,
-                                        Cin, in_cs, Cout, out.shape[-1], out_coff, float(slope), tile, ev_arr, current_stream()))
+                                        Cin, in_cs, Cout, out.shape[-1], out_coff, float(slope), tile, m, ev_arr, current_stream()))
     if events is not None:
         events.extend([("wino_in", evs[0], evs[1]), ("conv", evs[1], evs[2]), ("wino_out", evs[2], evs[3])])
     return out

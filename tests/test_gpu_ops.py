@@ -398,9 +398,10 @@ def test_fc6_and_pose_head(ops):
     np.testing.assert_allclose(se3.cpu().numpy(), ref, atol=5e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("shape", [(2, 15, 20, 64, 128), (1, 8, 10, 96, 64), (3, 30, 40, 256, 256), (2, 7, 9, 32, 64)])
-def test_conv3x3_winograd_vs_f64(hip_lib, shape):
-    """Winograd F(2x2,3x3) path (odd and even H/W, partial edge tiles, bias + LeakyReLU) vs torch-CPU float64 conv2d"""
+@pytest.mark.parametrize("m", [2, 4])
+@pytest.mark.parametrize("shape", [(2, 15, 20, 64, 128), (1, 8, 10, 96, 64), (3, 30, 40, 256, 256), (2, 7, 9, 32, 64), (1, 3, 5, 32, 64)])
+def test_conv3x3_winograd_vs_f64(hip_lib, shape, m):
+    """Winograd F(2x2,3x3) / F(4x4,3x3) paths (odd and even H/W, partial edge tiles, bias + LeakyReLU) vs torch-CPU float64 conv2d"""
     import torch.nn.functional as F
     from lib.hip import ops
 
@@ -411,16 +412,16 @@ def test_conv3x3_winograd_vs_f64(hip_lib, shape):
     b = torch.randn((Cout,), generator=g) * 0.1
     ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=1, padding=1), 0.1).permute(0, 2, 3, 1).numpy()
     xd = x.permute(0, 2, 3, 1).contiguous().to("cuda:0")
-    wp = ops.winograd_pack_weight(w.to("cuda:0"))
+    wp = ops.winograd_pack_weight(w.to("cuda:0"), m=m)
     for tile in (3, 4) if Cout % 128 == 0 else (3,):
-        y = ops.conv2d_fwd_winograd(xd, Cin, wp, b.to("cuda:0"), Cout, slope=0.1, tile=tile).cpu().numpy()
+        y = ops.conv2d_fwd_winograd(xd, Cin, wp, b.to("cuda:0"), Cout, slope=0.1, tile=tile, m=m).cpu().numpy()
         err = np.abs(y - ref).max()
         assert err <= 1e-4 * np.abs(ref).max() + 2e-5, (tile, err)
     # strided output (concat buffer) and padded input channels
     xd2 = torch.zeros((N, H, W, Cin + 32), device="cuda:0")
     xd2[..., :Cin] = xd
     out = torch.full((N, H, W, Cout + 64), 7.0, device="cuda:0")
-    ops.conv2d_fwd_winograd(xd2, Cin, wp, b.to("cuda:0"), Cout, slope=0.1, tile=3, out=out, out_coff=32)
+    ops.conv2d_fwd_winograd(xd2, Cin, wp, b.to("cuda:0"), Cout, slope=0.1, tile=3, out=out, out_coff=32, m=m)
     o = out.cpu().numpy()
     assert np.abs(o[..., 32:32 + Cout] - ref).max() <= 1e-4 * np.abs(ref).max() + 2e-5
     assert np.all(o[..., :32] == 7.0) and np.all(o[..., 32 + Cout:] == 7.0)
