@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a box with fewer GPUs than ranks, together with DIM_BENCH_DEVICE)")
-    ap.add_argument("--no-winograd", action="store_true", help="run conv3_1/conv4_1/conv5_1/conv6_1 through the direct kernel too")
+    ap.add_argument("--no-winograd", action="store_true", help="run every encoder layer through the direct kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--autotune", action="store_true", help="time tile/split-K candidates per layer first (untimed); default: fixed plan")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="bounded CPU-baseline sample (pairs refined by the oracle)")
@@ -178,13 +178,13 @@ def main():
             if tag == "conv":  # the symbol rocprofv3 --kernel-trace reports for this launch
                 if info.get("winograd"):  # batched GEMM of the Winograd path: the multiply-adds that launch really executes
                     kname = "dim::conv_fwd_kernel<{}, false>".format(TILE_SYM[info["wino_tile"]])
-                    tiles = info["wino_flops"] / (2.0 * 16 * info["cin"] * info["N"])
-                    flops, nbytes = info["wino_flops"], 4.0 * 16 * (tiles * info["cin"] + info["cin"] * info["N"] + tiles * info["N"])
+                    flops, nbytes = info["wino_flops"], info["wino_gemm_bytes"]
                 else:
                     kname = "dim::conv_fwd_kernel<{}, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
                     flops, nbytes = info["flops"], info["min_bytes"]
             elif tag in ("wino_in", "wino_out"):
-                kname, flops, nbytes = "dim::wino_input_kernel" if tag == "wino_in" else "dim::wino_output_kernel", 0.0, 0.0
+                kname, flops = info["wino_in_kernel" if tag == "wino_in" else "wino_out_kernel"], 0.0
+                nbytes = info["wino_in_bytes" if tag == "wino_in" else "wino_out_bytes"]  # HBM-bound: read x + write V / read M + write y
             else:
                 kname, flops, nbytes = "dim::splitk_reduce_kernel", 0.0, 0.0
             k = per_kernel.setdefault(kname, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "layers": []})
@@ -212,7 +212,8 @@ def main():
                 "min_bytes_per_launch_avg": round(dom["bytes"] / dom["launches"]),
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 4), "launches_timed": dom["launches"],
                 "gflop_per_launch_avg": round(dom["flops"] / dom["launches"] / 1e9, 3),
-                "all_kernels": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "avg_launch_ms": round(v["ms"] / v["launches"], 4),
+                "all_kernels": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "algorithmic_GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                    "avg_launch_ms": round(v["ms"] / v["launches"], 4),
                                     "ms_per_forward": round(v["ms"] / nfwd, 4)} for k, v in per_kernel.items()},
                 "conv_stack_ms_per_forward": round(sum(v["ms"] for v in per_kernel.values()) / nfwd, 3)}
 
@@ -225,7 +226,7 @@ def main():
         "config": {"workload": "LINEMOD 'ape' batch={} per GPU, {} iters, fp32, FAST_TEST graph (zoom + FlowNetS encoder + FC heads) "
                                "+ SE3 compose + HIP rasteriser ({} triangles) + box_rendered mask update".format(
                                    B, test_iter, models[0][2].shape[0]),
-                   "pairs_per_gpu": B, "global_pairs": B * world, "test_iter": test_iter, "hipgraph": not args.no_graph, "winograd_3x3s1": not args.no_winograd,
+                   "pairs_per_gpu": B, "global_pairs": B * world, "test_iter": test_iter, "hipgraph": not args.no_graph, "winograd": "off" if args.no_winograd else "F(4x4,3x3): conv3_1 conv4_1 conv5_1 conv6_1; phase images + F(4x4,3x3): conv2 conv3",
                    "gflop_per_refinement": round(net.flops_per_forward() * test_iter / B / 1e9, 2), "status_flags": status,
                    "conv_plan": {k: list(v) for k, v in net.conv_plan.items()}},
         "roofline": roofline,

@@ -166,6 +166,17 @@ int dim_winograd_pack_weight(const float* w_oihw, float* w_packed, int Cout, int
 int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
                             int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, int m,
                             void** events4, void* stream);
+/* 5x5 / stride 2 / pad 2 layers (conv2, conv3 of deepim/symbols/deepIM_flownet.py:95-101) through Winograd as well: the layer is
+ * the sum of four 3x3 / stride-1 / pad-1 convolutions of the phase images x[2r + py][2q + px] with the sub-kernels
+ * w[2u + py][2v + px]; the four F(4x4,3x3)-transformed phase tiles are concatenated along the channels, so 36 GEMMs with K = 4 Cin
+ * replace the 25-tap direct form (2.78x fewer multiply-adds) and the output transform is the one of the stride-1 layers.
+ * Weights: MXNet layout (Cout,Cin,5,5).  Output (N, ceil(H/2), ceil(W/2), Cout).  Same f32 accuracy class as F(4x4,3x3). */
+long dim_winograd5x5s2_packed_weight_floats(int Cout, int Cin);
+long dim_winograd5x5s2_workspace_floats(int N, int H, int W, int Cin, int Cout);
+int dim_winograd5x5s2_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream);
+int dim_conv2d_fwd_winograd5x5s2(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
+                                 int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, void** events4,
+                                 void* stream);
 /* dim_conv2d_pack_weight with the output channels zero-padded to CoutPad (multiple of 64) */
 int dim_conv2d_pack_weight_padded(const float* w_oihw, float* w_packed, int Cout, int CoutPad, int Cin, int KH, int KW, void* stream);
 /* Decoder (deepIM_flownet.py:213-299): y[..., out_coff:out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x, k=4, s=2, p=0) + bias,

@@ -1178,14 +1178,19 @@ struct WinoVec {
     O[5 * S] = D[1] + 1.5f * D[2] - 2.f * D[3] - 1.5f * D[4] + D[5];                    \
   }
 
-// V[k][t][c], k = 6a + b: thread = (tile t, VEC channels)
-template <int VEC>
+// V[k][t][c], k = 6a + b: thread = (tile t, VEC channels).
+// S = 1: a 3x3 / stride-1 / pad-1 layer.  S = 2: a 5x5 / stride-2 / pad-2 layer as the sum of four 3x3 / stride-1 / pad-1
+// convolutions of its phase images X^(py,px)[r][q] = x[2r + py][2q + px] (sub-kernels g[u][v] = w[2u + py][2v + px], zero beyond
+// the 5 taps): the four transformed phase tiles are concatenated along the channels, V has 4C of them (phase-major), so that ONE
+// GEMM per Winograd plane contracts over phases and channels and the output transform is that of the stride-1 layer.
+template <int VEC, int S>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C,
                                                           int in_cstride, int th, int tw, FastDiv div_cq, FastDiv div_tw, FastDiv div_th) {
 #pragma clang fp contract(fast)
   typedef typename WinoVec<VEC>::type vf;
   const unsigned idx = blockIdx.x * 256u + threadIdx.x;
-  const unsigned CQ = C / VEC;
+  const unsigned CT = C * S * S;  // channels of V
+  const unsigned CQ = CT / VEC;
   const unsigned T = (unsigned)N * th * tw;
   const unsigned t = fastdiv(idx, div_cq);
   if (t >= T) return;
@@ -1194,19 +1199,22 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
   const unsigned tx = t - r * tw;
   const unsigned n = fastdiv(r, div_th);
   const unsigned ty = r - n * th;
-  const int y0 = 4 * (int)ty - 1, x0 = 4 * (int)tx - 1;
-  const float* base = x + (long)n * H * W * in_cstride + cq * VEC;
+  const int y0 = 4 * (int)ty - 1, x0 = 4 * (int)tx - 1;  // tile origin in the (phase) image
+  const unsigned cc = cq * VEC;
+  const unsigned ph = S == 1 ? 0u : (unsigned)(cc >= (unsigned)C) + (unsigned)(cc >= 2u * C) + (unsigned)(cc >= 3u * C);
+  const int py = ph >> 1, px = ph & 1;
+  const float* base = x + (long)n * H * W * in_cstride + (cc - ph * C);
   vf tmp[36];
 #pragma unroll
   for (int b = 0; b < 6; ++b) {  // B^T d, one tile column at a time
-    const int xx = x0 + b;
+    const int xx = S * (x0 + b) + px;
     const bool okx = (unsigned)xx < (unsigned)W;
     const int xc = okx ? xx : 0;
     vf d[6];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       // load from a clamped address, then select: a conditional load would compile to a branch with a wait per load
-      const int yy = y0 + a;
+      const int yy = S * (y0 + a) + py;
       const bool ok = okx && (unsigned)yy < (unsigned)H;
       const int yc = (unsigned)yy < (unsigned)H ? yy : 0;
       vf v = *reinterpret_cast<const vf*>(base + ((long)yc * W + xc) * in_cstride);
@@ -1215,8 +1223,8 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     vf* o = tmp + b;
     DIM_WINO4_BT(o, d, 6)
   }
-  const long plane = (long)T * C;
-  float* out = V + (long)t * C + cq * VEC;
+  const long plane = (long)T * CT;
+  float* out = V + (long)t * CT + cc;
 #pragma unroll
   for (int a = 0; a < 6; ++a) {  // (.) B
     vf o[6];
@@ -1285,12 +1293,8 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
   }
 }
 
-// U_k = G g G^T per (co, ci) in the 1x1 packed layout of each of the 36 GEMMs: [k][ci/32][co][ci%32]; f64 inside (runs once)
-__global__ void wino4_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)Cout * Cin) return;
-  const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
-  const float* g = w + ((long)co * Cin + ci) * 9;
+// U_k = G g G^T for one 3x3 kernel g, scattered with stride per_k over the 36 planes; f64 inside (runs once per weight update)
+__device__ __forceinline__ void wino4_transform_weight(const float g[9], float* __restrict__ o, long per_k) {
   const double G[6][3] = {{1., 0., 0.},
                           {-1. / 3, -1. / 3, -1. / 3},
                           {1. / 3, -1. / 3, 1. / 3},
@@ -1302,12 +1306,42 @@ __global__ void wino4_pack_weight_kernel(const float* __restrict__ w, float* __r
   for (int i = 0; i < 6; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) Gg[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
-  const long per_k = (long)Cin * Cout;
-  float* o = wp + ((long)(ci >> 5) * Cout + co) * 32 + (ci & 31);
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
     for (int j = 0; j < 6; ++j) o[(i * 6 + j) * per_k] = (float)(Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2]);
+}
+
+// (Cout,Cin,3,3) -> the 1x1 packed layout of each of the 36 GEMMs: [k][ci/32][co][ci%32]
+__global__ void wino4_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Cout * Cin) return;
+  const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
+  const float* gp = w + ((long)co * Cin + ci) * 9;
+  float g[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) g[i] = gp[i];
+  wino4_transform_weight(g, wp + ((long)(ci >> 5) * Cout + co) * 32 + (ci & 31), (long)Cin * Cout);
+}
+
+// (Cout,Cin,5,5) of a stride-2 layer -> 36 GEMMs over K = 4 Cin (phase-major: kk = (2 py + px) Cin + ci), sub-kernel of phase
+// (py,px): g[u][v] = w[2u + py][2v + px], zero where 2u + py or 2v + px > 4
+__global__ void wino4_pack_weight_5x5s2_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Cout * Cin * 4) return;
+  const int kk = (int)(idx % (4 * Cin)), co = (int)(idx / (4 * Cin));
+  const int ph = kk / Cin, ci = kk - ph * Cin;
+  const int py = ph >> 1, px = ph & 1;
+  const float* gp = w + ((long)co * Cin + ci) * 25;
+  float g[9];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int i = 2 * u + py, j = 2 * v + px;
+      g[u * 3 + v] = (i < 5 && j < 5) ? gp[i * 5 + j] : 0.f;
+    }
+  wino4_transform_weight(g, wp + ((long)(kk >> 5) * Cout + co) * 32 + (kk & 31), 4L * Cin * Cout);
 }
 
 }  // namespace dim
@@ -1334,9 +1368,10 @@ int dim_winograd_pack_weight(const float* w_oihw, float* w_packed, int Cout, int
   return check_launch("winograd_pack_weight");
 }
 
-int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
-                            int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, int m,
-                            void** events4, void* stream) {
+// S = 1: 3x3 / stride 1 / pad 1 with output tile m; S = 2: 5x5 / stride 2 / pad 2 through its four phase images (m = 4)
+static int winograd_impl(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W, int Cin,
+                         int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, int m, int S, void** events4,
+                         void* stream) {
   if (N == 0) return DIM_OK;
   DIM_REQUIRE(x && w_packed && y && workspace, "null pointer");
   DIM_REQUIRE(m == 2 || m == 4, "output tile m must be 2 or 4");
@@ -1345,12 +1380,14 @@ int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* 
   if (out_cstride == 0) out_cstride = Cout;
   DIM_REQUIRE(in_cstride >= Cin && in_cstride % 4 == 0 && out_cstride >= out_coff + Cout && out_cstride % 4 == 0 && out_coff % 4 == 0,
               "channel strides / offsets must be multiples of 4 and cover the channels");
-  const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
+  const int Ho = S == 1 ? H : (H + 1) / 2, Wo = S == 1 ? W : (W + 1) / 2;  // 5x5 / s2 / p2: floor((H - 1) / 2) + 1
+  const int CT = Cin * S * S;                                                  // contraction length of the GEMMs
+  const int th = (Ho + m - 1) / m, tw = (Wo + m - 1) / m;
   const int nk = (m + 2) * (m + 2);
   const long T = (long)N * th * tw;
-  DIM_REQUIRE(T * (Cin > Cout ? Cin : Cout) / 2 < (1L << 32) && T < (1L << 31), "too many tiles");
+  DIM_REQUIRE(T * (CT > Cout ? CT : Cout) / 2 < (1L << 32) && T < (1L << 31), "too many tiles");
   float* V = workspace;
-  float* M = workspace + nk * T * Cin;
+  float* M = workspace + nk * T * CT;
   hipStream_t st = as_stream(stream);
   const FastDiv dtw = make_fastdiv((unsigned)tw), dth = make_fastdiv((unsigned)th);
 #define DIM_WINO_EVENT(I)                                                                  \
@@ -1362,31 +1399,64 @@ int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* 
   if (m == 2)
     hipLaunchKernelGGL(wino_input_kernel, dim3(ceil_div(T * (Cin / 4), 256)), dim3(256), 0, st, x, V, N, H, W, Cin, in_cstride, th, tw,
                        make_fastdiv((unsigned)(Cin / 4)), dtw, dth);
+  else if (S == 1)
+    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 1>), dim3(ceil_div(T * (CT / kWino4Vec), 256)), dim3(256), 0, st, x, V, N, H, W, Cin,
+                       in_cstride, th, tw, make_fastdiv((unsigned)(CT / kWino4Vec)), dtw, dth);
   else
-    hipLaunchKernelGGL(wino4_input_kernel<kWino4Vec>, dim3(ceil_div(T * (Cin / kWino4Vec), 256)), dim3(256), 0, st, x, V, N, H, W, Cin,
-                       in_cstride, th, tw, make_fastdiv((unsigned)(Cin / kWino4Vec)), dtw, dth);
+    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 2>), dim3(ceil_div(T * (CT / kWino4Vec), 256)), dim3(256), 0, st, x, V, N, H, W, Cin,
+                       in_cstride, th, tw, make_fastdiv((unsigned)(CT / kWino4Vec)), dtw, dth);
   int rc = check_launch("winograd_input");
   if (rc != DIM_OK) return rc;
   DIM_WINO_EVENT(1)
   ConvEx ex = {};
   ex.pad_w = -1;
   ex.batch = nk;
-  ex.bx = T * Cin;
-  ex.bw = (long)Cin * Cout;
+  ex.bx = T * CT;
+  ex.bw = (long)CT * Cout;
   ex.by = T * Cout;
-  rc = conv2d_fwd_impl(V, w_packed, nullptr, M, nullptr, 1, 1, (int)T, Cin, Cout, 1, 1, 1, 0, 1.0f, 1, tile, 0, stream, &ex);
+  rc = conv2d_fwd_impl(V, w_packed, nullptr, M, nullptr, 1, 1, (int)T, CT, Cout, 1, 1, 1, 0, 1.0f, 1, tile, 0, stream, &ex);
   if (rc != DIM_OK) return rc;
   DIM_WINO_EVENT(2)
   if (m == 2)
-    hipLaunchKernelGGL(wino_output_kernel, dim3(ceil_div(T * (Cout / 4), 256)), dim3(256), 0, st, M, bias, y, N, H, W, Cout, out_cstride,
+    hipLaunchKernelGGL(wino_output_kernel, dim3(ceil_div(T * (Cout / 4), 256)), dim3(256), 0, st, M, bias, y, N, Ho, Wo, Cout, out_cstride,
                        out_coff, th, tw, slope, make_fastdiv((unsigned)(Cout / 4)), dtw, dth);
   else
-    hipLaunchKernelGGL(wino4_output_kernel<kWino4Vec>, dim3(ceil_div(T * (Cout / kWino4Vec), 256)), dim3(256), 0, st, M, bias, y, N, H, W,
+    hipLaunchKernelGGL(wino4_output_kernel<kWino4Vec>, dim3(ceil_div(T * (Cout / kWino4Vec), 256)), dim3(256), 0, st, M, bias, y, N, Ho, Wo,
                        Cout, out_cstride, out_coff, th, tw, slope, make_fastdiv((unsigned)(Cout / kWino4Vec)), dtw, dth);
   rc = check_launch("winograd_output");
   DIM_WINO_EVENT(3)
 #undef DIM_WINO_EVENT
   return rc;
+}
+
+int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
+                            int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, int m,
+                            void** events4, void* stream) {
+  return winograd_impl(x, w_packed, bias, y, workspace, N, H, W, Cin, in_cstride, Cout, out_cstride, out_coff, slope, tile, m, 1, events4,
+                       stream);
+}
+
+long dim_winograd5x5s2_packed_weight_floats(int Cout, int Cin) { return 36L * Cout * 4 * Cin; }
+
+long dim_winograd5x5s2_workspace_floats(int N, int H, int W, int Cin, int Cout) {
+  long T = (long)N * (((H + 1) / 2 + 3) / 4) * (((W + 1) / 2 + 3) / 4);
+  return 36 * T * (4L * Cin + Cout);
+}
+
+int dim_winograd5x5s2_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream) {
+  DIM_REQUIRE(w_oihw && w_packed, "null weight pointer");
+  DIM_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "Cin %% 32 == 0 and Cout %% 64 == 0 required");
+  long total = 4L * Cout * Cin;
+  hipLaunchKernelGGL(wino4_pack_weight_5x5s2_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout,
+                     Cin);
+  return check_launch("winograd5x5s2_pack_weight");
+}
+
+int dim_conv2d_fwd_winograd5x5s2(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
+                                 int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, void** events4,
+                                 void* stream) {
+  return winograd_impl(x, w_packed, bias, y, workspace, N, H, W, Cin, in_cstride, Cout, out_cstride, out_coff, slope, tile, 4, 2, events4,
+                       stream);
 }
 
 }  // extern "C"

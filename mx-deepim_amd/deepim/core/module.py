@@ -141,6 +141,8 @@ class MutableModule(object):
             if forward:
                 if name in net.wino:   # 3x3 / stride-1 layers run their forward through Winograd: re-transform the weights
                     net.wino[name] = ops.winograd_pack_weight(w[name + "_weight"], m=net.wino_m[name])
+                elif name in net.wino5:  # 5x5 / stride-2 layers: phase-image Winograd forward (the backward stays direct)
+                    net.wino5[name] = ops.winograd5x5s2_pack_weight(w[name + "_weight"])
                 else:
                     net.packed[name] = ops.conv2d_pack_weight(w[name + "_weight"])
             if name in net.wino:

@@ -164,7 +164,8 @@ class FlowNetHip(object):
 
     def __init__(self, cfg, arg_params, batch_size, device="cuda:0", conv_plan=None, winograd=True, wino_m=None, wino_tile=None):
         """winograd: run the 3x3 / stride-1 layers (conv3_1, conv4_1, conv5_1, conv6_1) through Winograd F(4x4,3x3) / F(2x2,3x3)
-        (same f32 result within 1e-4 relative, 4x / 2.25x fewer multiply-adds).  False = direct kernel for every layer.
+        (same f32 result within 1e-4 relative, 4x / 2.25x fewer multiply-adds) and the 5x5 / stride-2 layers (conv2, conv3) through
+        their four phase images and F(4x4,3x3) (2.78x fewer).  False = direct kernel for every layer.
         wino_m / wino_tile: optional {layer: output tile edge 2|4} / {layer: GEMM workgroup tile 3|4} overrides."""
         self.cfg = cfg
         self.B = batch_size
@@ -178,9 +179,11 @@ class FlowNetHip(object):
         for name, cout, k, s, p in ENCODER:
             self.packed[name] = ops.conv2d_pack_weight(self.params[name + "_weight"])
         self.packed["fc6"] = ops.fc_pack_weight(self.params["fc6_weight"], 1024, 8, 10)
-        self.wino, self.wino_m = {}, {}
+        self.wino, self.wino_m, self.wino5 = {}, {}, {}
         if winograd:
             for name, cout, k, s, p in ENCODER:
+                if k == 5 and s == 2 and p == 2:  # conv2, conv3: four phase images through F(4x4,3x3), 36 GEMMs with K = 4 Cin
+                    self.wino5[name] = ops.winograd5x5s2_pack_weight(self.params[name + "_weight"])
                 if k == 3 and s == 1 and p == 1:
                     # output tile edge: F(4x4,3x3) (4x fewer multiply-adds) by default
                     self.wino_m[name] = int((wino_m or {}).get(name, WINO_M_DEFAULT.get(name, 4)))
@@ -212,8 +215,13 @@ class FlowNetHip(object):
                 m = self.wino_m[name]
                 tiles = B * (-(-h // m)) * (-(-w // m))
                 wt = (wino_tile or {}).get(name, 4 if (cout % 128 == 0 and tiles >= 1024) else 3)
-                self.layer_info[name].update(winograd=True, wino_m=m, wino_tile=wt, wino_flops=2 * (m + 2) ** 2 * tiles * c * cout)
+                self.layer_info[name].update(self._wino_info(m, 1, wt, tiles, c, cout, B * h * w * c, B * ho * wo * cout))
                 max_ws = max(max_ws, ops.lib().dim_winograd_workspace_floats(B, h, w, c, cout, m))
+            if name in self.wino5:
+                tiles = B * (-(-ho // 4)) * (-(-wo // 4))
+                wt = (wino_tile or {}).get(name, 4 if (cout % 128 == 0 and tiles >= 1024) else 3)
+                self.layer_info[name].update(self._wino_info(4, 2, wt, tiles, c, cout, B * h * w * c, B * ho * wo * cout))
+                max_ws = max(max_ws, ops.lib().dim_winograd5x5s2_workspace_floats(B, h, w, c, cout))
             h, w, c = ho, wo, cout
         assert (h, w, c) == (8, 10, 1024)
         tile, splits = self.conv_plan["fc6"]
@@ -248,6 +256,17 @@ class FlowNetHip(object):
         self.status = torch.zeros((B,), dtype=torch.int32, device=d)
         torch.cuda.synchronize(d)
 
+    @staticmethod
+    def _wino_info(m, S, tile, tiles, cin, cout, x_floats, y_floats):
+        """accounting of one Winograd layer for bench.py: the batched GEMM (planes x [tiles x K] . [K x cout]) and the algorithmic
+        bytes of the two transform kernels (read x + write V; read M + write y)"""
+        planes, K = (m + 2) ** 2, cin * S * S
+        return dict(winograd=True, wino_m=m, wino_tile=tile, wino_planes=planes, wino_rows=tiles, wino_k=K,
+                    wino_flops=2 * planes * tiles * K * cout, wino_gemm_bytes=4 * planes * (tiles * K + K * cout + tiles * cout),
+                    wino_in_bytes=4 * (x_floats + planes * tiles * K), wino_out_bytes=4 * (planes * tiles * cout + y_floats),
+                    wino_in_kernel="dim::wino_input_kernel" if m == 2 else "dim::wino4_input_kernel<2, %d>" % S,
+                    wino_out_kernel="dim::wino_output_kernel" if m == 2 else "dim::wino4_output_kernel<2>")
+
     # ---- pieces -------------------------------------------------------------------------------
     def zoom(self, batch, bbox_ren=None, nchw_out=None, bbox_obs=None, src_pose=None, status=None):
         """ZoomMask + ZoomImageWithFactor + Concat (reference :783-806, :53-60).  At test time
@@ -271,6 +290,11 @@ class FlowNetHip(object):
                 x = ops.conv2d_fwd_winograd(x, x.shape[-1], self.wino[name], self.params[name + "_bias"], cout, slope=0.1,
                                             tile=self.layer_info[name]["wino_tile"], out=self.acts[name], workspace=self.workspace,
                                             events=None if events is None else events.setdefault(name, []), m=self.wino_m[name])
+                continue
+            if name in self.wino5:
+                x = ops.conv2d_fwd_winograd5x5s2(x, x.shape[-1], self.wino5[name], self.params[name + "_bias"], cout, slope=0.1,
+                                                 tile=self.layer_info[name]["wino_tile"], out=self.acts[name], workspace=self.workspace,
+                                                 events=None if events is None else events.setdefault(name, []))
                 continue
             tile, splits = self.conv_plan[name]
             x = ops.conv2d_fwd(x, self.packed[name], self.params[name + "_bias"], cout, k, k, s, p, slope=0.1, splits=splits, tile=tile,

@@ -213,6 +213,41 @@ def conv2d_fwd_winograd(x_nhwc, Cin, w_packed, bias, Cout, slope=0.1, tile=0, ou
     return out
 
 
+
+def winograd5x5s2_pack_weight(w_oihw):
+    """(Cout,Cin,5,5) of a stride-2 / pad-2 layer -> the 36 transformed weight sets (K = 4 Cin) of dim_conv2d_fwd_winograd5x5s2"""
+    Cout, Cin, KH, KW = w_oihw.shape
+    assert KH == 5 and KW == 5
+    out = _new((lib().dim_winograd5x5s2_packed_weight_floats(Cout, Cin),), w_oihw)
+    check(lib().dim_winograd5x5s2_pack_weight(dptr(w_oihw, f32), dptr(out, f32), Cout, Cin, current_stream()))
+    return out
+
+
+def _wino_events(events):
+    import ctypes
+
+    if events is None:
+        return None, None
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for e in evs:
+        e.record()  # materialises the hipEvent_t behind the torch object
+    return (ctypes.c_void_p * 4)(*[e.cuda_event for e in evs]), evs
+
+
+def conv2d_fwd_winograd5x5s2(x_nhwc, Cin, w_packed, bias, Cout, slope=0.1, tile=0, out=None, out_coff=0, workspace=None, events=None):
+    """5x5 / stride 2 / pad 2 convolution as four phase images through Winograd F(4x4,3x3) (see include/deepim_hip.h)."""
+    ev_arr, evs = _wino_events(events)
+    N, H, W, in_cs = x_nhwc.shape
+    out = out if out is not None else _new((N, (H + 1) // 2, (W + 1) // 2, Cout), x_nhwc)
+    need = lib().dim_winograd5x5s2_workspace_floats(N, H, W, Cin, Cout)
+    if workspace is None or workspace.numel() < need:
+        workspace = _new((need,), x_nhwc)
+    check(lib().dim_conv2d_fwd_winograd5x5s2(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), dptr(workspace, f32),
+                                             N, H, W, Cin, in_cs, Cout, out.shape[-1], out_coff, float(slope), tile, ev_arr, current_stream()))
+    if events is not None:
+        events.extend([("wino_in", evs[0], evs[1]), ("conv", evs[1], evs[2]), ("wino_out", evs[2], evs[3])])
+    return out
+
 def conv2d_fwd(x_nhwc, w_packed, bias, Cout, KH, KW, stride, pad, slope=0.1, splits=1, tile=0, out=None, workspace=None,
                events=None):
     """splits: 1 = one launch; > 1 = split-K through `workspace`; 0 = auto (whole tiles per CU in one launch, the remaining tiles

@@ -427,6 +427,37 @@ def test_conv3x3_winograd_vs_f64(hip_lib, shape, m):
     assert np.all(o[..., :32] == 7.0) and np.all(o[..., 32 + Cout:] == 7.0)
 
 
+@pytest.mark.parametrize("shape", [(2, 30, 40, 64, 128), (1, 16, 24, 32, 64), (2, 15, 21, 64, 64), (1, 6, 9, 32, 128), (3, 60, 80, 128, 256)])
+def test_conv5x5s2_winograd_vs_f64(hip_lib, shape):
+    """5x5 / stride-2 / pad-2 layer (conv2, conv3) as four phase images through Winograd F(4x4,3x3): even and odd H/W, partial
+    tiles, bias + LeakyReLU, strided output, padded input channels -- vs torch-CPU float64 conv2d and vs the direct MFMA kernel"""
+    import torch.nn.functional as F
+    from lib.hip import ops
+
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 5, 5), generator=g) * (1.0 / np.sqrt(25 * Cin))
+    b = torch.randn((Cout,), generator=g) * 0.1
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=2), 0.1).permute(0, 2, 3, 1).numpy()
+    xd = x.permute(0, 2, 3, 1).contiguous().to("cuda:0")
+    wp = ops.winograd5x5s2_pack_weight(w.to("cuda:0"))
+    for tile in (3, 4) if Cout % 128 == 0 else (3,):
+        y = ops.conv2d_fwd_winograd5x5s2(xd, Cin, wp, b.to("cuda:0"), Cout, slope=0.1, tile=tile).cpu().numpy()
+        assert y.shape == ref.shape
+        err = np.abs(y - ref).max()
+        assert err <= 1e-4 * np.abs(ref).max() + 2e-5, (tile, err)
+    yd = ops.conv2d_fwd(xd, ops.conv2d_pack_weight(w.to("cuda:0")), b.to("cuda:0"), Cout, 5, 5, 2, 2, slope=0.1, tile=3).cpu().numpy()
+    assert np.abs(y - yd).max() <= 1e-4 * np.abs(ref).max() + 2e-5
+    xd2 = torch.zeros((N, H, W, Cin + 32), device="cuda:0")
+    xd2[..., :Cin] = xd
+    out = torch.full(ref.shape[:3] + (Cout + 64,), 7.0, device="cuda:0")
+    ops.conv2d_fwd_winograd5x5s2(xd2, Cin, wp, b.to("cuda:0"), Cout, slope=0.1, tile=3, out=out, out_coff=32)
+    o = out.cpu().numpy()
+    assert np.abs(o[..., 32:32 + Cout] - ref).max() <= 1e-4 * np.abs(ref).max() + 2e-5
+    assert np.all(o[..., :32] == 7.0) and np.all(o[..., 32 + Cout:] == 7.0)
+
+
 @pytest.mark.parametrize("shape,tile", [((16, 60, 80, 64, 256, 3, 1, 1), 4), ((9, 120, 160, 32, 128, 3, 2, 1), 4), ((6, 96, 128, 32, 64, 3, 1, 1), 3)])
 def test_conv_auto_split_tail_vs_f64(hip_lib, shape, tile):
     """splits = 0: whole tiles per CU in one launch + split-K tail (dim_conv2d_tail_plan confirms the two-launch path) vs float64"""
