@@ -25,6 +25,10 @@ inline int check_launch(const char* what) {
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// wino_gemm.hip: the P plane GEMMs of a Winograd layer as one persistent stream-K launch.  V [T][P][K], U [P][K/32][Cout][32],
+// M [T][P][Cout]; tile 4 = 128x128 workgroup tiles, otherwise 64x64.
+int launch_wino_gemm(const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile, hipStream_t st);
+
 // Unsigned division by a launch-time constant in 4 VALU ops (Granlund-Montgomery): q = (t + ((n - t) >> s1)) >> s2,
 // t = mulhi(n, mul).  Exact for every 32-bit n and d >= 1.  Kernels that decode a pixel index every K step use it instead
 // of the ~20-instruction integer division sequence.

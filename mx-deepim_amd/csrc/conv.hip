@@ -1028,15 +1028,14 @@ int dim_pose_head_fwd(const float* fc6, const float* fc7_w, const float* fc7_b, 
 // ------------------------------------------------------------------------------------------------ Winograd F(2x2, 3x3)
 // 3x3 / stride 1 / pad 1 layers (conv3_1, conv4_1, conv5_1, conv6_1 of deepIM_flownet.py:103-191) as
 //   V = B^T d B  (input tiles 4x4, stride 2)  ->  16 independent GEMMs  M_k = V_k (T x Cin) * U_k (Cin x Cout)  ->  Y = A^T M A
-// 2.25x fewer multiply-adds than the direct form; the GEMMs run as ONE batched launch of conv_fwd_kernel (a 1x1 "convolution"
-// over T tile-pixels, blockIdx.y = k).  Transforms are exact in the sense of using only +,- on the data (B, A have entries
+// 2.25x fewer multiply-adds than the direct form; the GEMMs run as ONE persistent stream-K launch (wino_gemm.hip).  Transforms are exact in the sense of using only +,- on the data (B, A have entries
 // 0, +-1); the weight transform G (entries 1, 1/2) is applied once at pack time.  f32 throughout.
 namespace dim {
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-// V[k][t][c]: thread = (tile t, channel quad)
+// V[t][k][c]: thread = (tile t, channel quad)
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C,
                                                          int in_cstride, int th, int tw, FastDiv div_cq, FastDiv div_tw, FastDiv div_th) {
   const unsigned idx = blockIdx.x * 256u + threadIdx.x;
@@ -1069,8 +1068,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     tmp[2][b] = f4sub(d[2][b], d[1][b]);
     tmp[3][b] = f4sub(d[1][b], d[3][b]);
   }
-  const long plane = (long)T * C;
-  float* out = V + (long)t * C + cq * 4;
+  const long plane = C;  // V [t][k][c]: the 16 planes of a tile are consecutive K columns of its row (wino_gemm.hip)
+  float* out = V + (long)t * 16 * C + cq * 4;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {  // (.) B
     *reinterpret_cast<float4*>(out + (a * 4 + 0) * plane) = f4sub(tmp[a][0], tmp[a][2]);
@@ -1094,8 +1093,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   const unsigned tx = t - r * tw;
   const unsigned n = fastdiv(r, div_th);
   const unsigned ty = r - n * th;
-  const long plane = (long)T * C;
-  const float* in = M + (long)t * C + cq * 4;
+  const long plane = C;  // M [t][k][c]
+  const float* in = M + (long)t * 16 * C + cq * 4;
   float4 m[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -1178,7 +1177,7 @@ struct WinoVec {
     O[5 * S] = D[1] + 1.5f * D[2] - 2.f * D[3] - 1.5f * D[4] + D[5];                    \
   }
 
-// V[k][t][c], k = 6a + b: thread = (tile t, VEC channels).
+// V[t][k][c], k = 6a + b: thread = (tile t, VEC channels).
 // S = 1: a 3x3 / stride-1 / pad-1 layer.  S = 2: a 5x5 / stride-2 / pad-2 layer as the sum of four 3x3 / stride-1 / pad-1
 // convolutions of its phase images X^(py,px)[r][q] = x[2r + py][2q + px] (sub-kernels g[u][v] = w[2u + py][2v + px], zero beyond
 // the 5 taps): the four transformed phase tiles are concatenated along the channels, V has 4C of them (phase-major), so that ONE
@@ -1223,8 +1222,8 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     vf* o = tmp + b;
     DIM_WINO4_BT(o, d, 6)
   }
-  const long plane = (long)T * CT;
-  float* out = V + (long)t * CT + cc;
+  const long plane = CT;  // V [t][k][c]
+  float* out = V + (long)t * 36 * CT + cc;
 #pragma unroll
   for (int a = 0; a < 6; ++a) {  // (.) B
     vf o[6];
@@ -1261,8 +1260,8 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
   const unsigned tx = t - r * tw;
   const unsigned n = fastdiv(r, div_th);
   const unsigned ty = r - n * th;
-  const long plane = (long)T * C;
-  const float* in = M + (long)t * C + cq * VEC;
+  const long plane = C;  // M [t][k][c]
+  const float* in = M + (long)t * 36 * C + cq * VEC;
   vf rr[24];  // A^T m: rr[4 rows][6 columns]
 #pragma unroll
   for (int b = 0; b < 6; ++b) {
@@ -1408,13 +1407,8 @@ static int winograd_impl(const float* x, const float* w_packed, const float* bia
   int rc = check_launch("winograd_input");
   if (rc != DIM_OK) return rc;
   DIM_WINO_EVENT(1)
-  ConvEx ex = {};
-  ex.pad_w = -1;
-  ex.batch = nk;
-  ex.bx = T * CT;
-  ex.bw = (long)CT * Cout;
-  ex.by = T * Cout;
-  rc = conv2d_fwd_impl(V, w_packed, nullptr, M, nullptr, 1, 1, (int)T, CT, Cout, 1, 1, 1, 0, 1.0f, 1, tile, 0, stream, &ex);
+  if (tile == 0) tile = (Cout % 128 == 0 && T >= 1024) ? 4 : 3;
+  rc = launch_wino_gemm(V, w_packed, M, (int)T, CT, Cout, nk, tile, st);
   if (rc != DIM_OK) return rc;
   DIM_WINO_EVENT(2)
   if (m == 2)

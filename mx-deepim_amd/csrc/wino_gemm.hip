@@ -1,0 +1,307 @@
+// The P independent GEMMs of a Winograd layer (P = 16 or 36 planes:  M_p[T x Cout] = V_p[T x K] . U_p[K x Cout]) as ONE persistent
+// launch.  (deepim/symbols/deepIM_flownet.py:95-191 are the layers; see conv.hip for the transforms around this kernel.)
+//
+// Why not blockIdx.y = plane on conv_fwd_kernel (the first version): a plane's K loop is only K / 32 = 8 or 16 chunks long, so
+// every workgroup paid its pipeline fill (first global loads -> LDS -> barrier) and its drain (epilogue stores, exit, dispatch of
+// the successor) for that little work -- measured 2.1 chunk-times per (plane, tile), 103-115 TFLOP/s against 127-134 for the long
+// loops of the direct layers -- and tiles x planes workgroups of equal length quantise badly on 512 resident slots (conv3: 2736
+// workgroups = 5.34 rounds -> 6).
+//
+// Here the (row tile, Cout tile, plane, K chunk) space is ONE flat list of chunks, dealt in equal contiguous ranges to exactly as
+// many workgroups as are resident at once (stream-K).  A workgroup walks its range with the software pipeline of conv_fwd_kernel
+// never draining: the prefetch of the next (plane, tile)'s first chunks is in flight while the last chunk of the current one is
+// multiplied; at the end of an item the accumulators are stored and cleared between two chunks.  Ranges start and end anywhere,
+// so at most one item per workgroup boundary is shared by two workgroups; its output tile is zeroed beforehand
+// (wino_gemm_zero_kernel) and both add their partial sums with float atomics -- two summands on a zero: the result does not
+// depend on their order, the launch stays deterministic.
+//
+// Layouts (plane-minor, so that "next plane" is just "next K columns" for the loader):
+//   V [T][P][K]      row stride P*K floats
+//   U [P][K/32][Cout][32]   = the packed 1x1 weights of conv_fwd_kernel, plane-major: flat chunk index p*K/32 + c
+//   M [T][P][Cout]   row stride P*Cout floats
+#include "common.h"
+
+namespace dim {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WGemmArgs {
+  const float* V;
+  const float* U;
+  float* M;
+  int T, K, Cout, P;
+  int nch;       // K / 32
+  int NTN;       // Cout / BN
+  int per, rem;  // chunks per workgroup: per, +1 for the first rem workgroups
+  unsigned v_bytes, u_bytes, m_bytes;
+  FastDiv d_nch, d_P, d_NTN;
+};
+
+// position in the flat chunk list: item = (mt * NTN + nt) * P + p, chunk ch of it
+struct WCur {
+  int ch, p, nt, mt;
+};
+__device__ __forceinline__ WCur wcur_decode(int chunk, const WGemmArgs& a) {
+  WCur c;
+  const unsigned item = fastdiv((unsigned)chunk, a.d_nch);
+  c.ch = chunk - (int)item * a.nch;
+  const unsigned t = fastdiv(item, a.d_P);
+  c.p = (int)(item - t * a.P);
+  const unsigned mt = fastdiv(t, a.d_NTN);
+  c.nt = (int)(t - mt * a.NTN);
+  c.mt = (int)mt;
+  return c;
+}
+__device__ __forceinline__ void wcur_advance(WCur& c, const WGemmArgs& a) {
+  if (++c.ch == a.nch) {
+    c.ch = 0;
+    if (++c.p == a.P) {
+      c.p = 0;
+      if (++c.nt == a.NTN) {
+        c.nt = 0;
+        ++c.mt;
+      }
+    }
+  }
+}
+__device__ __forceinline__ int wg_first_chunk(int w, const WGemmArgs& a) { return w * a.per + min(w, a.rem); }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void wino_gemm_kernel(WGemmArgs a) {
+  constexpr int BK = 32;
+  constexpr int NT = WM * WN * 64;
+  constexpr int RP = NT / 8;   // rows staged per pass (8 threads x float4 = one 32-float row)
+  constexpr int LDK = BK + 4;  // conflict-free for ds_write_b128 staging and ds_read_b128 fragments (see conv.hip)
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  static_assert(BM / RP == 2, "two staging loads per thread");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;  // [2][BM][LDK]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int q = tid & 7;
+  const int srow = tid >> 3;
+  const int frow = lane & 31;
+  const int khalf = lane >> 5;
+
+  const int c_begin = wg_first_chunk(blockIdx.x, a);
+  const int c_end = wg_first_chunk(blockIdx.x + 1, a);
+
+  const int RS = a.P * a.K;  // V row stride (floats)
+  const int a_voff0 = (srow * RS + q * 4) * 4;
+  const int a_voff1 = a_voff0 + RP * RS * 4;
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V), 0, a.v_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.U), 0, a.u_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, a.m_bytes, 0x00020000);
+  const int wchunk_bytes = a.Cout * BK * 4;
+
+  // three cursors into the chunk list: L = next A chunk to load (runs two ahead), Bc = next B fragments (one ahead), C = compute
+  WCur L = wcur_decode(c_begin, a), Bc = L, C = L;
+
+  float4 ra0, ra1;  // staging registers of the A chunk (named: arrays ended up in scratch)
+  // rows past T read as zeros through the descriptor's range check (offset 0xFFFFFFFF); so does every load past the range's end.
+  // The scalar offset is NOT range-checked, which is fine: it is only ever added to an in-range or a rejected vector offset.
+#define W_LOAD_CHUNK(PF_OK)                                                            \
+  {                                                                                    \
+    const bool pf = (PF_OK);                                                           \
+    const int mb = L.mt * BM;                                                          \
+    const int soff = (int)((unsigned)(mb * RS + L.p * a.K + L.ch * BK) * 4u);          \
+    ra0 = buf_load16(rv, (pf && mb + srow < a.T) ? a_voff0 : -1, soff);                \
+    ra1 = buf_load16(rv, (pf && mb + srow + RP < a.T) ? a_voff1 : -1, soff);           \
+    wcur_advance(L, a);                                                                \
+  }
+#define W_STORE_CHUNK(BUF)                                                             \
+  {                                                                                    \
+    float* dA = sA + (BUF) * BM * LDK;                                                 \
+    *reinterpret_cast<float4*>(dA + srow * LDK + q * 4) = ra0;                         \
+    *reinterpret_cast<float4*>(dA + (srow + RP) * LDK + q * 4) = ra1;                  \
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int a_off = (wm * (BM / WM) + frow) * LDK + 4 * khalf;
+  float4 fa[2][TM];
+#define W_FRAG_READ(IDX, PA, S)                                                                                        \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[IDX][i] = *reinterpret_cast<const float4*>((PA) + 32 * i * LDK + 8 * (S)); \
+  }
+  // B fragments straight from L2, one chunk ahead (fbq[set][group][tile]); past the end of the range: chunk 0 (unused values)
+  float4 fbq[2][4][TN];
+  const int bf_voff = ((wn * (BN / WN) + frow) * BK + 4 * khalf) * 4;
+#define W_LOAD_BFRAG(SET, VALID)                                                                                       \
+  {                                                                                                                    \
+    const int bsoff = (VALID) ? (Bc.p * a.nch + Bc.ch) * wchunk_bytes + Bc.nt * BN * BK * 4 : 0;                        \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) _Pragma("unroll") for (int j = 0; j < TN; ++j)                        \
+      fbq[SET][g][j] = buf_load16(ru, bf_voff + (32 * j * BK + 8 * g) * 4, bsoff);                                      \
+    wcur_advance(Bc, a);                                                                                               \
+  }
+#define W_MFMA_GROUP(IDX, SET, G)                                                                                      \
+  {                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].x, fbq[SET][G][j].x, acc[i][j], 0, 0, 0);             \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].y, fbq[SET][G][j].y, acc[i][j], 0, 0, 0);             \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].z, fbq[SET][G][j].z, acc[i][j], 0, 0, 0);             \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[IDX][i].w, fbq[SET][G][j].w, acc[i][j], 0, 0, 0);             \
+    }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  }
+
+  // ---- output: D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int ldc = a.P * a.Cout;
+  const int o_row = wm * (BM / WM) + 4 * khalf;  // + 32 i + (r & 3) + 8 (r >> 2)
+  const int o_col = wn * (BN / WN) + frow;       // + 32 j
+  const int o_voff = (o_row * ldc + o_col) * 4;
+  // `whole`: this workgroup has multiplied every chunk of the current item -> plain stores; otherwise the item is shared with the
+  // neighbouring workgroup, its tile was zeroed before the launch, and both add
+  bool whole = C.ch == 0;
+#define W_FLUSH_CHECK(KCUR)                                                                                            \
+  {                                                                                                                    \
+    const bool item_end = C.ch == a.nch - 1;                                                                           \
+    if (item_end || (KCUR) == c_end - 1) {                                                                             \
+      const int mb = C.mt * BM;                                                                                        \
+      const int cb = C.p * a.Cout + C.nt * BN;                                                                         \
+      const int lim = a.T - mb;                                                                                        \
+      int ov = o_voff, orow = o_row; /* opaque copies: keeps the 32 store offsets from being hoisted out of the K loop */ \
+      asm volatile("" : "+v"(ov), "+v"(orow));                                                                         \
+      const int soff = (int)((unsigned)(mb * ldc + cb) * 4u);                                                          \
+      const bool plain = whole && item_end;                                                                            \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                               \
+          const int dr = 32 * i + (r & 3) + 8 * (r >> 2);                                                              \
+          const int vo = (orow + dr < lim) ? ov + (dr * ldc + 32 * j) * 4 : -1; /* rows past T: rejected by the range check */ \
+          if (plain)                                                                                                   \
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rm, vo, soff, 0);                     \
+          else if (vo != -1) /* exec-masked rather than rejected: an out-of-range buffer ATOMIC faulted on this part */  \
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][r], rm, vo, soff, 0);                            \
+        }                                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;                                             \
+      whole = true;                                                                                                    \
+    }                                                                                                                  \
+    wcur_advance(C, a);                                                                                                \
+  }
+
+  // ---- software pipeline per chunk of 32 (four MFMA groups), as in conv_fwd_kernel:
+  //   g0 | g1 | [registers -> LDS for chunk k+1, global loads for chunk k+2] | g2 | LDS barrier | [fragments g0 of chunk k+1] | g3
+  W_LOAD_CHUNK(true)
+  W_STORE_CHUNK(0)
+  W_LOAD_BFRAG(0, true)
+  __syncthreads();
+  W_LOAD_CHUNK(c_begin + 1 < c_end)
+  W_FRAG_READ(0, sA + a_off, 0)
+
+#define W_CHUNK_BODY(SET, KCUR)                                                        \
+  {                                                                                    \
+    const float* cA = sA + buf * BM * LDK + a_off;                                     \
+    const float* nA = sA + (buf ^ 1) * BM * LDK + a_off;                               \
+    W_LOAD_BFRAG(1 - SET, (KCUR) + 1 < c_end)                                          \
+    W_FRAG_READ(1, cA, 1)                                                              \
+    W_MFMA_GROUP(0, SET, 0)                                                            \
+    W_FRAG_READ(0, cA, 2)                                                              \
+    W_MFMA_GROUP(1, SET, 1)                                                            \
+    W_STORE_CHUNK(buf ^ 1)                                                             \
+    W_LOAD_CHUNK((KCUR) + 2 < c_end)                                                   \
+    W_FRAG_READ(1, cA, 3)                                                              \
+    W_MFMA_GROUP(0, SET, 2)                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                    \
+    W_FRAG_READ(0, nA, 0)                                                              \
+    W_MFMA_GROUP(1, SET, 3)                                                            \
+    buf ^= 1;                                                                          \
+    W_FLUSH_CHECK(KCUR)                                                                \
+  }
+  int buf = 0;
+  for (int kc = c_begin; kc < c_end; kc += 2) {
+    W_CHUNK_BODY(0, kc)
+    if (kc + 1 < c_end) W_CHUNK_BODY(1, kc + 1)
+  }
+#undef W_CHUNK_BODY
+#undef W_FLUSH_CHECK
+#undef W_MFMA_GROUP
+#undef W_LOAD_BFRAG
+#undef W_FRAG_READ
+#undef W_STORE_CHUNK
+#undef W_LOAD_CHUNK
+}
+
+// zero the output tile of every item that two workgroups share (the one a range boundary falls into)
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void wino_gemm_zero_kernel(WGemmArgs a) {
+  const int w = blockIdx.x + 1;
+  const int cb = wg_first_chunk(w, a);
+  const WCur c = wcur_decode(cb, a);
+  if (c.ch == 0) return;  // the boundary coincides with an item boundary
+  const int ldc = a.P * a.Cout;
+  float* base = a.M + (long)c.mt * BM * ldc + c.p * a.Cout + c.nt * BN;
+  const int rows = min(BM, a.T - c.mt * BM);
+  for (int idx = threadIdx.x; idx < rows * (BN / 4); idx += 256) {
+    const int r = idx / (BN / 4), c4 = idx - r * (BN / 4);
+    *reinterpret_cast<float4*>(base + (long)r * ldc + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_wino_gemm_t(WGemmArgs a, int T, int items, hipStream_t st) {
+  // as many workgroups as are resident at once (occupancy x CUs), never more than there are items: every range is then at
+  // least one item long and an item is shared by at most two workgroups
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 0, occ = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(&wino_gemm_kernel<BM, BN, WM, WN>),
+                                                       WM * WN * 64, 2 * BM * 36 * sizeof(float));
+    if (e != hipSuccess || cus <= 0 || occ <= 0) return set_err(DIM_ERR_LAUNCH, "winograd gemm occupancy query: %s", hipGetErrorString(e));
+    slots = cus * occ;
+  }
+  const int G = items < slots ? items : slots;
+  const long total = (long)items * a.nch;
+  a.per = (int)(total / G);
+  a.rem = (int)(total % G);
+  if (G > 1) hipLaunchKernelGGL((wino_gemm_zero_kernel<BM, BN>), dim3(G - 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN>), dim3(G), dim3(WM * WN * 64), 2 * BM * 36 * sizeof(float), st, a);
+  return check_launch("winograd_gemm");
+}
+
+// tile: 4 = 128x128 (8 waves), anything else = 64x64 (4 waves)
+int launch_wino_gemm(const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile, hipStream_t st) {
+  if (tile == 4 && Cout % 128 != 0) tile = 3;
+  const int BM = tile == 4 ? 128 : 64, BN = BM;
+  DIM_REQUIRE(K % 32 == 0 && Cout % BN == 0 && T > 0, "winograd gemm: K %% 32 == 0 and Cout %% 64 == 0 required");
+  const long MT = (T + BM - 1) / BM;
+  const long items = MT * (Cout / BN) * P;
+  DIM_REQUIRE(items * (K / 32) < (1L << 31) && (long)T * P * K * 4 < (1L << 32) && (long)T * P * Cout * 4 < (1L << 32) &&
+                  (long)P * K * Cout * 4 < (1L << 31) && (long)BM * P * (K > Cout ? K : Cout) * 4 < (1L << 31),
+              "winograd gemm: problem too large for 32-bit byte offsets (split the batch)");
+  WGemmArgs a = {};
+  a.V = V;
+  a.U = U;
+  a.M = M;
+  a.T = T;
+  a.K = K;
+  a.Cout = Cout;
+  a.P = P;
+  a.nch = K / 32;
+  a.NTN = Cout / BN;
+  a.v_bytes = (unsigned)((long)T * P * K * 4);
+  a.u_bytes = (unsigned)((long)P * K * Cout * 4);
+  a.m_bytes = (unsigned)((long)T * P * Cout * 4);
+  a.d_nch = make_fastdiv((unsigned)a.nch);
+  a.d_P = make_fastdiv((unsigned)P);
+  a.d_NTN = make_fastdiv((unsigned)a.NTN);
+  if (tile == 4) return launch_wino_gemm_t<128, 128, 2, 4>(a, T, (int)items, st);
+  return launch_wino_gemm_t<64, 64, 2, 2>(a, T, (int)items, st);
+}
+
+}  // namespace dim
