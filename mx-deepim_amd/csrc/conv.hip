@@ -1349,9 +1349,17 @@ extern "C" {
 
 long dim_winograd_packed_weight_floats(int Cout, int Cin, int m) { return (long)(m + 2) * (m + 2) * Cout * Cin; }
 
+// images per slice: tiles * planes * max(K, Cout) floats of one slice stay below 2^32 bytes (32-bit buffer offsets in the plane GEMMs)
+static long wino_slice_images(long tiles_per_image, int planes, long K, long Cout) {
+  const long per_image = tiles_per_image * planes * (K > Cout ? K : Cout) * 4;
+  return per_image < (1L << 32) ? ((1L << 32) - 1) / per_image : 0;
+}
+
 long dim_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int m) {
   if (m != 2 && m != 4) return 0;
-  long T = (long)N * ((H + m - 1) / m) * ((W + m - 1) / m);
+  const long per = (long)((H + m - 1) / m) * ((W + m - 1) / m);
+  const long ns = wino_slice_images(per, (m + 2) * (m + 2), Cin, Cout);
+  long T = (N < ns || ns == 0 ? (long)N : ns) * per;
   return (long)(m + 2) * (m + 2) * T * ((long)Cin + Cout);
 }
 
@@ -1367,24 +1375,15 @@ int dim_winograd_pack_weight(const float* w_oihw, float* w_packed, int Cout, int
   return check_launch("winograd_pack_weight");
 }
 
-// S = 1: 3x3 / stride 1 / pad 1 with output tile m; S = 2: 5x5 / stride 2 / pad 2 through its four phase images (m = 4)
-static int winograd_impl(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W, int Cin,
-                         int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, int m, int S, void** events4,
-                         void* stream) {
-  if (N == 0) return DIM_OK;
-  DIM_REQUIRE(x && w_packed && y && workspace, "null pointer");
-  DIM_REQUIRE(m == 2 || m == 4, "output tile m must be 2 or 4");
-  DIM_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "Cin %% 32 == 0 and Cout %% 64 == 0 required");
-  if (in_cstride == 0) in_cstride = Cin;
-  if (out_cstride == 0) out_cstride = Cout;
-  DIM_REQUIRE(in_cstride >= Cin && in_cstride % 4 == 0 && out_cstride >= out_coff + Cout && out_cstride % 4 == 0 && out_coff % 4 == 0,
-              "channel strides / offsets must be multiples of 4 and cover the channels");
+// one slice of the batch: T * planes * max(K, Cout) floats must stay below 2^32 bytes (32-bit buffer offsets in the GEMM)
+static int winograd_slice(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W, int Cin,
+                          int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, int m, int S, void** events4,
+                          void* stream) {
   const int Ho = S == 1 ? H : (H + 1) / 2, Wo = S == 1 ? W : (W + 1) / 2;  // 5x5 / s2 / p2: floor((H - 1) / 2) + 1
   const int CT = Cin * S * S;                                                  // contraction length of the GEMMs
   const int th = (Ho + m - 1) / m, tw = (Wo + m - 1) / m;
   const int nk = (m + 2) * (m + 2);
   const long T = (long)N * th * tw;
-  DIM_REQUIRE(T * (CT > Cout ? CT : Cout) / 2 < (1L << 32) && T < (1L << 31), "too many tiles");
   float* V = workspace;
   float* M = workspace + nk * T * CT;
   hipStream_t st = as_stream(stream);
@@ -1423,6 +1422,36 @@ static int winograd_impl(const float* x, const float* w_packed, const float* bia
   return rc;
 }
 
+// S = 1: 3x3 / stride 1 / pad 1 with output tile m; S = 2: 5x5 / stride 2 / pad 2 through its four phase images (m = 4).
+// Large batches run as several slices of whole images through the same workspace (stream order keeps them apart).
+static int winograd_impl(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W, int Cin,
+                         int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, int m, int S, void** events4,
+                         void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(x && w_packed && y && workspace, "null pointer");
+  DIM_REQUIRE(m == 2 || m == 4, "output tile m must be 2 or 4");
+  DIM_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "Cin %% 32 == 0 and Cout %% 64 == 0 required");
+  if (in_cstride == 0) in_cstride = Cin;
+  if (out_cstride == 0) out_cstride = Cout;
+  DIM_REQUIRE(in_cstride >= Cin && in_cstride % 4 == 0 && out_cstride >= out_coff + Cout && out_cstride % 4 == 0 && out_coff % 4 == 0,
+              "channel strides / offsets must be multiples of 4 and cover the channels");
+  const int Ho = S == 1 ? H : (H + 1) / 2, Wo = S == 1 ? W : (W + 1) / 2;
+  const long ns = wino_slice_images((long)((Ho + m - 1) / m) * ((Wo + m - 1) / m), (m + 2) * (m + 2), (long)Cin * S * S, Cout);
+  DIM_REQUIRE(ns > 0, "one image alone exceeds the 32-bit offsets of the plane GEMMs");
+  int n_slice = ns < N ? (int)ns : N;
+  if (const char* e = getenv("DIM_WINO_MAX_SLICE")) {  // test hook: force the slicing path at sizes a unit test can check
+    const int cap = atoi(e);
+    if (cap > 0 && cap < n_slice) n_slice = cap;
+  }
+  for (int n0 = 0; n0 < N; n0 += n_slice) {
+    const int n = N - n0 < n_slice ? N - n0 : n_slice;
+    int rc = winograd_slice(x + (long)n0 * H * W * in_cstride, w_packed, bias, y + (long)n0 * Ho * Wo * out_cstride, workspace, n, H, W, Cin,
+                            in_cstride, Cout, out_cstride, out_coff, slope, tile, m, S, n0 == 0 ? events4 : nullptr, stream);
+    if (rc != DIM_OK) return rc;
+  }
+  return DIM_OK;
+}
+
 int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
                             int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, int m,
                             void** events4, void* stream) {
@@ -1433,7 +1462,9 @@ int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* 
 long dim_winograd5x5s2_packed_weight_floats(int Cout, int Cin) { return 36L * Cout * 4 * Cin; }
 
 long dim_winograd5x5s2_workspace_floats(int N, int H, int W, int Cin, int Cout) {
-  long T = (long)N * (((H + 1) / 2 + 3) / 4) * (((W + 1) / 2 + 3) / 4);
+  const long per = (long)(((H + 1) / 2 + 3) / 4) * (((W + 1) / 2 + 3) / 4);
+  const long ns = wino_slice_images(per, 36, 4L * Cin, Cout);
+  long T = (N < ns || ns == 0 ? (long)N : ns) * per;
   return 36 * T * (4L * Cin + Cout);
 }
 

@@ -460,6 +460,26 @@ def test_conv5x5s2_winograd_vs_f64(hip_lib, shape):
     assert np.all(o[..., :32] == 7.0) and np.all(o[..., 32 + Cout:] == 7.0)
 
 
+def test_winograd_batch_slices(hip_lib, monkeypatch):
+    """batches whose transformed tiles would exceed the 32-bit offsets of the plane GEMMs run as slices of whole images through
+    the same workspace; DIM_WINO_MAX_SLICE forces that path at a size the test can check (5 images as 2 + 2 + 1)"""
+    from lib.hip import ops
+
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((5, 22, 30, 64), generator=g).to("cuda:0")
+    b = (torch.randn((128,), generator=g) * 0.1).to("cuda:0")
+    w3 = (torch.randn((128, 64, 3, 3), generator=g) * 0.05).to("cuda:0")
+    w5 = (torch.randn((128, 64, 5, 5), generator=g) * 0.03).to("cuda:0")
+    wp3, wp5 = ops.winograd_pack_weight(w3, m=4), ops.winograd5x5s2_pack_weight(w5)
+    ws = torch.empty(ops.lib().dim_winograd5x5s2_workspace_floats(5, 22, 30, 64, 128) + ops.lib().dim_winograd_workspace_floats(5, 22, 30, 64, 128, 4),
+                     device="cuda:0")
+    whole3 = ops.conv2d_fwd_winograd(x, 64, wp3, b, 128, m=4, workspace=ws).clone()
+    whole5 = ops.conv2d_fwd_winograd5x5s2(x, 64, wp5, b, 128, workspace=ws).clone()
+    monkeypatch.setenv("DIM_WINO_MAX_SLICE", "2")
+    np.testing.assert_array_equal(ops.conv2d_fwd_winograd(x, 64, wp3, b, 128, m=4, workspace=ws).cpu().numpy(), whole3.cpu().numpy())
+    np.testing.assert_array_equal(ops.conv2d_fwd_winograd5x5s2(x, 64, wp5, b, 128, workspace=ws).cpu().numpy(), whole5.cpu().numpy())
+
+
 @pytest.mark.parametrize("shape,tile", [((16, 60, 80, 64, 256, 3, 1, 1), 4), ((9, 120, 160, 32, 128, 3, 2, 1), 4), ((6, 96, 128, 32, 64, 3, 1, 1), 3)])
 def test_conv_auto_split_tail_vs_f64(hip_lib, shape, tile):
     """splits = 0: whole tiles per CU in one launch + split-K tail (dim_conv2d_tail_plan confirms the two-launch path) vs float64"""
