@@ -42,6 +42,7 @@ struct ConvArgs {
   int accumulate;  // out += v (final pass only)
   unsigned x_bytes, w_bytes;  // extents of x / w for the buffer descriptors (loads past them return 0)
   int xcd_chunk;   // > 0: workgroup id -> tile remap that keeps consecutive tiles on one XCD (see conv_fwd_kernel)
+  FastDiv div_kw;  // 8-channel layer: flat tap index -> (kh, kw)
   long bx, bw, by; // batched launch (gridDim.y > 1): element strides of x / w / y between the problems (Winograd: 16 GEMMs)
   int tile_off;    // first tile of this launch (tail launch of an "auto" workload)
   int slab_row0;   // split-K slabs hold rows [slab_row0, M)
@@ -95,10 +96,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
     int ho = t % a.Ho;
     int n = t / a.Ho;
     a_hi0[i] = ok ? ho * a.stride - a.pad_h : -(1 << 28);  // rows past M: every tap fails the bounds test
-    a_wi0[i] = wo * a.stride - a.pad_w + (CIN8 ? (q >> 1) : 0);
+    a_wi0[i] = wo * a.stride - a.pad_w;
     // BYTE offset of this thread's float4 at tap (0,0), channel 0 (may be negative in the padding; 32 bits, host-checked).
-    // For the 8-channel layer the 4 taps of a chunk are contiguous in memory, so "+ q*4" covers tap and channel half.
-    a_pix[i] = ((n * a.H + (ok ? a_hi0[i] : 0)) * a.W * a.in_cstride + (wo * a.stride - a.pad_w) * a.in_cstride + q * 4) * 4;
+    // 8-channel layer: a chunk is 4 taps x 8 channels, thread q holds channel half q & 1 of tap q >> 1 (tap offset added per chunk).
+    a_pix[i] = ((n * a.H + (ok ? a_hi0[i] : 0)) * a.W * a.in_cstride + (wo * a.stride - a.pad_w) * a.in_cstride + (CIN8 ? (q & 1) * 4 : q * 4)) * 4;
   }
   // Both operands go through buffer descriptors: a padding tap is a load at offset 0xFFFFFFFF (the range check returns
   // zeros: one v_cndmask on a 32-bit offset, no pointer select, no exec juggling, and -- unlike the flat loads a pointer
@@ -114,8 +115,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   // chunk -> (kh, kw, c0) counters
   int kh, kw, c0;
   if (CIN8) {
-    kh = kc_begin >> 1;
-    kw = (kc_begin & 1) * 4;
+    // 8-channel layer: K = (tap, channel) flattened, 4 taps per chunk, taps numbered row-major over KH x KW with NO padding per
+    // kernel row (7x7: 49 taps = 13 chunks instead of the 14 that "two chunks per row" needed).  `kw` holds this thread's flat tap.
+    kw = 4 * kc_begin + (q >> 1);
+    kh = 0;
     c0 = 0;
   } else {
     // K order for Cin % 32 == 0: 32-channel slice OUTER, taps INNER -- consecutive chunks read the same channels at the
@@ -136,22 +139,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   // one is excluded from the range check, and a_pix alone is negative = out of range in the top/left padding.)
 #define DIM_LOAD_A(REG, I)                                                                                         \
   if (I < A_PER_T) {                                                                                                \
-    bool ok = pf_ok && (unsigned)(a_hi0[I] + kh) < (unsigned)a.H && (unsigned)(a_wi0[I] + kw) < (unsigned)a.W &&    \
-              (!CIN8 || kw + (q >> 1) < a.KW);                                                                      \
+    bool ok = pf_ok && (unsigned)(a_hi0[I] + tkh) < (unsigned)a.H && (unsigned)(a_wi0[I] + tkw) < (unsigned)a.W;    \
     REG = buf_load16(rx, ok ? a_pix[I] + tap_off : -1, 0);                                                          \
   }
   // PF_OK = false on the one prefetch past the last chunk: its (kh,kw,c0) counters already point one channel slice beyond
   // the tensor, so the (unused) activation read is dropped like a padding tap
 #define DIM_LOAD_CHUNK(PF_OK)                                      \
   {                                                                \
-    const bool pf_ok = (PF_OK);                                    \
-    const int tap_off = ((kh * a.W + kw) * a.in_cstride + c0) * 4; \
+    /* (tkh, tkw) = the tap this thread loads: wave-uniform for the 32-channel layers, per thread (from its flat tap) for the */ \
+    /* 8-channel one, where a tap past KH*KW lands on a row >= KH only if the bounds test below rejects it explicitly */ \
+    const int tkh = CIN8 ? (int)fastdiv((unsigned)kw, a.div_kw) : kh;                                   \
+    const int tkw = CIN8 ? kw - tkh * a.KW : kw;                                                        \
+    const bool pf_ok = (PF_OK) && (!CIN8 || tkh < a.KH);           \
+    const int tap_off = ((tkh * a.W + tkw) * a.in_cstride + c0) * 4; \
     DIM_LOAD_A(ra0, 0) DIM_LOAD_A(ra1, 1) DIM_LOAD_A(ra2, 2) DIM_LOAD_A(ra3, 3) \
   }
 #define DIM_ADVANCE()                        \
   if (CIN8) {                                \
     kw += 4;                                 \
-    if (kw >= 8) { kw = 0; ++kh; }           \
   } else {                                   \
     if (++kw == a.KW) {                      \
       kw = 0;                                \
@@ -366,8 +371,9 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
   int kc = (int)(t / Cout);
   int kh, kw, c;
   if (cin8) {
-    kh = kc >> 1;
-    kw = (kc & 1) * 4 + (kin >> 3);
+    const int t = kc * 4 + (kin >> 3);  // flat tap, row-major over KH x KW (taps past KH*KW: kh >= KH -> zero weight)
+    kh = t / KW;
+    kw = t - kh * KW;
     c = kin & 7;
   } else {
     int taps = KH * KW;
@@ -593,7 +599,7 @@ using namespace dim;
 extern "C" {
 
 long dim_conv2d_packed_weight_floats(int Cout, int Cin, int KH, int KW) {
-  if (Cin == 8) return (long)KH * 2 * 32 * Cout;  // 8 taps (KW<=8) x 8 ch per row = 2 chunks
+  if (Cin == 8) return (long)((KH * KW + 3) / 4) * 32 * Cout;  // 4 taps x 8 channels per chunk, taps flat over KH x KW
   return (long)KH * KW * Cin * Cout;
 }
 
@@ -602,7 +608,7 @@ int dim_conv2d_pack_weight(const float* w_oihw, float* w_packed, int Cout, int C
   DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
   DIM_REQUIRE(Cin != 8 || KW <= 8, "Cin==8 path needs KW<=8 (got %d)", KW);
   int cin8 = Cin == 8;
-  int nchunks = cin8 ? KH * 2 : KH * KW * (Cin / 32);
+  int nchunks = cin8 ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
   long total = (long)nchunks * 32 * Cout;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed,
                      Cout, Cin, KH, KW, nchunks, cin8, Cout);
@@ -679,7 +685,7 @@ static void conv_tail_plan(int M, int Cout, int nchunks, int tile, int* tail_beg
 int dim_conv2d_tail_plan(int M, int Cout, int Cin, int KH, int KW, int tile, int* tail_begin_tile, int* tail_splits) {
   DIM_REQUIRE(tail_begin_tile && tail_splits, "null pointer");
   if (tile == 0) tile = (Cout % 128 == 0 && Cin != 8 && M >= 128) ? 4 : 3;
-  conv_tail_plan(M, Cout, (Cin == 8) ? KH * 2 : KH * KW * (Cin / 32), tile, tail_begin_tile, tail_splits);
+  conv_tail_plan(M, Cout, (Cin == 8) ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32), tile, tail_begin_tile, tail_splits);
   return DIM_OK;
 }
 
@@ -734,7 +740,8 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
               (long)N * H * W * a.in_cstride);
   a.x_bytes = (unsigned)((long)N * H * W * a.in_cstride * 4);
   a.M = N * a.Ho * a.Wo;
-  a.nchunks = (Cin == 8) ? KH * 2 : KH * KW * (Cin / 32);
+  a.nchunks = (Cin == 8) ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
+  a.div_kw = make_fastdiv((unsigned)KW);
   DIM_REQUIRE((long)a.nchunks * Cout * 32 * 4 < (1L << 31), "packed weights too large for 32-bit byte offsets");
   a.w_bytes = (unsigned)((long)a.nchunks * Cout * 32 * 4);
   const bool auto_split = splits == 0;

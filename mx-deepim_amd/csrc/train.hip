@@ -13,7 +13,7 @@
 namespace dim {
 
 // ---------------------------------------------------------------------------------------------- weight layout converters
-// packed [chunk][Cout][32] (chunk = (32-channel slice, kh, kw) | first layer: (kh, 4-tap group)) -> OIHW.  Inverse of
+// packed [chunk][Cout][32] (chunk = (32-channel slice, kh, kw) | first layer: 4 consecutive flat taps) -> OIHW.  Inverse of
 // pack_conv_weight_kernel (conv.hip); used to bring wgrad's output into the flat MXNet-layout gradient bucket.
 __global__ void unpack_conv_weight_kernel(const float* __restrict__ wp, float* __restrict__ w, int Cout, int CoutPad, int Cin, int KH, int KW,
                                           int cin8, float scale, int accumulate) {
@@ -27,8 +27,9 @@ __global__ void unpack_conv_weight_kernel(const float* __restrict__ wp, float* _
   int co = (int)(t / Cin);
   int kc, kin;
   if (cin8) {
-    kc = kh * 2 + (kw >> 2);
-    kin = (kw & 3) * 8 + ci;
+    const int t = kh * KW + kw;  // flat tap: 4 taps x 8 channels per chunk
+    kc = t >> 2;
+    kin = (t & 3) * 8 + ci;
   } else {
     kc = (ci >> 5) * KH * KW + kh * KW + kw;
     kin = ci & 31;

@@ -57,7 +57,10 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
   for (int c = 0; c < NCH; ++c) {
     const int kc = kc0 + c;
     if (CIN8) {
-      kh[c] = kc >> 1; kw[c] = (kc & 1) * 4; c0[c] = 0;
+      // 8-channel layer: 4 taps x 8 channels per chunk, taps flat over KH x KW; this THREAD stages tap 4 kc + (xq >> 1)
+      // (kh >= KH for the padding taps of the last chunk: rejected by the bounds test)
+      const int t = 4 * kc + ((tid & 7) >> 1);
+      kh[c] = t / a.KW; kw[c] = t - kh[c] * a.KW; c0[c] = 0;
     } else {
       int taps = a.KH * a.KW;
       int cc = kc / taps, tap = kc - cc * taps;
@@ -94,8 +97,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
 #define DIM_WG_LX(REG, C, I)                                                                                      \
   if (C < NCH && I < XP) {                                                                                        \
     int hi = hb##I + kh[C];                                                                                       \
-    int wi = wb##I + kw[C] + (CIN8 ? (xq >> 1) : 0);                                                              \
-    bool ok = okm##I && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && (!CIN8 || kw[C] + (xq >> 1) < a.KW); \
+    int wi = wb##I + kw[C];                                                                                       \
+    bool ok = okm##I && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && (!CIN8 || kh[C] < a.KH);  \
     REG = buf_load16(rsx, ok ? pix##I + tapb[C] : -1, 0);                                                         \
   }
 #define DIM_WG_PIX(I)                                                                                             \
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
   unsigned t##I = fastdiv(mm##I, a.div_wo), n##I = fastdiv(t##I, a.div_ho);                                       \
   int wo##I = mm##I - t##I * a.Wo, ho##I = t##I - n##I * a.Ho;                                                    \
   int hb##I = ho##I * a.stride - a.pad, wb##I = wo##I * a.stride - a.pad;                                         \
-  int pix##I = (((int)n##I * a.H + hb##I) * a.W + wb##I) * (a.in_cstride * 4) + xq * 16;
+  int pix##I = (((int)n##I * a.H + hb##I) * a.W + wb##I) * (a.in_cstride * 4) + (CIN8 ? (xq & 1) : xq) * 16;
   // global -> registers for step `st` (pf = false: everything reads the zero block; used for the prefetch past the end)
 #define DIM_WG_LOAD(st, pf_ok)                                      \
   {                                                                 \
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
   const bool add = gridDim.z == 1 && a.accumulate;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
+    if (kc0 + c >= a.nchunks) break;  // odd chunk count: the last workgroup's second chunk does not exist (its loads read zeros)
     float* out = (gridDim.z == 1 ? a.dw : a.dw + (long)split * a.nchunks * a.Cout * 32) +
                  ((long)(kc0 + c) * a.Cout + co0 + wave * 32 + 4 * fh) * 32 + fi;
 #pragma unroll
@@ -255,7 +259,7 @@ extern "C" {
 
 long dim_conv2d_wgrad_workspace_floats(int Cout, int Cin, int KH, int KW, int splits) {
   if (splits <= 1) return 0;
-  long n = (Cin == 8) ? (long)KH * 2 * 32 * Cout : (long)KH * KW * Cin * Cout;
+  long n = (Cin == 8) ? (long)((KH * KW + 3) / 4) * 32 * Cout : (long)KH * KW * Cin * Cout;
   return n * splits;
 }
 
@@ -279,7 +283,7 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   a.dz_bytes = (unsigned)((long)N * Ho * Wo * dz_cstride * 4);
   a.div_wo = make_fastdiv((unsigned)Wo);
   a.div_ho = make_fastdiv((unsigned)Ho);
-  a.nchunks = (Cin == 8) ? KH * 2 : KH * KW * (Cin / 32);
+  a.nchunks = (Cin == 8) ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
   a.nsteps = ceil_div(a.M, 32);
   if (splits < 1) splits = 1;
   if (splits > a.nsteps) splits = a.nsteps;
@@ -290,8 +294,8 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   a.accumulate = accumulate;
   hipStream_t st = as_stream(stream);
   const bool nw4 = Cout % 128 == 0;
-  const bool two = a.nchunks % 2 == 0;  // two K chunks (64 packed columns) per workgroup share one dZ tile
-  dim3 grid(a.nchunks / (two ? 2 : 1), Cout / (nw4 ? 128 : 64), splits);
+  const bool two = a.nchunks >= 2;  // two K chunks (64 packed columns) per workgroup share one dZ tile
+  dim3 grid(two ? (a.nchunks + 1) / 2 : a.nchunks, Cout / (nw4 ? 128 : 64), splits);
 #define DIM_WG_LAUNCH(NW, C8, NCH) hipLaunchKernelGGL((conv_wgrad_kernel<NW, C8, NCH>), grid, dim3(64 * NW), 0, st, a)
   if (Cin == 8) {
     if (nw4) { if (two) DIM_WG_LAUNCH(4, true, 2); else DIM_WG_LAUNCH(4, true, 1); }

@@ -104,7 +104,7 @@ class MutableModule(object):
         h, w, c = 480, 640, 8
         for name, cout, k, s, p in ENCODER:
             ho, wo = ops.conv_out_hw(h, w, k, k, s, p)
-            nchunks = k * 2 if c == 8 else k * k * (c // 32)
+            nchunks = -(-k * k // 4) if c == 8 else k * k * (c // 32)
             blocks = nchunks * (cout // 128 if cout % 128 == 0 else cout // 64)
             nsteps = -(-B * ho * wo // 32)
             sp = max(1, min(-(-4096 // blocks), max(1, nsteps // 4)))

@@ -203,7 +203,7 @@ class FlowNetHip(object):
         for name, cout, k, s, p in ENCODER:
             ho, wo = ops.conv_out_hw(h, w, k, k, s, p)
             self.acts[name] = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=d)
-            nchunks = k * 2 if c == 8 else k * k * (c // 32)
+            nchunks = -(-k * k // 4) if c == 8 else k * k * (c // 32)
             tile, splits = self.conv_plan.get(name, ops.conv_auto_plan(B * ho * wo, cout, nchunks, cin=c))
             self.conv_plan[name] = (tile, splits)
             self.layer_info[name] = dict(M=B * ho * wo, K=c * k * k, N=cout, flops=2 * B * ho * wo * cout * c * k * k, tile=tile,
