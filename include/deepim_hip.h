@@ -177,6 +177,13 @@ int dim_winograd5x5s2_pack_weight(const float* w_oihw, float* w_packed, int Cout
 int dim_conv2d_fwd_winograd5x5s2(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
                                  int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, void** events4,
                                  void* stream);
+/* Input gradient of the same 5x5 / stride-2 layers (training): dx (N,H,W,dx_cstride) = conv_transpose(dy (N,ceil(H/2),ceil(W/2),
+ * dy_cstride), w) as ONE F(4x4,3x3) transform of dy, 36 GEMMs with K = Cout and N = 4 Cin (the four phase images of dx), and a
+ * phase-scattering output transform; dx is overwritten.  Weights: dim_winograd5x5s2_dgrad_pack_weight from the same (Cout,Cin,5,5)
+ * array (dim_winograd5x5s2_packed_weight_floats floats); workspace: dim_winograd5x5s2_workspace_floats floats. */
+int dim_winograd5x5s2_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream);
+int dim_conv2d_dgrad_winograd5x5s2(const float* dy, const float* w_packed, float* dx, float* workspace, int N, int H, int W, int Cin,
+                                   int dx_cstride, int Cout, int dy_cstride, int tile, void* stream);
 /* dim_conv2d_pack_weight with the output channels zero-padded to CoutPad (multiple of 64) */
 int dim_conv2d_pack_weight_padded(const float* w_oihw, float* w_packed, int Cout, int CoutPad, int Cin, int KH, int KW, void* stream);
 /* Decoder (deepIM_flownet.py:213-299): y[..., out_coff:out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x, k=4, s=2, p=0) + bias,

@@ -1250,15 +1250,18 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     O[3 * S] = d1 + 8.f * M[3] - 0.125f * M[4] + M[5];              \
   }
 
-// Y = A^T M A + bias, LeakyReLU; thread = (tile t, VEC output channels); writes the 4x4 outputs that fall inside H x W
-template <int VEC>
+// Y = A^T M A + bias, LeakyReLU; thread = (tile t, VEC output channels); writes the 4x4 outputs that fall inside H x W.
+// S = 2 (input gradient of a 5x5 / stride-2 layer): M carries 4 C channels, phase-major; the 4x4 block of phase (py,px) is one
+// of the four stride-2 phase images of the H x W output: pixel (2 (4 ty + a) + py, 2 (4 tx + b) + px), channel c.
+template <int VEC, int S>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y,
                                                            int N, int H, int W, int C, int out_cstride, int out_coff, int th, int tw,
                                                            float slope, FastDiv div_cq, FastDiv div_tw, FastDiv div_th) {
 #pragma clang fp contract(fast)
   typedef typename WinoVec<VEC>::type vf;
   const unsigned idx = blockIdx.x * 256u + threadIdx.x;
-  const unsigned CQ = C / VEC;
+  const unsigned CT = C * S * S;  // channels of M
+  const unsigned CQ = CT / VEC;
   const unsigned T = (unsigned)N * th * tw;
   const unsigned t = fastdiv(idx, div_cq);
   if (t >= T) return;
@@ -1267,8 +1270,12 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
   const unsigned tx = t - r * tw;
   const unsigned n = fastdiv(r, div_th);
   const unsigned ty = r - n * th;
-  const long plane = C;  // M [t][k][c]
-  const float* in = M + (long)t * 36 * C + cq * VEC;
+  const long plane = CT;  // M [t][k][c]
+  const unsigned cc = cq * VEC;
+  const unsigned ph = S == 1 ? 0u : (unsigned)(cc >= (unsigned)C) + (unsigned)(cc >= 2u * C) + (unsigned)(cc >= 3u * C);
+  const int py = ph >> 1, px = ph & 1;
+  const unsigned co = cc - ph * C;  // output channel
+  const float* in = M + (long)t * 36 * CT + cc;
   vf rr[24];  // A^T m: rr[4 rows][6 columns]
 #pragma unroll
   for (int b = 0; b < 6; ++b) {
@@ -1279,21 +1286,21 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     DIM_WINO4_AT(o, m, 6)
   }
   vf bv = (vf)(0.f);
-  if (bias) bv = *reinterpret_cast<const vf*>(bias + cq * VEC);
+  if (bias) bv = *reinterpret_cast<const vf*>(bias + co);
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     vf o[4];
     const vf* m = rr + 6 * a;
     DIM_WINO4_AT(o, m, 1)
-    const int oy = 4 * (int)ty + a;
+    const int oy = S * (4 * (int)ty + a) + py;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int ox = 4 * (int)tx + b;
+      const int ox = S * (4 * (int)tx + b) + px;
       if (oy < H && ox < W) {
         vf v = o[b] + bv;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
-        *reinterpret_cast<vf*>(y + (((long)n * H + oy) * W + ox) * out_cstride + out_coff + cq * VEC) = v;
+        *reinterpret_cast<vf*>(y + (((long)n * H + oy) * W + ox) * out_cstride + out_coff + co) = v;
       }
     }
   }
@@ -1348,6 +1355,27 @@ __global__ void wino4_pack_weight_5x5s2_kernel(const float* __restrict__ w, floa
       g[u * 3 + v] = (i < 5 && j < 5) ? gp[i * 5 + j] : 0.f;
     }
   wino4_transform_weight(g, wp + ((long)(kk >> 5) * Cout + co) * 32 + (kk & 31), 4L * Cin * Cout);
+}
+
+// Input gradient of the 5x5 / stride-2 layer: dX^(py,px)[r][q] = sum_{u,v} g_ph[2-u][2-v] dY[r+u-1][q+v-1]  (the forward's sub-kernels,
+// flipped), contracted over the OUTPUT channels: one F(4x4,3x3) transform of dY, 36 GEMMs with K = Cout and N = 4 Cin (phase-major
+// n = (2 py + px) Cin + ci), phase-scattering output transform.  Packed [k][co/32][4 Cin][co%32].
+__global__ void wino4_pack_weight_5x5s2_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Cout * Cin * 4) return;
+  const int co = (int)(idx % Cout), nn = (int)(idx / Cout);
+  const int ph = nn / Cin, ci = nn - ph * Cin;
+  const int py = ph >> 1, px = ph & 1;
+  const float* gp = w + ((long)co * Cin + ci) * 25;
+  float g[9];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int i = 2 * (2 - u) + py, j = 2 * (2 - v) + px;
+      g[u * 3 + v] = (i < 5 && j < 5) ? gp[i * 5 + j] : 0.f;
+    }
+  wino4_transform_weight(g, wp + ((long)(co >> 5) * (4 * Cin) + nn) * 32 + (co & 31), 4L * Cin * Cout);
 }
 
 }  // namespace dim
@@ -1421,7 +1449,7 @@ static int winograd_slice(const float* x, const float* w_packed, const float* bi
     hipLaunchKernelGGL(wino_output_kernel, dim3(ceil_div(T * (Cout / 4), 256)), dim3(256), 0, st, M, bias, y, N, Ho, Wo, Cout, out_cstride,
                        out_coff, th, tw, slope, make_fastdiv((unsigned)(Cout / 4)), dtw, dth);
   else
-    hipLaunchKernelGGL(wino4_output_kernel<kWino4Vec>, dim3(ceil_div(T * (Cout / kWino4Vec), 256)), dim3(256), 0, st, M, bias, y, N, Ho, Wo,
+    hipLaunchKernelGGL((wino4_output_kernel<kWino4Vec, 1>), dim3(ceil_div(T * (Cout / kWino4Vec), 256)), dim3(256), 0, st, M, bias, y, N, Ho, Wo,
                        Cout, out_cstride, out_coff, th, tw, slope, make_fastdiv((unsigned)(Cout / kWino4Vec)), dtw, dth);
   rc = check_launch("winograd_output");
   DIM_WINO_EVENT(3)
@@ -1482,6 +1510,51 @@ int dim_winograd5x5s2_pack_weight(const float* w_oihw, float* w_packed, int Cout
   hipLaunchKernelGGL(wino4_pack_weight_5x5s2_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout,
                      Cin);
   return check_launch("winograd5x5s2_pack_weight");
+}
+
+int dim_winograd5x5s2_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream) {
+  DIM_REQUIRE(w_oihw && w_packed, "null weight pointer");
+  DIM_REQUIRE(Cout % 32 == 0 && (4 * Cin) % 64 == 0, "Cout %% 32 == 0 and Cin %% 16 == 0 required");
+  long total = 4L * Cout * Cin;
+  hipLaunchKernelGGL(wino4_pack_weight_5x5s2_dgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed,
+                     Cout, Cin);
+  return check_launch("winograd5x5s2_dgrad_pack_weight");
+}
+
+int dim_conv2d_dgrad_winograd5x5s2(const float* dy, const float* w_packed, float* dx, float* workspace, int N, int H, int W, int Cin,
+                                   int dx_cstride, int Cout, int dy_cstride, int tile, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(dy && w_packed && dx && workspace, "null pointer");
+  DIM_REQUIRE(Cout % 32 == 0 && (4 * Cin) % 64 == 0 && Cin % 2 == 0, "Cout %% 32 == 0 and Cin %% 16 == 0 required");
+  if (dx_cstride == 0) dx_cstride = Cin;
+  if (dy_cstride == 0) dy_cstride = Cout;
+  DIM_REQUIRE(dx_cstride >= Cin && dx_cstride % 2 == 0 && dy_cstride >= Cout && dy_cstride % 2 == 0, "channel strides must cover the channels");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int th = (Ho + 3) / 4, tw = (Wo + 3) / 4;
+  const int CT = 4 * Cin;
+  const long ns = wino_slice_images((long)th * tw, 36, Cout, CT);
+  DIM_REQUIRE(ns > 0, "one image alone exceeds the 32-bit offsets of the plane GEMMs");
+  hipStream_t st = as_stream(stream);
+  const FastDiv dtw = make_fastdiv((unsigned)tw), dth = make_fastdiv((unsigned)th);
+  for (int n0 = 0; n0 < N; n0 += (int)ns) {
+    const int n = N - n0 < ns ? N - n0 : (int)ns;
+    const long T = (long)n * th * tw;
+    float* V = workspace;
+    float* M = workspace + 36 * T * Cout;
+    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 1>), dim3(ceil_div(T * (Cout / kWino4Vec), 256)), dim3(256), 0, st,
+                       dy + (long)n0 * Ho * Wo * dy_cstride, V, n, Ho, Wo, Cout, dy_cstride, th, tw, make_fastdiv((unsigned)(Cout / kWino4Vec)),
+                       dtw, dth);
+    int rc = check_launch("winograd_dgrad_input");
+    if (rc != DIM_OK) return rc;
+    rc = launch_wino_gemm(V, w_packed, M, (int)T, Cout, CT, 36, tile == 0 ? ((CT % 128 == 0 && T >= 1024) ? 4 : 3) : tile, st);
+    if (rc != DIM_OK) return rc;
+    hipLaunchKernelGGL((wino4_output_kernel<kWino4Vec, 2>), dim3(ceil_div(T * (CT / kWino4Vec), 256)), dim3(256), 0, st, M, nullptr,
+                       dx + (long)n0 * H * W * dx_cstride, n, H, W, Cin, dx_cstride, 0, th, tw, 1.0f, make_fastdiv((unsigned)(CT / kWino4Vec)),
+                       dtw, dth);
+    rc = check_launch("winograd_dgrad_output");
+    if (rc != DIM_OK) return rc;
+  }
+  return DIM_OK;
 }
 
 int dim_conv2d_fwd_winograd5x5s2(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,

@@ -122,12 +122,15 @@ class MutableModule(object):
         # dgrad-layout weights (refreshed by repack())
         self.dgrad_packed = {}
         self.wino_dgrad = {}
+        self.wino5_dgrad = {}
         self.wino_ws = None
-        if net.wino:
+        if net.wino or net.wino5:
             need, h, w, c = 4, 480, 640, 8
             for name, cout, k, s, p in ENCODER:
                 if name in net.wino:
                     need = max(need, ops.lib().dim_winograd_workspace_floats(B, h, w, cout, c, net.wino_m[name]))
+                if name in net.wino5:
+                    need = max(need, ops.lib().dim_winograd5x5s2_workspace_floats(B, h, w, c, cout))
                 h, w = ops.conv_out_hw(h, w, k, k, s, p)
                 c = cout
             self.wino_ws = torch.empty(need, dtype=torch.float32, device=d)
@@ -141,12 +144,14 @@ class MutableModule(object):
             if forward:
                 if name in net.wino:   # 3x3 / stride-1 layers run their forward through Winograd: re-transform the weights
                     net.wino[name] = ops.winograd_pack_weight(w[name + "_weight"], m=net.wino_m[name])
-                elif name in net.wino5:  # 5x5 / stride-2 layers: phase-image Winograd forward (the backward stays direct)
+                elif name in net.wino5:  # 5x5 / stride-2 layers: phase-image Winograd forward (backward: wino5_dgrad below)
                     net.wino5[name] = ops.winograd5x5s2_pack_weight(w[name + "_weight"])
                 else:
                     net.packed[name] = ops.conv2d_pack_weight(w[name + "_weight"])
             if name in net.wino:
                 self.wino_dgrad[name] = ops.winograd_pack_weight(w[name + "_weight"].flip(2, 3).transpose(0, 1).contiguous(), m=net.wino_m[name])
+            elif name in net.wino5:  # 5x5 / stride-2 layers: input gradient through Winograd too (four phase images of dX)
+                self.wino5_dgrad[name] = ops.winograd5x5s2_dgrad_pack_weight(w[name + "_weight"])
             elif name != "flow_conv1":
                 self.dgrad_packed[name] = ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p)
         if forward:
@@ -268,6 +273,8 @@ class MutableModule(object):
                     ops.conv2d_fwd_winograd(dy, cout, self.wino_dgrad[name], None, cin[name], slope=1.0,
                                             tile=4 if (cin[name] % 128 == 0 and wtiles >= 1024) else 3,
                                             out=self.dacts[prev[name]], workspace=self.wino_ws, m=wm)
+                elif name in self.wino5_dgrad:
+                    ops.conv2d_dgrad_winograd5x5s2(dy, cout, self.wino5_dgrad[name], self.dacts[prev[name]], cin[name], workspace=self.wino_ws)
                 else:
                     ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False)
         return g

@@ -223,6 +223,27 @@ def winograd5x5s2_pack_weight(w_oihw):
     return out
 
 
+def winograd5x5s2_dgrad_pack_weight(w_oihw):
+    """(Cout,Cin,5,5) -> the 36 transformed weight sets (K = Cout, N = 4 Cin) of dim_conv2d_dgrad_winograd5x5s2"""
+    Cout, Cin, KH, KW = w_oihw.shape
+    assert KH == 5 and KW == 5
+    out = _new((lib().dim_winograd5x5s2_packed_weight_floats(Cout, Cin),), w_oihw)
+    check(lib().dim_winograd5x5s2_dgrad_pack_weight(dptr(w_oihw, f32), dptr(out, f32), Cout, Cin, current_stream()))
+    return out
+
+
+def conv2d_dgrad_winograd5x5s2(dy_nhwc, Cout, w_packed, dx_nhwc, Cin, tile=0, workspace=None):
+    """dx (N,H,W,>=Cin) = input gradient of the 5x5 / stride 2 / pad 2 convolution, from dy (N,ceil(H/2),ceil(W/2),>=Cout); overwrites dx"""
+    N, H, W, dx_cs = dx_nhwc.shape
+    assert dy_nhwc.shape[:3] == (N, (H + 1) // 2, (W + 1) // 2)
+    need = lib().dim_winograd5x5s2_workspace_floats(N, H, W, Cin, Cout)
+    if workspace is None or workspace.numel() < need:
+        workspace = _new((need,), dx_nhwc)
+    check(lib().dim_conv2d_dgrad_winograd5x5s2(dptr(dy_nhwc, f32), dptr(w_packed, f32), dptr(dx_nhwc, f32), dptr(workspace, f32), N, H, W, Cin,
+                                               dx_cs, Cout, dy_nhwc.shape[-1], tile, current_stream()))
+    return dx_nhwc
+
+
 def _wino_events(events):
     import ctypes
 

@@ -460,6 +460,37 @@ def test_conv5x5s2_winograd_vs_f64(hip_lib, shape):
     assert np.all(o[..., :32] == 7.0) and np.all(o[..., 32 + Cout:] == 7.0)
 
 
+@pytest.mark.parametrize("shape", [(2, 30, 40, 64, 128), (1, 15, 21, 32, 64), (2, 60, 80, 128, 256), (1, 7, 10, 16, 32), (16, 60, 78, 32, 64)])
+def test_conv5x5s2_winograd_dgrad_vs_f64(hip_lib, shape):
+    """input gradient of the 5x5 / stride-2 / pad-2 layer through Winograd (one transform of dY, K = Cout, N = 4 Cin, phase scatter)
+    vs torch-CPU float64 autograd and vs the direct dgrad path; even / odd H and W; padded channel strides on both sides"""
+    import torch.nn.functional as F
+    from lib.hip import ops
+
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 13)
+    w = torch.randn((Cout, Cin, 5, 5), generator=g) * (1.0 / np.sqrt(25 * Cout))
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    dy = torch.randn((N, Cout, Ho, Wo), generator=g)
+    x = torch.zeros((N, Cin, H, W), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w.double(), None, stride=2, padding=2).backward(dy.double())
+    ref = x.grad.permute(0, 2, 3, 1).numpy()
+    dyd = torch.zeros((N, Ho, Wo, Cout + 32), device="cuda:0")
+    dyd[..., :Cout] = dy.permute(0, 2, 3, 1).to("cuda:0")
+    wp = ops.winograd5x5s2_dgrad_pack_weight(w.to("cuda:0"))
+    dx = torch.full((N, H, W, Cin + 8), 7.0, device="cuda:0")
+    ops.conv2d_dgrad_winograd5x5s2(dyd, Cout, wp, dx, Cin)
+    got = dx.cpu().numpy()
+    tol = 1e-4 * np.abs(ref).max() + 2e-5
+    assert np.abs(got[..., :Cin] - ref).max() <= tol
+    assert np.all(got[..., Cin:] == 7.0)
+    if Cin % 64:
+        return  # the direct dgrad path wants dx channels in multiples of 64
+    dx2 = torch.empty((N, H, W, Cin), device="cuda:0")
+    ops.conv2d_dgrad(dyd[..., :Cout].contiguous(), Cout, ops.conv2d_dgrad_pack_weight(w.to("cuda:0"), 2, 2), dx2, Cin, 5, 5, 2, 2, accumulate=False)
+    assert np.abs(got[..., :Cin] - dx2.cpu().numpy()).max() <= tol
+
+
 def test_winograd_batch_slices(hip_lib, monkeypatch):
     """batches whose transformed tiles would exceed the 32-bit offsets of the plane GEMMs run as slices of whole images through
     the same workspace; DIM_WINO_MAX_SLICE forces that path at a size the test can check (5 images as 2 + 2 + 1)"""
