@@ -28,11 +28,15 @@ def timed(fn, n=3):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-print("B =", B)
-print("forward        %.2f ms" % timed(lambda: mod.forward(batch)))
-print("backward       %.2f ms" % timed(lambda: mod.backward(batch)))
-print("update+repack  %.2f ms" % timed(lambda: mod.update(0.0)))
+import json
+res = {"B": B, "forward_ms": timed(lambda: mod.forward(batch)), "backward_ms": timed(lambda: mod.backward(batch)),
+       "update_repack_ms": timed(lambda: mod.update(0.0))}
 preds = mod.forward(batch)
-print("batch updater  %.2f ms" % timed(lambda: upd.forward(batch, preds)))
+res["batch_updater_ms"] = timed(lambda: upd.forward(batch, preds))
 t = timed(lambda: (mod.forward_backward(batch), mod.update(1e-4)))
-print("train iteration %.2f ms -> %.1f pair-iterations/s" % (t, B / t * 1e3))
+res["train_iteration_ms"] = t
+res["pair_iterations_per_s"] = B / t * 1e3
+res["config"] = "LINEMOD 'ape' training graph (encoder + decoder + flow / mask / point-matching losses), SGD momentum, fp32, 1x MI355X, synthetic pairs"
+for k, v in res.items():
+    print(k, ("%.2f" % v) if isinstance(v, float) else v)
+print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res.items()}))
