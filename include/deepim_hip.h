@@ -184,6 +184,14 @@ int dim_conv2d_fwd_winograd5x5s2(const float* x, const float* w_packed, const fl
 int dim_winograd5x5s2_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream);
 int dim_conv2d_dgrad_winograd5x5s2(const float* dy, const float* w_packed, float* dx, float* workspace, int N, int H, int W, int Cin,
                                    int dx_cstride, int Cout, int dy_cstride, int tile, void* stream);
+/* Weight gradient of the same layers through Winograd (training): dw (Cout,Cin,k,k) MXNet layout (=, or += when accumulate) =
+ * scale * sum over pixels of x (*) dy.  S = 1: 3x3 / stride 1 / pad 1 (k = 3); S = 2: 5x5 / stride 2 / pad 2 (k = 5, four phase
+ * images of x).  Per 4x4 tile of dy this is the correlation F(3x3,4x4): V = B^T x B (the forward's input transform), D = G4 dy G4^T,
+ * 36 plane products contracted over tiles and batch on the wgrad MFMA kernel (`splits` pixel ranges, deterministic slab reduce),
+ * dW = A3^T dM A3: 4x (S = 1) / 2.78x (S = 2) fewer multiply-adds than dim_conv2d_wgrad.  x (N,H,W,in_cstride), dy (N,Ho,Wo,dy_cstride). */
+long dim_conv2d_wgrad_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int S, int splits);
+int dim_conv2d_wgrad_winograd(const float* x, const float* dy, float* dw_oihw, float* workspace, int N, int H, int W, int Cin, int in_cstride,
+                              int Cout, int dy_cstride, int S, int splits, float scale, int accumulate, void* stream);
 /* dim_conv2d_pack_weight with the output channels zero-padded to CoutPad (multiple of 64) */
 int dim_conv2d_pack_weight_padded(const float* w_oihw, float* w_packed, int Cout, int CoutPad, int Cin, int KH, int KW, void* stream);
 /* Decoder (deepIM_flownet.py:213-299): y[..., out_coff:out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x, k=4, s=2, p=0) + bias,

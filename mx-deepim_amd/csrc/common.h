@@ -25,6 +25,9 @@ inline int check_launch(const char* what) {
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// wgrad.hip: the plane products of a Winograd weight gradient, dM_p[k][co] = sum_t V[t][p][k] D[t][p][co], packed [p*K/32 + k/32][Cout][k%32]
+int launch_wgrad_planes(const float* V, const float* D, float* dM_packed, float* slabs, int T, int K, int Cout, int planes, int splits,
+                        hipStream_t st);
 // wino_gemm.hip: the P plane GEMMs of a Winograd layer as one persistent stream-K launch.  V [T][P][K], U [P][K/32][Cout][32],
 // M [T][P][Cout]; tile 4 = 128x128 workgroup tiles, otherwise 64x64.
 int launch_wino_gemm(const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile, hipStream_t st);

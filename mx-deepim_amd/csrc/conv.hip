@@ -1378,6 +1378,115 @@ __global__ void wino4_pack_weight_5x5s2_dgrad_kernel(const float* __restrict__ w
   wino4_transform_weight(g, wp + ((long)(co >> 5) * (4 * Cin) + nn) * 32 + (co & 31), 4L * Cin * Cout);
 }
 
+// ------------------------------------------------------------------------------------------------ Winograd weight gradient
+// dW[u][v] = sum_{n,y,x} X[y+u-1][x+v-1] dY[y][x] per 4x4 tile of dY is the correlation F(3x3, 4x4): input = the 6x6 tile of X (the
+// forward's V = B^T d B, same tiles, same kernel), "filter" = the 4x4 tile of dY (D = G4 g G4^T), three outputs per axis:
+//   dW = A3^T [ sum_tiles V (.) D ] A3      -- the sum over tiles and batch is a GEMM per plane (contraction over T), 36 instead of 144
+// multiply-adds per tile and (ci, co).  Same six points {0, 1, -1, 2, -1/2, inf}:
+//   G4  = [1 0 0 0; -1/3 -1/3 -1/3 -1/3; 1/3 -1/3 1/3 -1/3; 1/15 2/15 4/15 8/15; -16/15 8/15 -4/15 2/15; 0 0 0 1]
+//   A3^T = [1 1 1 1 1 0; 0 1 -1 2 -1/2 0; 0 1 1 4 1/4 1]
+#define DIM_WINO4_G4(O, D, S)                                                                        \
+  {                                                                                                  \
+    const vf ev_ = D[0] + D[2], od_ = D[1] + D[3];                                                   \
+    O[0 * S] = D[0];                                                                                 \
+    O[1 * S] = (-1.f / 3) * (ev_ + od_);                                                             \
+    O[2 * S] = (1.f / 3) * (ev_ - od_);                                                              \
+    O[3 * S] = (1.f / 15) * D[0] + (2.f / 15) * D[1] + (4.f / 15) * D[2] + (8.f / 15) * D[3];        \
+    O[4 * S] = (-16.f / 15) * D[0] + (8.f / 15) * D[1] - (4.f / 15) * D[2] + (2.f / 15) * D[3];      \
+    O[5 * S] = D[3];                                                                                 \
+  }
+
+// D[t][k][c] = (G4 g G4^T)[k] for the 4x4 tile g of dY at (4 ty, 4 tx); thread = (tile, VEC channels)
+template <int VEC>
+__global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ D, int N, int H, int W, int C,
+                                                       int cstride, int th, int tw, FastDiv div_cq, FastDiv div_tw, FastDiv div_th) {
+#pragma clang fp contract(fast)
+  typedef typename WinoVec<VEC>::type vf;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  const unsigned CQ = C / VEC;
+  const unsigned T = (unsigned)N * th * tw;
+  const unsigned t = fastdiv(idx, div_cq);
+  if (t >= T) return;
+  const unsigned cq = idx - t * CQ;
+  const unsigned r = fastdiv(t, div_tw);
+  const unsigned tx = t - r * tw;
+  const unsigned n = fastdiv(r, div_th);
+  const unsigned ty = r - n * th;
+  const float* base = dy + (long)n * H * W * cstride + cq * VEC;
+  vf tmp[24];  // G4 g: [6][4]
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int xx = 4 * (int)tx + b;
+    const bool okx = xx < W;
+    const int xc = okx ? xx : 0;
+    vf g[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int yy = 4 * (int)ty + a;
+      const bool ok = okx && yy < H;
+      vf v = *reinterpret_cast<const vf*>(base + ((long)(yy < H ? yy : 0) * W + xc) * cstride);
+      g[a] = ok ? v : (vf)(0.f);
+    }
+    vf* o = tmp + b;
+    DIM_WINO4_G4(o, g, 4)
+  }
+  float* out = D + (long)t * 36 * C + cq * VEC;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    vf o[6];
+    const vf* g = tmp + 4 * a;
+    DIM_WINO4_G4(o, g, 1)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) *reinterpret_cast<vf*>(out + (a * 6 + b) * (long)C) = o[b];
+  }
+}
+
+// dW = A3^T dM A3 per (co, kk): dM packed [p * K/32 + kk/32][Cout][kk%32] -> MXNet layout.  S = 1: 3x3 / stride-1 layer, K = Cin, dW is
+// the (Cout,Cin,3,3) gradient.  S = 2: 5x5 / stride-2 layer, kk = (2 py + px) Cin + ci, and the 3x3 result of phase (py,px) holds the
+// taps w[2u + py][2v + px] of the (Cout,Cin,5,5) gradient (u or v = 2 does not exist for an odd phase: dropped).
+template <int S>
+__global__ __launch_bounds__(256) void wino4_wgrad_output_kernel(const float* __restrict__ dM, float* __restrict__ dw, int Cout, int Cin,
+                                                                 float scale, int accumulate) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int K = Cin * S * S;
+  if (idx >= (long)Cout * K) return;
+  const int kk = (int)(idx % K), co = (int)(idx / K);  // kk fastest: the 32 k of a packed row are contiguous
+  const long per_k = (long)K * Cout;
+  const float* in = dM + ((long)(kk >> 5) * Cout + co) * 32 + (kk & 31);
+  const float AT[3][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -0.5f, 0.f}, {0.f, 1.f, 1.f, 4.f, 0.25f, 1.f}};
+  float r[3][6];  // A3^T dM
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    float m[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) m[a] = in[(a * 6 + b) * per_k];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) acc += AT[u][a] * m[a];
+      r[u][b] = acc;
+    }
+  }
+  const int ph = S == 1 ? 0 : kk / Cin, ci = kk - ph * Cin;
+  const int py = ph >> 1, px = ph & 1;
+  constexpr int KS = S == 1 ? 3 : 5;
+  float* o = dw + ((long)co * Cin + ci) * (KS * KS);
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      float acc = 0.f;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) acc += r[u][b] * AT[v][b];
+      const int i = S == 1 ? u : 2 * u + py, j = S == 1 ? v : 2 * v + px;
+      if (i < KS && j < KS) {
+        const float val = acc * scale;
+        o[i * KS + j] = accumulate ? o[i * KS + j] + val : val;
+      }
+    }
+}
+
 }  // namespace dim
 
 extern "C" {
@@ -1555,6 +1664,57 @@ int dim_conv2d_dgrad_winograd5x5s2(const float* dy, const float* w_packed, float
     if (rc != DIM_OK) return rc;
   }
   return DIM_OK;
+}
+
+// Weight gradient through Winograd.  S = 1: 3x3 / stride 1 / pad 1; S = 2: 5x5 / stride 2 / pad 2 (phase images of x).
+long dim_conv2d_wgrad_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int S, int splits) {
+  const int Ho = S == 1 ? H : (H + 1) / 2, Wo = S == 1 ? W : (W + 1) / 2;
+  const long T = (long)N * ((Ho + 3) / 4) * ((Wo + 3) / 4);
+  const long K = (long)Cin * S * S;
+  if (splits < 1) splits = 1;
+  return 36 * T * (K + Cout) + 36 * K * Cout * (long)(splits + 1);
+}
+
+int dim_conv2d_wgrad_winograd(const float* x, const float* dy, float* dw_oihw, float* workspace, int N, int H, int W, int Cin, int in_cstride,
+                              int Cout, int dy_cstride, int S, int splits, float scale, int accumulate, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(x && dy && dw_oihw && workspace, "null pointer");
+  DIM_REQUIRE(S == 1 || S == 2, "S must be 1 (3x3 / stride 1) or 2 (5x5 / stride 2)");
+  DIM_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0 && (Cin * S * S) % 64 == 0, "Cin %% 32 == 0 (%% 64 for S = 1) and Cout %% 64 == 0 required");
+  if (in_cstride == 0) in_cstride = Cin;
+  if (dy_cstride == 0) dy_cstride = Cout;
+  DIM_REQUIRE(in_cstride >= Cin && in_cstride % 2 == 0 && dy_cstride >= Cout && dy_cstride % 2 == 0, "channel strides must cover the channels");
+  const int Ho = S == 1 ? H : (H + 1) / 2, Wo = S == 1 ? W : (W + 1) / 2;
+  const int th = (Ho + 3) / 4, tw = (Wo + 3) / 4;
+  const long T = (long)N * th * tw;
+  const int K = Cin * S * S;
+  DIM_REQUIRE(T * 36 * (K > Cout ? K : Cout) < (1L << 29), "winograd wgrad: batch too large for 32-bit byte offsets");
+  if (splits < 1) splits = 1;
+  float* V = workspace;
+  float* D = V + 36 * T * K;
+  float* dM = D + 36 * T * Cout;
+  float* slabs = dM + 36L * K * Cout;
+  hipStream_t st = as_stream(stream);
+  const FastDiv dtw = make_fastdiv((unsigned)tw), dth = make_fastdiv((unsigned)th);
+  if (S == 1)
+    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 1>), dim3(ceil_div(T * (K / kWino4Vec), 256)), dim3(256), 0, st, x, V, N, H, W, Cin,
+                       in_cstride, th, tw, make_fastdiv((unsigned)(K / kWino4Vec)), dtw, dth);
+  else
+    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 2>), dim3(ceil_div(T * (K / kWino4Vec), 256)), dim3(256), 0, st, x, V, N, H, W, Cin,
+                       in_cstride, th, tw, make_fastdiv((unsigned)(K / kWino4Vec)), dtw, dth);
+  hipLaunchKernelGGL(wino4_dy_kernel<kWino4Vec>, dim3(ceil_div(T * (Cout / kWino4Vec), 256)), dim3(256), 0, st, dy, D, N, Ho, Wo, Cout,
+                     dy_cstride, th, tw, make_fastdiv((unsigned)(Cout / kWino4Vec)), dtw, dth);
+  int rc = check_launch("winograd_wgrad_transforms");
+  if (rc != DIM_OK) return rc;
+  rc = launch_wgrad_planes(V, D, dM, slabs, (int)T, K, Cout, 36, splits, st);
+  if (rc != DIM_OK) return rc;
+  if (S == 1)
+    hipLaunchKernelGGL(wino4_wgrad_output_kernel<1>, dim3(ceil_div((long)Cout * K, 256)), dim3(256), 0, st, dM, dw_oihw, Cout, Cin, scale,
+                       accumulate);
+  else
+    hipLaunchKernelGGL(wino4_wgrad_output_kernel<2>, dim3(ceil_div((long)Cout * K, 256)), dim3(256), 0, st, dM, dw_oihw, Cout, Cin, scale,
+                       accumulate);
+  return check_launch("winograd_wgrad_output");
 }
 
 int dim_conv2d_fwd_winograd5x5s2(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,

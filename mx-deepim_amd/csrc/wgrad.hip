@@ -27,6 +27,9 @@ struct WgradArgs {
   int accumulate;
   unsigned x_bytes, dz_bytes;  // extents for the buffer descriptors
   FastDiv div_wo, div_ho;      // pixel index -> (n, ho, wo) every step without integer division sequences
+  // Winograd planes (dim_conv2d_wgrad_winograd): the K chunks [p * chunks_per_plane, (p + 1) * chunks_per_plane) belong to plane p,
+  // whose dZ operand sits dz_plane_stride channels further in the row (0 / 0: plain convolution)
+  int chunks_per_plane, dz_plane_stride;
 };
 
 template <int NW, bool CIN8, int NCH>
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
   // select (it compiled to flat loads, which also count on lgkmcnt and so serialised against the LDS fragment reads).
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz), 0, a.dz_bytes, 0x00020000);
-  const int z_voff = (a.dz_coff + co0 + zq * 4) * 4;
+  const int z_voff = (a.dz_coff + (a.chunks_per_plane ? (kc0 / a.chunks_per_plane) * a.dz_plane_stride : 0) + co0 + zq * 4) * 4;
   int tapb[NCH];  // byte offset of each chunk's tap / channel slice
 #pragma unroll
   for (int c = 0; c < NCH; ++c) tapb[c] = ((kh[c] * a.W + kw[c]) * a.in_cstride + c0[c]) * 4;
@@ -253,6 +256,9 @@ __global__ void lrelu_bwd_kernel(const float* __restrict__ y, int y_cstride, int
 
 }  // namespace dim
 
+namespace dim {
+int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, int accumulate, void* stream);
+}
 using namespace dim;
 
 extern "C" {
@@ -274,7 +280,7 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   DIM_REQUIRE((long)N * H * W * in_cstride < (1L << 29) && (long)N * Ho * Wo * dz_cstride < (1L << 29),
               "tensor too large for 32-bit byte offsets");
   DIM_REQUIRE(dz_cstride % 4 == 0 && dz_coff % 4 == 0 && in_cstride % 4 == 0, "channel strides / offsets must be multiples of 4");
-  WgradArgs a;
+  WgradArgs a = {};
   a.x = x; a.dz = dz;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_cstride = in_cstride; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.dz_cstride = dz_cstride; a.dz_coff = dz_coff; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
@@ -284,6 +290,15 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   a.div_wo = make_fastdiv((unsigned)Wo);
   a.div_ho = make_fastdiv((unsigned)Ho);
   a.nchunks = (Cin == 8) ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
+  return wgrad_launch(a, dw_packed, workspace, splits, accumulate, stream);
+}
+
+}  // extern "C"
+
+namespace dim {
+
+int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, int accumulate, void* stream) {
+  const int Cin = a.Cin, Cout = a.Cout;
   a.nsteps = ceil_div(a.M, 32);
   if (splits < 1) splits = 1;
   if (splits > a.nsteps) splits = a.nsteps;
@@ -317,6 +332,32 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   }
   return DIM_OK;
 }
+
+// The 36 plane products of a Winograd weight gradient, dM_p[k][co] = sum_t V[t][p][k] D[t][p][co], as ONE launch of the wgrad
+// kernel: a 1x1 "convolution" over T tile-pixels with planes * K input channels whose dZ operand moves with the plane.
+// dM comes out in the packed layout [p * K/32 + k/32][Cout][k%32].
+int launch_wgrad_planes(const float* V, const float* D, float* dM_packed, float* slabs, int T, int K, int Cout, int planes, int splits,
+                        hipStream_t st) {
+  DIM_REQUIRE(K % 64 == 0 && Cout % 64 == 0, "winograd wgrad: K %% 64 == 0 and Cout %% 64 == 0 required");
+  DIM_REQUIRE((long)T * planes * K < (1L << 29) && (long)T * planes * Cout < (1L << 29), "winograd wgrad: tensor too large for 32-bit byte offsets");
+  WgradArgs a = {};
+  a.x = V; a.dz = D;
+  a.N = 1; a.H = 1; a.W = T; a.Cin = planes * K; a.in_cstride = planes * K; a.Ho = 1; a.Wo = T; a.Cout = Cout;
+  a.dz_cstride = planes * Cout; a.dz_coff = 0; a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
+  a.M = T;
+  a.x_bytes = (unsigned)((long)T * planes * K * 4);
+  a.dz_bytes = (unsigned)((long)T * planes * Cout * 4);
+  a.div_wo = make_fastdiv((unsigned)T);
+  a.div_ho = make_fastdiv(1u);
+  a.nchunks = planes * (K / 32);
+  a.chunks_per_plane = K / 32;
+  a.dz_plane_stride = Cout;
+  return wgrad_launch(a, dM_packed, slabs, splits, 0, st);
+}
+
+}  // namespace dim
+
+extern "C" {
 
 // rows per partial block: at least 512, and few enough blocks (<= 256 per column tile) that the final fold stays short
 static int bias_rows_per_block(int M) {

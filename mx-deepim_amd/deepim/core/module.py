@@ -14,6 +14,8 @@ Master parameters keep the MXNet layouts and names (one flat fp32 vector, 57.75 
 """
 from __future__ import print_function, division
 
+import os
+
 import numpy as np
 import torch
 
@@ -134,6 +136,22 @@ class MutableModule(object):
                 h, w = ops.conv_out_hw(h, w, k, k, s, p)
                 c = cout
             self.wino_ws = torch.empty(need, dtype=torch.float32, device=d)
+        # Winograd weight gradients (3x3 / stride-1 and 5x5 / stride-2 layers whose maps are large enough: at 8x10 the 36 plane
+        # products are 3 pixel steps long and their 151 MB of dM cost more than the direct kernel saves): {layer: (S, pixel splits)}
+        self.wino_wgrad = {}
+        if os.environ.get("DIM_WINO_WGRAD", "1") != "0":
+            need, h, w, c = 4, 480, 640, 8
+            for name, cout, k, s, p in ENCODER:
+                ho, wo = ops.conv_out_hw(h, w, k, k, s, p)
+                S = 1 if name in net.wino else 2 if name in net.wino5 else 0
+                tiles = B * (-(-ho // 4)) * (-(-wo // 4))
+                if S and tiles >= 256 and (c * S * S) % 64 == 0:
+                    blocks = 36 * (c * S * S // 64) * (cout // 128 if cout % 128 == 0 else cout // 64)
+                    sp = max(1, min(-(-2048 // blocks), max(1, (tiles // 32) // 4)))
+                    self.wino_wgrad[name] = (S, sp)
+                    need = max(need, ops.lib().dim_conv2d_wgrad_winograd_workspace_floats(B, h, w, c, cout, S, sp))
+                h, w, c = ho, wo, cout
+            self.wino_wgrad_ws = torch.empty(need, dtype=torch.float32, device=d)
         self.repack(forward=False)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -261,8 +279,12 @@ class MutableModule(object):
                 dy.add_(self.dconcat3[..., :512])   # skip connection into Concat3
             ops.lrelu_bwd(net.acts[name], dy, cout)
             x = net.acts[prev[name]] if prev[name] else net.X
-            ops.conv2d_wgrad(x, cin[name], dy, cout, k, k, s, p, self.gpack, splits=self.wgrad_splits[name], workspace=self.ws)
-            ops.conv2d_unpack_weight(self.gpack, g[name + "_weight"])
+            if name in self.wino_wgrad:
+                S, sp = self.wino_wgrad[name]
+                ops.conv2d_wgrad_winograd(x, cin[name], dy, cout, g[name + "_weight"], S=S, splits=sp, workspace=self.wino_wgrad_ws)
+            else:
+                ops.conv2d_wgrad(x, cin[name], dy, cout, k, k, s, p, self.gpack, splits=self.wgrad_splits[name], workspace=self.ws)
+                ops.conv2d_unpack_weight(self.gpack, g[name + "_weight"])
             ops.bias_grad(dy, cout, g[name + "_bias"], workspace=self.bias_ws)
             if prev[name]:
                 if name in self.wino_dgrad:

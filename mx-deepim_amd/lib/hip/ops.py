@@ -244,6 +244,19 @@ def conv2d_dgrad_winograd5x5s2(dy_nhwc, Cout, w_packed, dx_nhwc, Cin, tile=0, wo
     return dx_nhwc
 
 
+def conv2d_wgrad_winograd(x_nhwc, Cin, dy_nhwc, Cout, dw_oihw, S=1, splits=4, workspace=None, scale=1.0, accumulate=False):
+    """dw (Cout,Cin,k,k) (+)= scale * weight gradient through Winograd; S = 1: 3x3 / stride 1 / pad 1, S = 2: 5x5 / stride 2 / pad 2"""
+    N, H, W, in_cs = x_nhwc.shape
+    k = 3 if S == 1 else 5
+    assert tuple(dw_oihw.shape) == (Cout, Cin, k, k) and dw_oihw.is_contiguous()
+    need = lib().dim_conv2d_wgrad_winograd_workspace_floats(N, H, W, Cin, Cout, S, splits)
+    if workspace is None or workspace.numel() < need:
+        workspace = _new((need,), x_nhwc)
+    check(lib().dim_conv2d_wgrad_winograd(dptr(x_nhwc, f32), dptr(dy_nhwc, f32), dptr(dw_oihw, f32), dptr(workspace, f32), N, H, W, Cin, in_cs,
+                                          Cout, dy_nhwc.shape[-1], S, splits, float(scale), int(accumulate), current_stream()))
+    return dw_oihw
+
+
 def _wino_events(events):
     import ctypes
 

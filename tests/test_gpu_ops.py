@@ -491,6 +491,36 @@ def test_conv5x5s2_winograd_dgrad_vs_f64(hip_lib, shape):
     assert np.abs(got[..., :Cin] - dx2.cpu().numpy()).max() <= tol
 
 
+@pytest.mark.parametrize("shape", [(2, 30, 40, 64, 128, 1), (1, 15, 21, 64, 64, 1), (3, 13, 18, 128, 256, 1), (2, 30, 40, 32, 64, 2),
+                                   (1, 15, 21, 64, 128, 2), (4, 24, 34, 32, 64, 2)])
+def test_conv_winograd_wgrad_vs_f64(hip_lib, shape):
+    """weight gradient through Winograd (F(3x3,4x4) per dY tile; S = 1: 3x3 / stride 1, S = 2: 5x5 / stride 2 over phase images) vs
+    torch-CPU float64 autograd; padded channel strides, several pixel splits, scale / accumulate"""
+    import torch.nn.functional as F
+    from lib.hip import ops
+
+    N, H, W, Cin, Cout, S = shape
+    k, pad = (3, 1) if S == 1 else (5, 2)
+    g = torch.Generator().manual_seed(sum(shape) + 17)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    Ho, Wo = (H, W) if S == 1 else ((H + 1) // 2, (W + 1) // 2)
+    dy = torch.randn((N, Cout, Ho, Wo), generator=g) / np.sqrt(N * Ho * Wo)
+    w = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, stride=S, padding=pad).backward(dy.double())
+    ref = w.grad.numpy()
+    xd = torch.zeros((N, H, W, Cin + 32), device="cuda:0")
+    xd[..., :Cin] = x.permute(0, 2, 3, 1).to("cuda:0")
+    dyd = torch.zeros((N, Ho, Wo, Cout + 64), device="cuda:0")
+    dyd[..., :Cout] = dy.permute(0, 2, 3, 1).to("cuda:0")
+    tol = 1e-4 * np.abs(ref).max() + 2e-6
+    for splits in (1, 3):
+        dw = torch.full((Cout, Cin, k, k), 9.0, device="cuda:0")
+        ops.conv2d_wgrad_winograd(xd, Cin, dyd, Cout, dw, S=S, splits=splits)
+        assert np.abs(dw.cpu().numpy() - ref).max() <= tol, splits
+    ops.conv2d_wgrad_winograd(xd, Cin, dyd, Cout, dw, S=S, splits=2, scale=0.5, accumulate=True)
+    assert np.abs(dw.cpu().numpy() - 1.5 * ref).max() <= 2 * tol
+
+
 def test_winograd_batch_slices(hip_lib, monkeypatch):
     """batches whose transformed tiles would exceed the 32-bit offsets of the plane GEMMs run as slices of whole images through
     the same workspace; DIM_WINO_MAX_SLICE forces that path at a size the test can check (5 images as 2 + 2 + 1)"""
