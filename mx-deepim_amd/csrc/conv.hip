@@ -43,6 +43,7 @@ struct ConvArgs {
   unsigned x_bytes, w_bytes;  // extents of x / w for the buffer descriptors (loads past them return 0)
   int xcd_chunk;   // > 0: workgroup id -> tile remap that keeps consecutive tiles on one XCD (see conv_fwd_kernel)
   FastDiv div_kw;  // 8-channel layer: flat tap index -> (kh, kw)
+  int boy, box;    // batched launch with scattered output: problem b lands at (ooy + (b >> 1) boy, oox + (b & 1) box) (deconv phases)
   long bx, bw, by; // batched launch (gridDim.y > 1): element strides of x / w / y between the problems (Winograd: 16 GEMMs)
   int tile_off;    // first tile of this launch (tail launch of an "auto" workload)
   int slab_row0;   // split-K slabs hold rows [slab_row0, M)
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
           int t = m / a.Wo;
           int ho = t % a.Ho;
           int n = t / a.Ho;
-          int oy = ho * a.osy + a.ooy, ox = wo * a.osx + a.oox;
+          int oy = ho * a.osy + a.ooy + (int)(blockIdx.y >> 1) * a.boy, ox = wo * a.osx + a.oox + (int)(blockIdx.y & 1) * a.box;
           if ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW) {
             float* o = yb + a.out_coff + ((long)(n * a.OH + oy) * a.OW + ox) * ldc + ncol;
 #pragma unroll
@@ -707,6 +708,7 @@ struct ConvEx {
   int Ho = 0, Wo = 0;    // > 0: explicit output grid instead of floor((H+2p-k)/s)+1 (asymmetric padding)
   int batch = 1;         // > 1: `batch` independent problems, strides below (elements)
   long bx = 0, bw = 0, by = 0;
+  int boy = 0, box = 0;  // scattered output: per-problem offset increments (see ConvArgs)
 };
 
 static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
@@ -758,6 +760,7 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   a.slab_stride = (long)N * a.Ho * a.Wo * Cout;
   const int batch = ex ? ex->batch : 1;
   a.bx = ex ? ex->bx : 0; a.bw = ex ? ex->bw : 0; a.by = ex ? ex->by : 0;
+  a.boy = ex ? ex->boy : 0; a.box = ex ? ex->box : 0;
   DIM_REQUIRE(batch == 1 || splits == 1, "batched launch does not combine with split-K");
   a.slope = slope;
   a.has_bias = bias != nullptr;
@@ -961,15 +964,15 @@ int dim_deconv4x4s2_fwd(const float* x, const float* w_packed, const float* bias
   DIM_REQUIRE(in_cstride >= CinPad, "in_cstride (%d) must cover the padded channel count %d (pad channels must hold zeros)", in_cstride,
               CinPad);
   DIM_REQUIRE(OH + crop <= 2 * H + 2 && OW + crop <= 2 * W + 2, "crop window outside the deconvolution output");
+  // the four output phases read the same input windows and differ in weights and in where they land: ONE batched launch
+  // (blockIdx.y = phase), 4x the workgroups of a per-phase launch on maps as small as 15x20
   const long per_phase = (long)CinPad * 4 * Cout;
-  for (int phase = 0; phase < 4; ++phase) {
-    int py = phase / 2, px = phase % 2;
-    ConvEx ex = {in_cstride, out_cstride, out_coff, OH, OW, 2, 2, py - crop, px - crop};
-    int rc = conv2d_fwd_impl(x, w_packed + phase * per_phase, bias, y, nullptr, N, H, W, CinPad, Cout, 2, 2, 1, 1, slope, 1, tile, 0,
-                             stream, &ex);
-    if (rc != DIM_OK) return rc;
-  }
-  return DIM_OK;
+  ConvEx ex = {in_cstride, out_cstride, out_coff, OH, OW, 2, 2, -crop, -crop};
+  ex.batch = 4;
+  ex.bw = per_phase;
+  ex.boy = 1;
+  ex.box = 1;
+  return conv2d_fwd_impl(x, w_packed, bias, y, nullptr, N, H, W, CinPad, Cout, 2, 2, 1, 1, slope, 1, tile, 0, stream, &ex);
 }
 
 int dim_conv_small_cout_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream) {
