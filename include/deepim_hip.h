@@ -192,6 +192,13 @@ int dim_conv2d_dgrad_winograd5x5s2(const float* dy, const float* w_packed, float
 long dim_conv2d_wgrad_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int S, int splits);
 int dim_conv2d_wgrad_winograd(const float* x, const float* dy, float* dw_oihw, float* workspace, int N, int H, int W, int Cin, int in_cstride,
                               int Cout, int dy_cstride, int S, int splits, float scale, int accumulate, void* stream);
+/* fc6 (deepim/symbols/deepIM_flownet.py:196-198) for the small batches of the refinement loop as a weight stream: y (B,Out) =
+ * LeakyReLU_slope(x (B,H,W,C NHWC) . W^T + bias) with W packed by dim_fc_pack_weight.  Every workgroup owns a contiguous range of K
+ * chunks and all outputs and writes one partial tile into `workspace` (dim_fc_fwd_workspace_floats floats); a second kernel sums the
+ * partials in a fixed order.  32 batch rows per pass.  Same result as dim_conv2d_fwd(KH=H, KW=W) up to the summation order. */
+long dim_fc_fwd_workspace_floats(int C, int H, int W, int Out);
+int dim_fc_fwd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int B, int C, int H, int W, int Out,
+               float slope, void* stream);
 /* dim_conv2d_pack_weight with the output channels zero-padded to CoutPad (multiple of 64) */
 int dim_conv2d_pack_weight_padded(const float* w_oihw, float* w_packed, int Cout, int CoutPad, int Cin, int KH, int KW, void* stream);
 /* Decoder (deepIM_flownet.py:213-299): y[..., out_coff:out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x, k=4, s=2, p=0) + bias,

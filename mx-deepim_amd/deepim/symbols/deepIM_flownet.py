@@ -227,7 +227,8 @@ class FlowNetHip(object):
         tile, splits = self.conv_plan["fc6"]
         self.layer_info["fc6"] = dict(M=B, K=81920, N=256, flops=2 * B * 81920 * 256, tile=tile, splits=splits, cin=1024,
                                       min_bytes=4 * (B * 81920 + 256 * 81920 + B * 256))
-        max_ws = max(max_ws, ops.lib().dim_conv2d_workspace_floats(B, 8, 10, 1024, 256, 8, 10, 1, 0, splits))
+        max_ws = max(max_ws, ops.lib().dim_conv2d_workspace_floats(B, 8, 10, 1024, 256, 8, 10, 1, 0, splits),
+                     ops.lib().dim_fc_fwd_workspace_floats(1024, 8, 10, 256))
         self.workspace = torch.empty((max(max_ws, 4),), dtype=torch.float32, device=d)
         # ---- decoder + flow / mask heads (only in the graph when not FAST_TEST, reference :840-954)
         self.has_decoder = "deconv5_weight" in self.params
@@ -300,9 +301,9 @@ class FlowNetHip(object):
             x = ops.conv2d_fwd(x, self.packed[name], self.params[name + "_bias"], cout, k, k, s, p, slope=0.1, splits=splits, tile=tile,
                                out=self.acts[name], workspace=self.workspace,
                                events=None if events is None else events.setdefault(name, []))
-        tile, splits = self.conv_plan["fc6"]
-        ops.conv2d_fwd(x, self.packed["fc6"], self.params["fc6_bias"], 256, 8, 10, 1, 0, slope=0.1, splits=splits, tile=tile,
-                       out=self.fc6, workspace=self.workspace, events=None if events is None else events.setdefault("fc6", []))
+        # fc6: a pure weight stream at these batch sizes (84 MB per forward) -> its own kernel instead of the 8x10 "convolution"
+        ops.fc_fwd(x, self.packed["fc6"], self.params["fc6_bias"], 256, slope=0.1, out=self.fc6, workspace=self.workspace,
+                   events=None if events is None else events.setdefault("fc6", []))
         return self.fc6
 
     def autotune(self, tiles=(3, 4), split_choices=(1, 2, 3, 4, 6, 8), reps=10):

@@ -70,6 +70,8 @@ SIGNATURES = {
     "dim_conv2d_dgrad_winograd5x5s2": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dim_conv2d_wgrad_winograd_workspace_floats": (L, [I, I, I, I, I, I, I]),
     "dim_conv2d_wgrad_winograd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P]),
+    "dim_fc_fwd_workspace_floats": (L, [I, I, I, I]),
+    "dim_fc_fwd": (I, [P, P, P, P, P, I, I, I, I, I, F, P]),
     "dim_conv2d_fwd_winograd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, P, P]),
     "dim_copy_words": (I, [P, P, L, P]),
     "dim_sgd_momentum": (I, [P, P, P, L, F, F, F, F, P]),

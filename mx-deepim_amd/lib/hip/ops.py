@@ -257,6 +257,27 @@ def conv2d_wgrad_winograd(x_nhwc, Cin, dy_nhwc, Cout, dw_oihw, S=1, splits=4, wo
     return dw_oihw
 
 
+def fc_fwd(x_nhwc, w_packed, bias, Out, slope=0.1, out=None, workspace=None, events=None):
+    """y (B,Out) = LeakyReLU(flatten(x) . W^T + b) as a weight stream (dim_fc_fwd); w_packed from fc_pack_weight.
+    events: optional list; one ("fc", start, end, 2) HIP-event tuple around the stream + reduce launches is appended."""
+    B, H, W, C = x_nhwc.shape
+    assert x_nhwc.is_contiguous()
+    out = out if out is not None else _new((B, Out), x_nhwc)
+    need = lib().dim_fc_fwd_workspace_floats(C, H, W, Out)
+    if workspace is None or workspace.numel() < need:
+        workspace = _new((need,), x_nhwc)
+    evs = None
+    if events is not None:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        evs[0].record()
+    check(lib().dim_fc_fwd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), dptr(workspace, f32), B, C, H, W, Out,
+                           float(slope), current_stream()))
+    if events is not None:
+        evs[1].record()
+        events.append(("fc", evs[0], evs[1], 2))
+    return out
+
+
 def _wino_events(events):
     import ctypes
 

@@ -521,6 +521,26 @@ def test_conv_winograd_wgrad_vs_f64(hip_lib, shape):
     assert np.abs(dw.cpu().numpy() - 1.5 * ref).max() <= 2 * tol
 
 
+@pytest.mark.parametrize("B", [1, 3, 16, 37])
+def test_fc_stream_vs_f64_and_conv_path(hip_lib, B):
+    """fc6 as a weight stream (dim_fc_fwd: partial tiles + fixed-order reduce, 32 rows per pass) vs float64 and vs the 8x10
+    "convolution" it replaces; MXNet's (c,h,w) flatten order"""
+    from lib.hip import ops
+
+    g = torch.Generator().manual_seed(40 + B)
+    feat = torch.randn((B, 1024, 8, 10), generator=g)
+    w = torch.randn((256, 81920), generator=g) * 0.01
+    b = torch.randn((256,), generator=g) * 0.1
+    ref = torch.nn.functional.leaky_relu(feat.double().reshape(B, -1) @ w.double().t() + b.double(), 0.1).numpy()
+    x = feat.permute(0, 2, 3, 1).contiguous().to("cuda:0")
+    wp = ops.fc_pack_weight(w.to("cuda:0"), 1024, 8, 10)
+    y = ops.fc_fwd(x, wp, b.to("cuda:0"), 256, slope=0.1)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, atol=5e-5, rtol=1e-4)
+    y2 = ops.conv2d_fwd(x, wp, b.to("cuda:0"), 256, 8, 10, 1, 0, slope=0.1, splits=40, tile=3).view(B, 256)
+    np.testing.assert_allclose(y.cpu().numpy(), y2.cpu().numpy(), atol=5e-5, rtol=1e-4)
+    np.testing.assert_array_equal(ops.fc_fwd(x, wp, b.to("cuda:0"), 256, slope=0.1).cpu().numpy(), y.cpu().numpy())  # deterministic
+
+
 def test_winograd_batch_slices(hip_lib, monkeypatch):
     """batches whose transformed tiles would exceed the 32-bit offsets of the plane GEMMs run as slices of whole images through
     the same workspace; DIM_WINO_MAX_SLICE forces that path at a size the test can check (5 images as 2 + 2 + 1)"""
