@@ -401,7 +401,9 @@ def test_fc6_and_pose_head(ops):
 @pytest.mark.parametrize("m", [2, 4])
 # the last shape has more (tile, plane) items than resident workgroups: stream-K ranges that start / end inside an item
 @pytest.mark.parametrize("shape", [(2, 15, 20, 64, 128), (1, 8, 10, 96, 64), (3, 30, 40, 256, 256), (2, 7, 9, 32, 64), (1, 3, 5, 32, 64),
-                                   (16, 58, 80, 64, 128)])
+                                   (16, 58, 80, 64, 128),
+                                   # few tiles, many weights (conv6_1-like): fewer rows than one workgroup tile
+                                   (2, 8, 10, 512, 512), (7, 7, 10, 256, 1024), (16, 8, 10, 256, 1024)])
 def test_conv3x3_winograd_vs_f64(hip_lib, shape, m):
     """Winograd F(2x2,3x3) / F(4x4,3x3) paths (odd and even H/W, partial edge tiles, bias + LeakyReLU) vs torch-CPU float64 conv2d"""
     import torch.nn.functional as F
