@@ -311,10 +311,17 @@ class FlowNetHip(object):
         Only speed changes: split-K alters the f32 summation order (|delta| ~1e-6 relative), nothing else."""
         x = self.X
         layers = [(n, co, k, k, s, p, self.params[n + "_bias"], self.acts[n]) for n, co, k, s, p in ENCODER]
-        layers.append(("fc6", 256, 8, 10, 1, 0, self.params["fc6_bias"], self.fc6))
         for name, cout, kh, kw, s, p, bias, out in layers:
             N, H, W, C = x.shape
-            cands = [(t, sp) for t in tiles for sp in (split_choices if name != "fc6" else (20, 40, 80, 160)) if not (t in (1, 4) and (cout % 128 or C == 8))]
+            if name in self.wino:  # Winograd layers have no (tile, splits) plan of the direct kernel: just produce their output
+                x = ops.conv2d_fwd_winograd(x, C, self.wino[name], bias, cout, slope=0.1, tile=self.layer_info[name]["wino_tile"], out=out,
+                                            workspace=self.workspace, m=self.wino_m[name])
+                continue
+            if name in self.wino5:
+                x = ops.conv2d_fwd_winograd5x5s2(x, C, self.wino5[name], bias, cout, slope=0.1, tile=self.layer_info[name]["wino_tile"],
+                                                 out=out, workspace=self.workspace)
+                continue
+            cands = [(t, sp) for t in tiles for sp in split_choices if not (t in (1, 4) and (cout % 128 or C == 8))]
             best = None
             for t, sp in cands:
                 ws_need = ops.lib().dim_conv2d_workspace_floats(N, H, W, C, cout, kh, kw, s, p, sp)
