@@ -177,7 +177,7 @@ def main():
             n_launch = ev[3] if len(ev) > 3 else 1  # auto mode: two conv launches (+ a reduce) inside one event pair
             if tag == "conv":  # the symbol rocprofv3 --kernel-trace reports for this launch
                 if info.get("winograd"):  # batched GEMM of the Winograd path: the multiply-adds that launch really executes
-                    kname = "dim::wino_gemm_kernel<{}>".format(TILE_SYM[info["wino_tile"]])  # + its zero kernel in the event pair
+                    kname = "dim::wino_gemm_kernel<{}>".format(TILE_SYM[info["wino_tile"]])
                     flops, nbytes = info["wino_flops"], info["wino_gemm_bytes"]
                 else:
                     kname = "dim::conv_fwd_kernel<{}, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")

@@ -68,6 +68,56 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff,
 }
 #endif
 
+// ---- plane GEMMs of the Winograd layers (wino_gemm.hip): launch plan, shared with the input-transform kernels of conv.hip, whose
+// spare blocks zero the output tiles that two stream-K workgroups share (saves a launch per layer)
+struct WGemmArgs {
+  const float* V;
+  const float* U;
+  float* M;
+  int T, K, Cout, P;
+  int nch;       // K / 32
+  int NTN;       // Cout / BN
+  int per, rem;  // chunks per workgroup: per, +1 for the first rem workgroups
+  unsigned v_bytes, u_bytes, m_bytes;
+  FastDiv d_nch, d_P, d_NTN;
+  int G, BM, BN, tile;  // workgroups of the GEMM launch, its tile shape and id
+};
+int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile);
+// zeroed = the shared tiles have been zeroed already (by the transform kernel that ran before): no separate zero launch
+int wino_gemm_run(const WGemmArgs& plan, bool zeroed, hipStream_t st);
+
+#ifdef __HIPCC__
+// position in the flat chunk list: item = (mt * NTN + nt) * P + p, chunk ch of it
+struct WCur {
+  int ch, p, nt, mt;
+};
+__device__ __forceinline__ WCur wcur_decode(int chunk, const WGemmArgs& a) {
+  WCur c;
+  const unsigned item = fastdiv((unsigned)chunk, a.d_nch);
+  c.ch = chunk - (int)item * a.nch;
+  const unsigned t = fastdiv(item, a.d_P);
+  c.p = (int)(item - t * a.P);
+  const unsigned mt = fastdiv(t, a.d_NTN);
+  c.nt = (int)(t - mt * a.NTN);
+  c.mt = (int)mt;
+  return c;
+}
+__device__ __forceinline__ int wg_first_chunk(int w, const WGemmArgs& a) { return w * a.per + min(w, a.rem); }
+// one 256-thread block zeroes the output tile of the item that the range boundary in front of workgroup w (1 <= w < G) falls into
+__device__ __forceinline__ void wino_gemm_zero_tile(const WGemmArgs& a, int w) {
+  const WCur c = wcur_decode(wg_first_chunk(w, a), a);
+  if (c.ch == 0) return;  // the boundary coincides with an item boundary
+  const int ldc = a.P * a.Cout;
+  float* base = a.M + (long)c.mt * a.BM * ldc + c.p * a.Cout + c.nt * a.BN;
+  const int rows = min(a.BM, a.T - c.mt * a.BM);
+  const int q = a.BN / 4;
+  for (int idx = threadIdx.x; idx < rows * q; idx += 256) {
+    const int r = idx / q, c4 = idx - r * q;
+    *reinterpret_cast<float4*>(base + (long)r * ldc + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+#endif
+
 }  // namespace dim
 
 #define DIM_REQUIRE(cond, ...)                                   \

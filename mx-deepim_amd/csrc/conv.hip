@@ -1194,9 +1194,14 @@ struct WinoVec {
 // GEMM per Winograd plane contracts over phases and channels and the output transform is that of the stride-1 layer.
 template <int VEC, int S>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C,
-                                                          int in_cstride, int th, int tw, FastDiv div_cq, FastDiv div_tw, FastDiv div_th) {
+                                                          int in_cstride, int th, int tw, FastDiv div_cq, FastDiv div_tw, FastDiv div_th,
+                                                          unsigned nblk, WGemmArgs plan) {
 #pragma clang fp contract(fast)
   typedef typename WinoVec<VEC>::type vf;
+  if (blockIdx.x >= nblk) {  // spare blocks: zero the M tiles that two workgroups of the following stream-K GEMM share
+    wino_gemm_zero_tile(plan, (int)(blockIdx.x - nblk) + 1);
+    return;
+  }
   const unsigned idx = blockIdx.x * 256u + threadIdx.x;
   const unsigned CT = C * S * S;  // channels of V
   const unsigned CQ = CT / VEC;
@@ -1540,21 +1545,25 @@ static int winograd_slice(const float* x, const float* w_packed, const float* bi
     hipError_t e = hipEventRecord(reinterpret_cast<hipEvent_t>(events4[I]), st);           \
     if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipEventRecord: %s", hipGetErrorString(e)); \
   }
+  if (tile == 0) tile = (Cout % 128 == 0 && T >= 1024) ? 4 : 3;
+  WGemmArgs plan;
+  int rc = wino_gemm_plan(&plan, V, w_packed, M, (int)T, CT, Cout, nk, tile);
+  if (rc != DIM_OK) return rc;
   DIM_WINO_EVENT(0)
+  const unsigned nblk = (unsigned)ceil_div(T * (CT / kWino4Vec), 256);
   if (m == 2)
     hipLaunchKernelGGL(wino_input_kernel, dim3(ceil_div(T * (Cin / 4), 256)), dim3(256), 0, st, x, V, N, H, W, Cin, in_cstride, th, tw,
                        make_fastdiv((unsigned)(Cin / 4)), dtw, dth);
-  else if (S == 1)
-    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 1>), dim3(ceil_div(T * (CT / kWino4Vec), 256)), dim3(256), 0, st, x, V, N, H, W, Cin,
-                       in_cstride, th, tw, make_fastdiv((unsigned)(CT / kWino4Vec)), dtw, dth);
+  else if (S == 1)  // + G - 1 spare blocks that zero the M tiles shared by two GEMM workgroups
+    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 1>), dim3(nblk + plan.G - 1), dim3(256), 0, st, x, V, N, H, W, Cin, in_cstride, th, tw,
+                       make_fastdiv((unsigned)(CT / kWino4Vec)), dtw, dth, nblk, plan);
   else
-    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 2>), dim3(ceil_div(T * (CT / kWino4Vec), 256)), dim3(256), 0, st, x, V, N, H, W, Cin,
-                       in_cstride, th, tw, make_fastdiv((unsigned)(CT / kWino4Vec)), dtw, dth);
-  int rc = check_launch("winograd_input");
+    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 2>), dim3(nblk + plan.G - 1), dim3(256), 0, st, x, V, N, H, W, Cin, in_cstride, th, tw,
+                       make_fastdiv((unsigned)(CT / kWino4Vec)), dtw, dth, nblk, plan);
+  rc = check_launch("winograd_input");
   if (rc != DIM_OK) return rc;
   DIM_WINO_EVENT(1)
-  if (tile == 0) tile = (Cout % 128 == 0 && T >= 1024) ? 4 : 3;
-  rc = launch_wino_gemm(V, w_packed, M, (int)T, CT, Cout, nk, tile, st);
+  rc = wino_gemm_run(plan, m == 4, st);
   if (rc != DIM_OK) return rc;
   DIM_WINO_EVENT(2)
   if (m == 2)
@@ -1653,12 +1662,15 @@ int dim_conv2d_dgrad_winograd5x5s2(const float* dy, const float* w_packed, float
     const long T = (long)n * th * tw;
     float* V = workspace;
     float* M = workspace + 36 * T * Cout;
-    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 1>), dim3(ceil_div(T * (Cout / kWino4Vec), 256)), dim3(256), 0, st,
-                       dy + (long)n0 * Ho * Wo * dy_cstride, V, n, Ho, Wo, Cout, dy_cstride, th, tw, make_fastdiv((unsigned)(Cout / kWino4Vec)),
-                       dtw, dth);
-    int rc = check_launch("winograd_dgrad_input");
+    WGemmArgs plan;
+    int rc = wino_gemm_plan(&plan, V, w_packed, M, (int)T, Cout, CT, 36, tile == 0 ? ((CT % 128 == 0 && T >= 1024) ? 4 : 3) : tile);
     if (rc != DIM_OK) return rc;
-    rc = launch_wino_gemm(V, w_packed, M, (int)T, Cout, CT, 36, tile == 0 ? ((CT % 128 == 0 && T >= 1024) ? 4 : 3) : tile, st);
+    const unsigned nblk = (unsigned)ceil_div(T * (Cout / kWino4Vec), 256);
+    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 1>), dim3(nblk + plan.G - 1), dim3(256), 0, st, dy + (long)n0 * Ho * Wo * dy_cstride, V, n,
+                       Ho, Wo, Cout, dy_cstride, th, tw, make_fastdiv((unsigned)(Cout / kWino4Vec)), dtw, dth, nblk, plan);
+    rc = check_launch("winograd_dgrad_input");
+    if (rc != DIM_OK) return rc;
+    rc = wino_gemm_run(plan, true, st);
     if (rc != DIM_OK) return rc;
     hipLaunchKernelGGL((wino4_output_kernel<kWino4Vec, 2>), dim3(ceil_div(T * (CT / kWino4Vec), 256)), dim3(256), 0, st, M, nullptr,
                        dx + (long)n0 * H * W * dx_cstride, n, H, W, Cin, dx_cstride, 0, th, tw, 1.0f, make_fastdiv((unsigned)(CT / kWino4Vec)),
@@ -1699,12 +1711,14 @@ int dim_conv2d_wgrad_winograd(const float* x, const float* dy, float* dw_oihw, f
   float* slabs = dM + 36L * K * Cout;
   hipStream_t st = as_stream(stream);
   const FastDiv dtw = make_fastdiv((unsigned)tw), dth = make_fastdiv((unsigned)th);
+  const unsigned nblk = (unsigned)ceil_div(T * (K / kWino4Vec), 256);  // no stream-K GEMM follows: no spare blocks
+  const WGemmArgs none = {};
   if (S == 1)
-    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 1>), dim3(ceil_div(T * (K / kWino4Vec), 256)), dim3(256), 0, st, x, V, N, H, W, Cin,
-                       in_cstride, th, tw, make_fastdiv((unsigned)(K / kWino4Vec)), dtw, dth);
+    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 1>), dim3(nblk), dim3(256), 0, st, x, V, N, H, W, Cin, in_cstride, th, tw,
+                       make_fastdiv((unsigned)(K / kWino4Vec)), dtw, dth, nblk, none);
   else
-    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 2>), dim3(ceil_div(T * (K / kWino4Vec), 256)), dim3(256), 0, st, x, V, N, H, W, Cin,
-                       in_cstride, th, tw, make_fastdiv((unsigned)(K / kWino4Vec)), dtw, dth);
+    hipLaunchKernelGGL((wino4_input_kernel<kWino4Vec, 2>), dim3(nblk), dim3(256), 0, st, x, V, N, H, W, Cin, in_cstride, th, tw,
+                       make_fastdiv((unsigned)(K / kWino4Vec)), dtw, dth, nblk, none);
   hipLaunchKernelGGL(wino4_dy_kernel<kWino4Vec>, dim3(ceil_div(T * (Cout / kWino4Vec), 256)), dim3(256), 0, st, dy, D, N, Ho, Wo, Cout,
                      dy_cstride, th, tw, make_fastdiv((unsigned)(Cout / kWino4Vec)), dtw, dth);
   int rc = check_launch("winograd_wgrad_transforms");

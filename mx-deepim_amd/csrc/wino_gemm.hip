@@ -12,7 +12,7 @@
 // never draining: the prefetch of the next (plane, tile)'s first chunks is in flight while the last chunk of the current one is
 // multiplied; at the end of an item the accumulators are stored and cleared between two chunks.  Ranges start and end anywhere,
 // so at most one item per workgroup boundary is shared by two workgroups; its output tile is zeroed beforehand
-// (wino_gemm_zero_kernel) and both add their partial sums with float atomics -- two summands on a zero: the result does not
+// (by spare blocks of the input-transform kernel that runs in front: common.h wino_gemm_zero_tile) and both add their partial sums with float atomics -- two summands on a zero: the result does not
 // depend on their order, the launch stays deterministic.
 //
 // Layouts (plane-minor, so that "next plane" is just "next K columns" for the loader):
@@ -25,33 +25,6 @@ namespace dim {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct WGemmArgs {
-  const float* V;
-  const float* U;
-  float* M;
-  int T, K, Cout, P;
-  int nch;       // K / 32
-  int NTN;       // Cout / BN
-  int per, rem;  // chunks per workgroup: per, +1 for the first rem workgroups
-  unsigned v_bytes, u_bytes, m_bytes;
-  FastDiv d_nch, d_P, d_NTN;
-};
-
-// position in the flat chunk list: item = (mt * NTN + nt) * P + p, chunk ch of it
-struct WCur {
-  int ch, p, nt, mt;
-};
-__device__ __forceinline__ WCur wcur_decode(int chunk, const WGemmArgs& a) {
-  WCur c;
-  const unsigned item = fastdiv((unsigned)chunk, a.d_nch);
-  c.ch = chunk - (int)item * a.nch;
-  const unsigned t = fastdiv(item, a.d_P);
-  c.p = (int)(item - t * a.P);
-  const unsigned mt = fastdiv(t, a.d_NTN);
-  c.nt = (int)(t - mt * a.NTN);
-  c.mt = (int)mt;
-  return c;
-}
 __device__ __forceinline__ void wcur_advance(WCur& c, const WGemmArgs& a) {
   if (++c.ch == a.nch) {
     c.ch = 0;
@@ -64,8 +37,6 @@ __device__ __forceinline__ void wcur_advance(WCur& c, const WGemmArgs& a) {
     }
   }
 }
-__device__ __forceinline__ int wg_first_chunk(int w, const WGemmArgs& a) { return w * a.per + min(w, a.rem); }
-
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void wino_gemm_kernel(WGemmArgs a) {
   constexpr int BK = 32;
@@ -234,26 +205,12 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(4,
 #undef W_LOAD_CHUNK
 }
 
-// zero the output tile of every item that two workgroups share (the one a range boundary falls into)
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void wino_gemm_zero_kernel(WGemmArgs a) {
-  const int w = blockIdx.x + 1;
-  const int cb = wg_first_chunk(w, a);
-  const WCur c = wcur_decode(cb, a);
-  if (c.ch == 0) return;  // the boundary coincides with an item boundary
-  const int ldc = a.P * a.Cout;
-  float* base = a.M + (long)c.mt * BM * ldc + c.p * a.Cout + c.nt * BN;
-  const int rows = min(BM, a.T - c.mt * BM);
-  for (int idx = threadIdx.x; idx < rows * (BN / 4); idx += 256) {
-    const int r = idx / (BN / 4), c4 = idx - r * (BN / 4);
-    *reinterpret_cast<float4*>(base + (long)r * ldc + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
+// zero the output tile of every item that two workgroups share (only when the transform kernel in front did not do it)
+__global__ __launch_bounds__(256) void wino_gemm_zero_kernel(WGemmArgs a) { wino_gemm_zero_tile(a, blockIdx.x + 1); }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_wino_gemm_t(WGemmArgs a, int T, int items, hipStream_t st) {
-  // as many workgroups as are resident at once (occupancy x CUs), never more than there are items: every range is then at
-  // least one item long and an item is shared by at most two workgroups
+static int wino_gemm_slots() {
+  // as many workgroups as are resident at once (occupancy x CUs)
   static int slots = 0;
   if (slots == 0) {
     int dev = 0, cus = 0, occ = 0;
@@ -265,18 +222,12 @@ static int launch_wino_gemm_t(WGemmArgs a, int T, int items, hipStream_t st) {
     if (e != hipSuccess || cus <= 0 || occ <= 0) return set_err(DIM_ERR_LAUNCH, "winograd gemm occupancy query: %s", hipGetErrorString(e));
     slots = cus * occ;
   }
-  const int G = items < slots ? items : slots;
-  const long total = (long)items * a.nch;
-  a.per = (int)(total / G);
-  a.rem = (int)(total % G);
-  if (G > 1) hipLaunchKernelGGL((wino_gemm_zero_kernel<BM, BN>), dim3(G - 1), dim3(256), 0, st, a);
-  hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN>), dim3(G), dim3(WM * WN * 64), 2 * BM * 36 * sizeof(float), st, a);
-  return check_launch("winograd_gemm");
+  return slots;
 }
 
 // tile: 4 = 128x128 (8 waves), anything else = 64x64 (4 waves)
-int launch_wino_gemm(const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile, hipStream_t st) {
-  if (tile == 4 && Cout % 128 != 0) tile = 3;
+int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile) {
+  if (tile != 4 || Cout % 128 != 0) tile = 3;
   const int BM = tile == 4 ? 128 : 64, BN = BM;
   DIM_REQUIRE(K % 32 == 0 && Cout % BN == 0 && T > 0, "winograd gemm: K %% 32 == 0 and Cout %% 64 == 0 required");
   const long MT = (T + BM - 1) / BM;
@@ -300,8 +251,34 @@ int launch_wino_gemm(const float* V, const float* U, float* M, int T, int K, int
   a.d_nch = make_fastdiv((unsigned)a.nch);
   a.d_P = make_fastdiv((unsigned)P);
   a.d_NTN = make_fastdiv((unsigned)a.NTN);
-  if (tile == 4) return launch_wino_gemm_t<128, 128, 2, 4>(a, T, (int)items, st);
-  return launch_wino_gemm_t<64, 64, 2, 2>(a, T, (int)items, st);
+  a.BM = BM;
+  a.BN = BN;
+  a.tile = tile;
+  // never more workgroups than items: every range is then at least one item long and an item is shared by at most two workgroups
+  const int slots = tile == 4 ? wino_gemm_slots<128, 128, 2, 4>() : wino_gemm_slots<64, 64, 2, 2>();
+  if (slots <= 0) return slots;
+  a.G = items < slots ? (int)items : slots;
+  const long total = items * a.nch;
+  a.per = (int)(total / a.G);
+  a.rem = (int)(total % a.G);
+  *plan = a;
+  return DIM_OK;
+}
+
+int wino_gemm_run(const WGemmArgs& a, bool zeroed, hipStream_t st) {
+  if (!zeroed && a.G > 1) hipLaunchKernelGGL(wino_gemm_zero_kernel, dim3(a.G - 1), dim3(256), 0, st, a);
+  if (a.tile == 4)
+    hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 4>), dim3(a.G), dim3(512), 2 * 128 * 36 * sizeof(float), st, a);
+  else
+    hipLaunchKernelGGL((wino_gemm_kernel<64, 64, 2, 2>), dim3(a.G), dim3(256), 2 * 64 * 36 * sizeof(float), st, a);
+  return check_launch("winograd_gemm");
+}
+
+int launch_wino_gemm(const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile, hipStream_t st) {
+  WGemmArgs a;
+  int rc = wino_gemm_plan(&a, V, U, M, T, K, Cout, P, tile);
+  if (rc != DIM_OK) return rc;
+  return wino_gemm_run(a, false, st);
 }
 
 }  // namespace dim
