@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--cfg", default=os.path.join(PKG, "experiments", "deepim", "cfgs", "deepim_hip_LM_ape_test.yaml"))
     ap.add_argument("--subdiv", type=int, default=5, help="icosphere subdivisions of the synthetic mesh (5 = 20480 triangles)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--full-graph", action="store_true",
+                    help="not the headline: run the full test graph (decoder + flow / mask heads every iteration, TEST.FAST_TEST = False)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a box with fewer GPUs than ranks, together with DIM_BENCH_DEVICE)")
     ap.add_argument("--no-winograd", action="store_true", help="run every encoder layer through the direct kernel")
@@ -120,6 +122,8 @@ def main():
     from lib.utils import synthetic as syn
 
     update_config(args.cfg)
+    if args.full_graph:
+        cfg.TEST.FAST_TEST = False
     B = args.batch_pairs or int(cfg.TEST.BATCH_PAIRS)
     test_iter = int(cfg.TEST.test_iter)
     sym = deepIM_flownet()
@@ -225,8 +229,10 @@ def main():
         "metric": "pose-refinements/sec (4 iters, 480x640)", "value": round(value, 2), "unit": "pose-refinements/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "LINEMOD 'ape' batch={} per GPU, {} iters, fp32, FAST_TEST graph (zoom + FlowNetS encoder + FC heads) "
-                               "+ SE3 compose + HIP rasteriser ({} triangles) + box_rendered mask update".format(
+        "config": {"workload": ("LINEMOD 'ape' batch={} per GPU, {} iters, fp32, "
+                                + ("FULL test graph (zoom + FlowNetS encoder + FC heads + decoder + flow / mask heads) " if args.full_graph
+                                   else "FAST_TEST graph (zoom + FlowNetS encoder + FC heads) ")
+                                + "+ SE3 compose + HIP rasteriser ({} triangles) + box_rendered mask update").format(
                                    B, test_iter, models[0][2].shape[0]),
                    "pairs_per_gpu": B, "global_pairs": B * world, "test_iter": test_iter, "hipgraph": not args.no_graph, "winograd": "off" if args.no_winograd else "F(4x4,3x3): conv3_1 conv4_1 conv5_1 conv6_1; phase images + F(4x4,3x3): conv2 conv3",
                    "gflop_per_refinement": round(net.flops_per_forward() * test_iter / B / 1e9, 2), "status_flags": status,
