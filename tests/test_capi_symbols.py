@@ -22,6 +22,20 @@ def test_pure_host_queries(hip_lib):
     assert hip_lib.dim_conv2d_packed_weight_floats(128, 64, 5, 5) == 25 * 64 * 128
     assert hip_lib.dim_conv2d_workspace_floats(2, 8, 10, 512, 1024, 3, 3, 1, 1, 4) == 4 * 2 * 8 * 10 * 1024
     assert hip_lib.dim_raster_workspace_bytes(2, 100, 480, 640) == 2 * 480 * 640 * 8 + 2 * 100 * 12
+    # Winograd paths: packed weights = planes x K x Cout, workspace = planes x tiles x (K + Cout)
+    assert hip_lib.dim_winograd_packed_weight_floats(256, 128, 4) == 36 * 256 * 128
+    assert hip_lib.dim_winograd_packed_weight_floats(256, 128, 2) == 16 * 256 * 128
+    assert hip_lib.dim_winograd_workspace_floats(16, 60, 80, 256, 256, 4) == 36 * (16 * 15 * 20) * 512
+    assert hip_lib.dim_winograd_workspace_floats(16, 60, 80, 256, 256, 2) == 16 * (16 * 30 * 40) * 512
+    assert hip_lib.dim_winograd_workspace_floats(1, 7, 9, 32, 64, 3) == 0  # unsupported tile size
+    assert hip_lib.dim_winograd5x5s2_packed_weight_floats(128, 64) == 36 * 128 * 256
+    assert hip_lib.dim_winograd5x5s2_workspace_floats(16, 240, 320, 64, 128) == 36 * (16 * 30 * 40) * (256 + 128)
+    # batches whose transformed tiles would overflow 32-bit byte offsets run in slices: the workspace stops growing with N
+    big = hip_lib.dim_winograd5x5s2_workspace_floats(512, 240, 320, 64, 128)
+    assert big == hip_lib.dim_winograd5x5s2_workspace_floats(1024, 240, 320, 64, 128)
+    assert big * 4 * 256 // (256 + 128) < (1 << 32)  # V of one slice stays below 4 GiB
+    assert hip_lib.dim_conv2d_wgrad_winograd_workspace_floats(16, 60, 80, 256, 256, 1, 4) == 36 * 4800 * 512 + 36 * 256 * 256 * 5
+    assert hip_lib.dim_fc_fwd_workspace_floats(1024, 8, 10, 256) == 256 * 32 * 256
 
 
 def test_product_never_imports_oracle():
