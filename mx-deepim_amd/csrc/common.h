@@ -66,6 +66,16 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff,
   f.w = __uint_as_float(v.w);
   return f;
 }
+// the same with the non-temporal hint: operands that are streamed once (the V planes of a Winograd GEMM)
+__device__ __forceinline__ float4 buf_load16_nt(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);
+  float4 f;
+  f.x = __uint_as_float(v.x);
+  f.y = __uint_as_float(v.y);
+  f.z = __uint_as_float(v.z);
+  f.w = __uint_as_float(v.w);
+  return f;
+}
 #endif
 
 // ---- plane GEMMs of the Winograd layers (wino_gemm.hip): launch plan, shared with the input-transform kernels of conv.hip, whose

@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     const vf* d = tmp + 6 * a;
     DIM_WINO4_BT(o, d, 1)
 #pragma unroll
-    for (int b = 0; b < 6; ++b) *reinterpret_cast<vf*>(out + (a * 6 + b) * plane) = o[b];
+    for (int b = 0; b < 6; ++b) __builtin_nontemporal_store(o[b], reinterpret_cast<vf*>(out + (a * 6 + b) * plane));
   }
 }
 
@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
   for (int b = 0; b < 6; ++b) {
     vf m[6];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const vf*>(in + (a * 6 + b) * plane);
+    for (int a = 0; a < 6; ++a) m[a] = __builtin_nontemporal_load(reinterpret_cast<const vf*>(in + (a * 6 + b) * plane));
     vf* o = rr + b;
     DIM_WINO4_AT(o, m, 6)
   }

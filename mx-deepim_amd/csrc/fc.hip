@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void fc_stream_kernel(FcArgs a) {
     const int woff = (KC) * wchunk_bytes;                                                     \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                           \
       fa[SET][g] = buf_load16(rx, a_voff == -1 ? -1 : a_voff + g * 32, xoff);                 \
-      fb[SET][g][0] = buf_load16(rw, b_voff + g * 32, woff);                                  \
-      fb[SET][g][1] = buf_load16(rw, b_voff + 32 * 32 * 4 + g * 32, woff);                    \
+      fb[SET][g][0] = buf_load16_nt(rw, b_voff + g * 32, woff);                               \
+      fb[SET][g][1] = buf_load16_nt(rw, b_voff + 32 * 32 * 4 + g * 32, woff);                 \
     }                                                                                         \
   }
   f32x16 acc[2];

@@ -81,8 +81,8 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(4,
     const bool pf = (PF_OK);                                                           \
     const int mb = L.mt * BM;                                                          \
     const int soff = (int)((unsigned)(mb * RS + L.p * a.K + L.ch * BK) * 4u);          \
-    ra0 = buf_load16(rv, (pf && mb + srow < a.T) ? a_voff0 : -1, soff);                \
-    ra1 = buf_load16(rv, (pf && mb + srow + RP < a.T) ? a_voff1 : -1, soff);           \
+    ra0 = buf_load16_nt(rv, (pf && mb + srow < a.T) ? a_voff0 : -1, soff);             \
+    ra1 = buf_load16_nt(rv, (pf && mb + srow + RP < a.T) ? a_voff1 : -1, soff);        \
     wcur_advance(L, a);                                                                \
   }
 #define W_STORE_CHUNK(BUF)                                                             \
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(4,
           const int dr = 32 * i + (r & 3) + 8 * (r >> 2);                                                              \
           const int vo = (orow + dr < lim) ? ov + (dr * ldc + 32 * j) * 4 : -1; /* rows past T: rejected by the range check */ \
           if (plain)                                                                                                   \
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rm, vo, soff, 0);                     \
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rm, vo, soff, 2);                     \
           else if (vo != -1) /* exec-masked rather than rejected: an out-of-range buffer ATOMIC faulted on this part */  \
             __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][r], rm, vo, soff, 0);                            \
         }                                                                                                              \
