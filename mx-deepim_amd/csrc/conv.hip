@@ -5,7 +5,8 @@
 // weights are pre-packed once into [K/32 chunks][Cout][32] (chunk order: 32-channel slice outer, taps inner); implicit GEMM
 //     Y[m = (n,ho,wo)][co] = sum_k X[n, ho*s-p+kh, wo*s-p+kw, c] * Wp[k][co]
 // with a 32-deep K chunk that is one tap x 32 channels (Cin % 32 == 0) or, for the 8-channel
-// first layer, four horizontally adjacent taps x 8 channels (= 32 contiguous floats in HBM).
+// first layer, four consecutive taps (flat, row-major over the kernel window) x 8 channels.
+// The 3x3 / stride-1 and 5x5 / stride-2 layers normally run in the Winograd domain instead (second half of this file + wino_gemm.hip).
 //
 // Block = 4 (or 8) waves; wave tile = (BM/WM) x (BN/WN) in 32x32 MFMA tiles.
 // LDS: the A (pixel) chunk [BM][32+4], k-contiguous: staged with one ds_write_b128 per float4 and read back as ds_read_b128 =

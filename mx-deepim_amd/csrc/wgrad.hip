@@ -3,8 +3,8 @@
 //   dWp[chunk][co][kin] = sum over pixels m=(n,ho,wo) of  dZ[m][co] * X[n, ho*s-p+kh, wo*s-p+kw, c0+kin]
 //
 // written DIRECTLY in the forward kernel's packed weight layout ([chunk][Cout][32], chunk = (32-channel slice, kh, kw) or, for
-// the 8-channel first layer, (kh, 4-tap group)), so SGD (elementwise) updates the packed weights in place and nothing is ever
-// re-packed during training.  Replaces the cuDNN backward-filter calls behind MXNet's Convolution / FullyConnected backward
+// the 8-channel first layer, four consecutive flat taps x 8 channels); dim_conv2d_unpack_weight brings it into the MXNet-layout
+// gradient bucket the optimizer works on.  Replaces the cuDNN backward-filter calls behind MXNet's Convolution / FullyConnected backward
 // (reference graph: deepim/symbols/deepIM_flownet.py:67-208; executor: deepim/core/module.py:1205-1209).
 //
 // Implicit GEMM with the PIXELS as the contraction dimension: A = dZ^T (co x pixels), B = gathered X (pixels x 32).
