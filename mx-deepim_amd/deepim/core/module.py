@@ -334,13 +334,21 @@ class MutableModule(object):
                 self.flat_v = torch.zeros_like(self.flat_m)
             b1, b2, t = 0.9, 0.999, self.num_update
             lr_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+            # only the SGD branch of train.py:383 forces rescale_grad = 1.0; for Adam Module.init_optimizer (module.py:566-584)
+            # fills in 1 / batch_size, batch_size = pairs over all devices
+            rescale = 1.0 / float(self.B * self.world_size())
             for a, b, _ in seg:
-                ops.adam(self.flat_w[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], lr_t, b1, b2, 1e-8, 0.0, 1.0)
+                ops.adam(self.flat_w[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], lr_t, b1, b2, 1e-8, 0.0, rescale)
         else:
             mom, wd = float(cfg.TRAIN.momentum), float(cfg.TRAIN.wd)
             for a, b, decay in seg:
                 ops.sgd_momentum(self.flat_w[a:b], self.flat_g[a:b], self.flat_m[a:b], lr, mom, wd if decay else 0.0, 1.0)
         self.repack(forward=True)
+
+    def world_size(self):
+        import torch.distributed as dist
+
+        return dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
 
     # optimizer state checkpoint (the reference pickles MXNet updater states: module_checkpoint(save_optimizer_states=True),
     # train.py:314-316 -- that pickle needs mxnet to read, so the state travels as a plain .npz here)
@@ -382,7 +390,9 @@ class MutableModule(object):
 
 def fit_batch(module, data_batch, batch_updater, lr):
     """The inner TRAIN_ITER_SIZE loop of MutableModule.fit (reference module.py:1205-1213): every iteration is a separate
-    optimizer step on refreshed inputs.  Returns the per-iteration outputs (what get_outputs feeds update_metric)."""
+    optimizer step on refreshed inputs.  Returns the per-iteration outputs (what get_outputs feeds update_metric).
+    lr: a float, or an LRScheduler -- then it is asked before EVERY update with that update's number, as mx.optimizer does
+    (a step boundary inside the inner loop takes effect at once, not at the next batch)."""
     cfg = module.cfg
     n_iter = int(cfg.network.TRAIN_ITER_SIZE) if cfg.network.TRAIN_ITER else 1
     outs = []
@@ -393,7 +403,7 @@ def fit_batch(module, data_batch, batch_updater, lr):
                      # what deepim/core/metric.py reads (Flow_L2Loss, PointMatchingLoss, MaskLoss)
                      "flow_loss_sum": module.loss_sums[0].clone(), "point_matching_loss_sum": module.loss_sums[1].clone(),
                      "mask_prob": module.mask_prob, "mask_gt": module.zoom_mask_gt})
-        module.update(lr)
+        module.update(lr(module.num_update + 1) if callable(lr) else lr)
         if iter_idx != n_iter - 1:
             data_batch = batch_updater.forward(data_batch, preds, cfg)
     return outs

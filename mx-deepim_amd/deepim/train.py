@@ -78,7 +78,7 @@ def train_net(args):
     arg_params = sym_instance.init_weights(config, arg_params, {}, seed=0)
 
     B = int(config.TRAIN.BATCH_PAIRS)
-    data = SyntheticPairs(config, args.num_pairs, B, device=device, rank=rank, world=world)
+    data = SyntheticPairs(config, args.num_pairs, B, device=device, rank=rank, world=world, equal_shards=True)
     mod = MutableModule(config, arg_params, B, device=device)
     states = "%s-%04d.states.npz" % (prefix, begin_epoch)
     if config.TRAIN.RESUME and os.path.exists(states):
@@ -107,7 +107,8 @@ def train_net(args):
                 break
             n_iter = int(config.network.TRAIN_ITER_SIZE) if config.network.TRAIN_ITER else 1
             # one optimizer step per inner iteration (module.py:1205-1213); the scheduler sees the update count
-            outs = fit_batch(mod, data_batch, updater, lr_scheduler(mod.num_update + 1))
+            # the Adam branch of the reference passes only learning_rate (train.py:339): constant rate, no scheduler
+            outs = fit_batch(mod, data_batch, updater, lr if str(config.TRAIN.optimizer).lower() == "adam" else lr_scheduler)
             assert len(outs) == n_iter
             for o in outs:
                 eval_metrics.update(None, o)

@@ -7,11 +7,13 @@ import numpy as np
 from lib.dataset.evaluation import PoseEvaluator
 from lib.render_hip.render_py_multi import Render_Py
 from lib.utils import synthetic as syn
-from lib.utils.dist_utils import shard_range
+from lib.utils.dist_utils import even_shard_range, shard_range
 
 
 class SyntheticPairs(object):
-    def __init__(self, config, num_pairs, batch_pairs, seed=2333, subdiv=4, device="cuda:0", rank=0, world=1):
+    def __init__(self, config, num_pairs, batch_pairs, seed=2333, subdiv=4, device="cuda:0", rank=0, world=1, equal_shards=False):
+        """equal_shards: every rank gets floor(n_batches / world) batches (training: one collective per optimizer step, so the
+        counts must agree); False = sizes differ by at most one (test / inference: no collective on the data path)."""
         self.config = config
         self.classes = list(config.dataset.class_name)
         self.models = syn.make_models(seed=seed, n_models=len(self.classes), subdiv=subdiv)
@@ -19,7 +21,10 @@ class SyntheticPairs(object):
         self.render_machine = Render_Py(None, self.classes, self.K, zNear=config.dataset.ZNEAR, zFar=config.dataset.ZFAR, device=device,
                                         meshes=self.models)
         self.batch_pairs, self.device, self.seed = int(batch_pairs), device, seed
-        lo, hi = shard_range(int(num_pairs) // self.batch_pairs, rank, world)  # whole batches per rank
+        n_batches = int(num_pairs) // self.batch_pairs  # whole batches only
+        lo, hi = (even_shard_range if equal_shards else shard_range)(n_batches, rank, world)
+        if equal_shards and hi == lo:
+            raise ValueError("{} batches cannot be split over {} ranks for training".format(n_batches, world))
         self.batch_ids = list(range(lo, hi))
         self.num_pairs = len(self.batch_ids) * self.batch_pairs
 

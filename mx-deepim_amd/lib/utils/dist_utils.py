@@ -20,6 +20,14 @@ def shard_range(total, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def even_shard_range(total, rank, world):
+    """contiguous slice [begin, end) with the SAME length floor(total / world) on every rank; the remainder is dropped.
+    Training needs this: each optimizer step posts a blocking all-reduce, so a rank with one batch more than its peers would wait
+    for a collective nobody else issues."""
+    per = total // world
+    return rank * per, rank * per + per
+
+
 def allreduce_sum_(flat, group=None):
     """in-place SUM over ranks of the flat gradient bucket (no-op in a single process)"""
     if is_distributed():

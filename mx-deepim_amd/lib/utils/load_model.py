@@ -1,41 +1,46 @@
-"""Checkpoint loading with the reference's function names (lib/utils/load_model.py:10-67), on numpy arrays.
+"""Checkpoint reading behind the reference's function names (lib/utils/load_model.py:10-67), on host numpy arrays.
 
-`prefix-%04d.params` files are MXNet NDArray lists with `arg:` / `aux:` key prefixes; parsed by lib/utils/mx_params.py."""
+A checkpoint is `<prefix>-<epoch:04d>.params`: an MXNet NDArray list whose keys are `arg:<name>` / `aux:<name>`
+(parsed without mxnet by lib/utils/mx_params.py).  Semantics kept from the reference:
+  load_checkpoint -> (arg_params, aux_params); keys with another prefix are dropped silently
+  load_param(process=True) strips the `_test` / `_i2r` markers from argument names (test-time renaming, :61-67)
+  convert_context  is where MXNet moves arrays to a device; the HIP executors upload when they pack, so it is a shallow copy
+"""
 from __future__ import print_function, division
 
 from lib.utils.mx_params import nd_load
 
+_RENAME_MARKERS = ("_test", "_i2r")  # applied in this order, like the reference's two passes
+
+
+def checkpoint_path(prefix, epoch):
+    return "{}-{:04d}.params".format(prefix, int(epoch))
+
 
 def load_checkpoint(prefix, epoch):
-    """-> (arg_params, aux_params): dicts of name -> numpy array  (reference :10-30)"""
-    save_dict = nd_load("%s-%04d.params" % (prefix, epoch))
-    arg_params = {}
-    aux_params = {}
-    for k, v in save_dict.items():
-        tp, name = k.split(":", 1)
-        if tp == "arg":
-            arg_params[name] = v
-        if tp == "aux":
-            aux_params[name] = v
-    return arg_params, aux_params
+    groups = {"arg": {}, "aux": {}}
+    for key, array in nd_load(checkpoint_path(prefix, epoch)).items():
+        kind, _, name = key.partition(":")
+        if kind in groups:
+            groups[kind][name] = array
+    return groups["arg"], groups["aux"]
 
 
 def convert_context(params, ctx):
-    """reference :33-42.  Arrays stay on the host until the executor packs them for the device; ctx is accepted and ignored."""
     return dict(params)
 
 
+def _strip_marker(params, marker):
+    """rename every key containing `marker` to the key without it (the renamed entry replaces a plain one of the same name)"""
+    for old in [k for k in params if marker in k]:
+        params[old.replace(marker, "")] = params.pop(old)
+
+
 def load_param(prefix, epoch, convert=False, ctx=None, process=False):
-    """wrapper for load_checkpoint (reference :45-67): `process` renames `*_test` and `*_i2r` parameters to their plain names."""
     arg_params, aux_params = load_checkpoint(prefix, epoch)
     if convert:
-        arg_params = convert_context(arg_params, ctx)
-        aux_params = convert_context(aux_params, ctx)
+        arg_params, aux_params = convert_context(arg_params, ctx), convert_context(aux_params, ctx)
     if process:
-        tests = [k for k in arg_params.keys() if "_test" in k]
-        for test in tests:
-            arg_params[test.replace("_test", "")] = arg_params.pop(test)
-        i2rs = [k for k in arg_params.keys() if "_i2r" in k]
-        for i2r in i2rs:
-            arg_params[i2r.replace("_i2r", "")] = arg_params.pop(i2r)
+        for marker in _RENAME_MARKERS:
+            _strip_marker(arg_params, marker)
     return arg_params, aux_params

@@ -8,7 +8,8 @@ import logging
 
 
 class LRScheduler(object):
-    """mxnet.lr_scheduler.LRScheduler: holds base_lr (the optimizer overwrites it with its learning_rate)."""
+    """mxnet.lr_scheduler.LRScheduler protocol: the optimizer writes its learning rate into `base_lr`, then asks
+    `scheduler(num_update)` for the rate of update number `num_update`."""
 
     def __init__(self, base_lr=0.01):
         self.base_lr = base_lr
@@ -17,39 +18,45 @@ class LRScheduler(object):
         raise NotImplementedError("must override this")
 
 
+def _check_milestones(step, factor):
+    assert isinstance(step, list) and len(step) >= 1
+    if any(s < 1 for s in step):
+        raise ValueError("Schedule step must be greater or equal than 1 round")
+    if any(b <= a for a, b in zip(step, step[1:])):
+        raise ValueError("Schedule step must be an increasing integer list")
+    if factor > 1.0:
+        raise ValueError("Factor must be no more than 1 to make lr reduce")
+
+
 class WarmupMultiFactorScheduler(LRScheduler):
-    """base_lr * factor^(number of entries of `step` that num_update has passed); warmup_lr for the first warmup_step updates."""
+    """Piecewise-constant decay: every milestone in `step` that the update counter has gone PAST (num_update > milestone)
+    multiplies `base_lr` by `factor`, once.  While `warmup` and num_update < warmup_step the answer is `warmup_lr` and no
+    milestone is consumed.  State the callers of the reference read is kept under the same names: `step`, `factor`,
+    `cur_step_ind` (milestones consumed so far), `count` (the last consumed milestone), `base_lr` (current rate)."""
 
     def __init__(self, step, factor=1, warmup=False, warmup_lr=0, warmup_step=0):
         super(WarmupMultiFactorScheduler, self).__init__()
-        assert isinstance(step, list) and len(step) >= 1
-        for i, _step in enumerate(step):
-            if i != 0 and step[i] <= step[i - 1]:
-                raise ValueError("Schedule step must be an increasing integer list")
-            if _step < 1:
-                raise ValueError("Schedule step must be greater or equal than 1 round")
-        if factor > 1.0:
-            raise ValueError("Factor must be no more than 1 to make lr reduce")
-        self.step = step
+        _check_milestones(step, factor)
+        self.step, self.factor = step, factor
+        self.warmup, self.warmup_lr, self.warmup_step = warmup, warmup_lr, warmup_step
         self.cur_step_ind = 0
-        self.factor = factor
         self.count = 0
-        self.warmup = warmup
-        self.warmup_lr = warmup_lr
-        self.warmup_step = warmup_step
+
+    def _pending(self, num_update):
+        """milestones not yet consumed that num_update has passed -- usually 0 or 1; several when a run resumes far ahead"""
+        n = 0
+        while self.cur_step_ind + n < len(self.step) and num_update > self.step[self.cur_step_ind + n]:
+            n += 1
+        return n
 
     def __call__(self, num_update):
-        # `while`, not `if`: a resumed run may jump over several steps at once (reference :57)
         if self.warmup and num_update < self.warmup_step:
             return self.warmup_lr
-        while self.cur_step_ind <= len(self.step) - 1:
-            if num_update > self.step[self.cur_step_ind]:
-                self.count = self.step[self.cur_step_ind]
-                self.cur_step_ind += 1
-                self.base_lr *= self.factor
-                logging.info("Update[%d]: Change learning rate to %0.5e", num_update, self.base_lr)
-            else:
-                return self.base_lr
+        for _ in range(self._pending(num_update)):
+            self.count = self.step[self.cur_step_ind]
+            self.cur_step_ind += 1
+            self.base_lr *= self.factor
+            logging.info("Update[%d]: Change learning rate to %0.5e", num_update, self.base_lr)
         return self.base_lr
 
 

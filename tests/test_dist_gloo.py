@@ -67,3 +67,37 @@ def test_shard_range_partitions_pairs():
                 assert 0 <= b <= e <= total and (e - b) in (total // world, total // world + 1)
                 cover += list(range(b, e))
             assert cover == list(range(total))
+
+
+def _uneven_worker(rank, world, port, n_batches, out_dir):
+    import datetime
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from lib.utils.dist_utils import allreduce_sum_, even_shard_range
+
+    lo, hi = even_shard_range(n_batches, rank, world)
+    acc = torch.zeros(4, dtype=torch.float64)
+    for i in range(lo, hi):           # one blocking collective per optimizer step, like MutableModule.update
+        g = torch.full((4,), float(i), dtype=torch.float64)
+        allreduce_sum_(g)
+        acc += g
+    np.save(os.path.join(out_dir, "acc{}.npy".format(rank)), np.append(acc.numpy(), hi - lo))
+    dist.destroy_process_group()
+
+
+def test_training_shards_are_equal_when_batches_do_not_divide_world3(tmp_path):
+    """16 batches on 3 ranks: shard_range would give 6/5/5 and the rank with the extra batch would block in an all-reduce the
+    others never post; the training split gives 5/5/5 (remainder dropped) and every rank runs the same number of collectives."""
+    from lib.utils.dist_utils import even_shard_range
+
+    world, n_batches, port = 3, 16, _free_port()
+    assert sorted(shard_range(n_batches, r, world)[1] - shard_range(n_batches, r, world)[0] for r in range(world)) == [5, 5, 6]
+    spans = [even_shard_range(n_batches, r, world) for r in range(world)]
+    assert [e - b for b, e in spans] == [5, 5, 5] and spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    mp.spawn(_uneven_worker, args=(world, port, n_batches, str(tmp_path)), nprocs=world, join=True)
+    accs = [np.load(os.path.join(str(tmp_path), "acc{}.npy".format(r))) for r in range(world)]
+    for a in accs:
+        np.testing.assert_array_equal(a, accs[0])
+    assert accs[0][4] == 5 and accs[0][0] == sum(range(15))

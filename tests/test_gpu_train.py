@@ -153,7 +153,7 @@ def test_adam_two_steps_and_optimizer_state_checkpoint(setup, tmp_path):
         for t in (1, 2):
             mod.forward_backward(batch)
             g = mod.get_grads()
-            p_ref, means, var = otrain.adam_step(p_ref, g, means, var, t, 1e-4)
+            p_ref, means, var = otrain.adam_step(p_ref, g, means, var, t, 1e-4, rescale_grad=1.0 / B)  # Module.init_optimizer: 1 / batch_size
             mod.update(1e-4)
             new = mod.get_params()
             for k in p_ref:
