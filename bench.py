@@ -50,6 +50,8 @@ def parse_args():
                     "multi-rank path on a box with fewer GPUs than ranks, together with DIM_BENCH_DEVICE)")
     ap.add_argument("--no-winograd", action="store_true", help="run every encoder layer through the direct kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the (non-headline) `train` object: timed training iterations at 16 pairs per GPU")
+    ap.add_argument("--train-steps", type=int, default=5, help="timed training iterations per phase for the `train` object")
     ap.add_argument("--autotune", action="store_true", help="time tile/split-K candidates per layer first (untimed); default: fixed plan")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="bounded CPU-baseline sample (pairs refined by the oracle)")
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-layer HIP events for the roofline object")
@@ -90,6 +92,73 @@ def cpu_baseline(cfg, params, models, batch, n_pairs):
     return {"value": n_pairs / dt, "unit": "pose-refinements/sec", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": "{} pairs x {} iters, batch 1 (torch-CPU f32 convs + numpy zoom + C rasteriser), {:.1f} s".format(
                 n_pairs, int(cfg.TEST.test_iter), dt)}
+
+
+def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps):
+    """Non-headline `train` object (BASELINE configs[2] per-GPU shape): one training iteration = train-graph forward (encoder +
+    decoder + flow / mask / pose heads) + all losses + full backward + gradient all-reduce(SUM) over the ranks + SGD-momentum
+    update + weight repack, 16 pairs per GPU, on a synthetic batch resident in HBM.  Phases are timed with HIP events on the
+    launch stream; the whole iteration with a barrier + device sync on both sides, MAX over ranks."""
+    from deepim.core.module import MutableModule
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+    from lib.pair_matching.batch_updater_py_multi import batchUpdaterPyMulti
+    from lib.utils import synthetic as syn
+
+    fast = cfg.TEST.FAST_TEST
+    cfg.TRAIN.lr = 1e-4
+    sym = deepIM_flownet()
+    sym.get_symbol(cfg, is_train=True)
+    params = sym.init_weights(cfg, {}, {}, seed=0)
+    batch = syn.build_device_train_batch(rm, B, seed=5 + rank, models=models, n_classes=len(models), pixel_means=cfg.network.PIXEL_MEANS,
+                                         npts=int(cfg.train_iter.NUM_3D_SAMPLE), device=dev)
+    upd = batchUpdaterPyMulti(cfg, 480, 640, render_machine=rm)
+
+    def phase_ms(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = {"pairs_per_gpu": B, "global_pairs": B * world, "steps": steps,
+           "workload": "train graph (encoder + decoder + flow / mask / point-matching losses), backward, all-reduce(SUM) of the 57.75 M "
+                       "gradients, SGD momentum + repack; synthetic batch resident in HBM"}
+    for dtype in ("f32",):
+        mod = MutableModule(cfg, params, B, device=dev)
+        r = {"forward_ms": phase_ms(lambda: mod.forward(batch)), "backward_ms": phase_ms(lambda: mod.backward(batch)),
+             "allreduce_update_repack_ms": phase_ms(lambda: mod.update(0.0))}
+        preds = mod.forward(batch)
+        r["batch_updater_ms"] = phase_ms(lambda: upd.forward(batch, preds))
+        mod.forward_backward(batch)
+        mod.update(1e-4)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mod.forward_backward(batch)
+            mod.update(1e-4)
+        sync()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        r["iteration_ms"] = el / steps * 1e3
+        r["pair_iterations_per_s"] = B * world * steps / el
+        r["finite"] = bool(torch.isfinite(mod.flat_w).all().item())
+        res[dtype] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()}
+        del mod
+    cfg.TEST.FAST_TEST = fast
+    return res
 
 
 def main():
@@ -173,7 +242,7 @@ def main():
             net.head()
     torch.cuda.synchronize()
     per_kernel = {}
-    TILE_SYM = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 128, 2, 4"}
+    TILE_SYM = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 128, 2, 4", 5: "128, 256, 2, 4"}
     for name, evs in events.items():
         info = net.layer_info[name]
         for ev in evs:
@@ -239,6 +308,11 @@ def main():
                    "conv_plan": {k: list(v) for k, v in net.conv_plan.items()}},
         "roofline": roofline,
     }
+    if not args.no_train:
+        del refiner, pred
+        torch.cuda.empty_cache()
+        out["train"] = train_bench(cfg, models, rm, int(cfg.TRAIN.BATCH_PAIRS) if args.batch_pairs is None else B, dev, rank, world, dist,
+                                   args.train_steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, params, models, batch, args.cpu_pairs)
     if rank == 0:

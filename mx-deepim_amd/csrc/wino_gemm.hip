@@ -37,8 +37,10 @@ __device__ __forceinline__ void wcur_advance(WCur& c, const WGemmArgs& a) {
     }
   }
 }
+// BN = 256 (tile 5): every wave owns a 64 x 64 block = four accumulators (64 registers) and twice the B fragments, so it is built
+// for two waves per SIMD = ONE 8-wave workgroup per CU; V is then read once for 256 output channels instead of once per 128.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void wino_gemm_kernel(WGemmArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN == 256 ? 2 : 4, 8))) void wino_gemm_kernel(WGemmArgs a) {
   constexpr int BK = 32;
   constexpr int NT = WM * WN * 64;
   constexpr int RP = NT / 8;   // rows staged per pass (8 threads x float4 = one 32-float row)
@@ -225,10 +227,11 @@ static int wino_gemm_slots() {
   return slots;
 }
 
-// tile: 4 = 128x128 (8 waves), anything else = 64x64 (4 waves)
+// tile: 5 = 128x256 (8 waves, 64x64 per wave), 4 = 128x128 (8 waves), anything else = 64x64 (4 waves)
 int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile) {
-  if (tile != 4 || Cout % 128 != 0) tile = 3;
-  const int BM = tile == 4 ? 128 : 64, BN = BM;
+  if (tile == 5 && Cout % 256 != 0) tile = 4;
+  if ((tile != 4 && tile != 5) || Cout % 128 != 0) tile = 3;
+  const int BM = tile == 3 ? 64 : 128, BN = tile == 5 ? 256 : BM;
   DIM_REQUIRE(K % 32 == 0 && Cout % BN == 0 && T > 0, "winograd gemm: K %% 32 == 0 and Cout %% 64 == 0 required");
   const long MT = (T + BM - 1) / BM;
   const long items = MT * (Cout / BN) * P;
@@ -255,7 +258,7 @@ int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, in
   a.BN = BN;
   a.tile = tile;
   // never more workgroups than items: every range is then at least one item long and an item is shared by at most two workgroups
-  const int slots = tile == 4 ? wino_gemm_slots<128, 128, 2, 4>() : wino_gemm_slots<64, 64, 2, 2>();
+  const int slots = tile == 5 ? wino_gemm_slots<128, 256, 2, 4>() : tile == 4 ? wino_gemm_slots<128, 128, 2, 4>() : wino_gemm_slots<64, 64, 2, 2>();
   if (slots <= 0) return slots;
   a.G = items < slots ? (int)items : slots;
   const long total = items * a.nch;
@@ -267,7 +270,9 @@ int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, in
 
 int wino_gemm_run(const WGemmArgs& a, bool zeroed, hipStream_t st) {
   if (!zeroed && a.G > 1) hipLaunchKernelGGL(wino_gemm_zero_kernel, dim3(a.G - 1), dim3(256), 0, st, a);
-  if (a.tile == 4)
+  if (a.tile == 5)
+    hipLaunchKernelGGL((wino_gemm_kernel<128, 256, 2, 4>), dim3(a.G), dim3(512), 2 * 128 * 36 * sizeof(float), st, a);
+  else if (a.tile == 4)
     hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 4>), dim3(a.G), dim3(512), 2 * 128 * 36 * sizeof(float), st, a);
   else
     hipLaunchKernelGGL((wino_gemm_kernel<64, 64, 2, 2>), dim3(a.G), dim3(256), 2 * 64 * 36 * sizeof(float), st, a);

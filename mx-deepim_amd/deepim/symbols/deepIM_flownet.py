@@ -214,12 +214,12 @@ class FlowNetHip(object):
                 # GEMM rows = tiles; 128x128 workgroup tiles once there are enough of them, 64x64 for the small maps
                 m = self.wino_m[name]
                 tiles = B * (-(-h // m)) * (-(-w // m))
-                wt = (wino_tile or {}).get(name, 4 if (cout % 128 == 0 and tiles >= 1024) else 3)
+                wt = (wino_tile or {}).get(name, self._wino_tile(cout, tiles))
                 self.layer_info[name].update(self._wino_info(m, 1, wt, tiles, c, cout, B * h * w * c, B * ho * wo * cout))
                 max_ws = max(max_ws, ops.lib().dim_winograd_workspace_floats(B, h, w, c, cout, m))
             if name in self.wino5:
                 tiles = B * (-(-ho // 4)) * (-(-wo // 4))
-                wt = (wino_tile or {}).get(name, 4 if (cout % 128 == 0 and tiles >= 1024) else 3)
+                wt = (wino_tile or {}).get(name, self._wino_tile(cout, tiles))
                 self.layer_info[name].update(self._wino_info(4, 2, wt, tiles, c, cout, B * h * w * c, B * ho * wo * cout))
                 max_ws = max(max_ws, ops.lib().dim_winograd5x5s2_workspace_floats(B, h, w, c, cout))
             h, w, c = ho, wo, cout
@@ -256,6 +256,17 @@ class FlowNetHip(object):
         self.bbox_ren = torch.empty((B, 4), dtype=torch.int32, device=d)
         self.status = torch.zeros((B,), dtype=torch.int32, device=d)
         torch.cuda.synchronize(d)
+
+    @staticmethod
+    def _wino_tile(cout, tiles):
+        """workgroup tile of a layer's plane GEMMs (wino_gemm.hip): 5 = 128 rows x 256 output channels (V is streamed once per 256
+        channels instead of once per 128: conv3, conv3_1, conv4_1), 4 = 128 x 128 (conv2: Cout = 128), 3 = 64 x 64 for the small maps.
+        DIM_WINO_BN256=0 keeps the 128 x 128 tile everywhere (A/B timing)."""
+        import os
+
+        if tiles < 1024 or cout % 128:
+            return 3
+        return 5 if (cout % 256 == 0 and os.environ.get("DIM_WINO_BN256", "1") != "0") else 4
 
     @staticmethod
     def _wino_info(m, S, tile, tiles, cin, cout, x_floats, y_floats):

@@ -417,7 +417,7 @@ def test_conv3x3_winograd_vs_f64(hip_lib, shape, m):
     ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=1, padding=1), 0.1).permute(0, 2, 3, 1).numpy()
     xd = x.permute(0, 2, 3, 1).contiguous().to("cuda:0")
     wp = ops.winograd_pack_weight(w.to("cuda:0"), m=m)
-    for tile in (3, 4) if Cout % 128 == 0 else (3,):
+    for tile in ((3, 4, 5) if Cout % 256 == 0 else (3, 4)) if Cout % 128 == 0 else (3,):  # 5 = 128 x 256 workgroup tile
         y = ops.conv2d_fwd_winograd(xd, Cin, wp, b.to("cuda:0"), Cout, slope=0.1, tile=tile, m=m).cpu().numpy()
         err = np.abs(y - ref).max()
         assert err <= 1e-4 * np.abs(ref).max() + 2e-5, (tile, err)
@@ -446,7 +446,7 @@ def test_conv5x5s2_winograd_vs_f64(hip_lib, shape):
     ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=2), 0.1).permute(0, 2, 3, 1).numpy()
     xd = x.permute(0, 2, 3, 1).contiguous().to("cuda:0")
     wp = ops.winograd5x5s2_pack_weight(w.to("cuda:0"))
-    for tile in (3, 4) if Cout % 128 == 0 else (3,):
+    for tile in ((3, 4, 5) if Cout % 256 == 0 else (3, 4)) if Cout % 128 == 0 else (3,):
         y = ops.conv2d_fwd_winograd5x5s2(xd, Cin, wp, b.to("cuda:0"), Cout, slope=0.1, tile=tile).cpu().numpy()
         assert y.shape == ref.shape
         err = np.abs(y - ref).max()
