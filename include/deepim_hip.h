@@ -30,6 +30,11 @@ extern "C" {
 #define DIM_OK 0
 #define DIM_ERR_ARG (-1)
 #define DIM_ERR_LAUNCH (-2)
+/* per-sample status words (device int32, OR-ed by the kernels, never cleared by them): */
+#define DIM_STATUS_OBS_BOX_EMPTY 1 /* dim_zoom_factor: observed box empty (the reference raises) */
+#define DIM_STATUS_REN_BOX_EMPTY 2 /* dim_zoom_factor: rendered box empty */
+#define DIM_STATUS_BAD_CLASS 4     /* dim_raster_render*: class_index outside [0, n_classes): sample rendered as background */
+#define DIM_STATUS_BAD_FACE 8      /* dim_raster_render*: a z-buffer key named a face outside the mesh (pixel left black) */
 
 const char* dim_last_error(void);
 /* library / device probe: fills name (<= n bytes), returns number of compute units or <0 */
@@ -97,26 +102,28 @@ int dim_depth_to_flow(const float* depth_src, const float* depth_tgt, const floa
  * Mesh table in HBM: verts (sumV,3), uvs (sumV,2), faces (sumF,3 int32, indices local to the mesh),
  * mesh_table (C,4 int32) = {vert_off, nvert, face_off, nface}; textures = concatenated uint8 RGB images
  * (row 0 = top of texture_map.png), tex_table (C,3 int32) = {byte_off, Ht, Wt}.
- * class_index (B int32), poses (B,3,4).  workspace: dim_raster_workspace_bytes().
+ * class_index (B int32) in [0, n_classes), poses (B,3,4).  workspace: dim_raster_workspace_bytes() (z-buffer, projected vertices,
+ * covered-pixel list).  status (B int32, may be NULL): DIM_STATUS_BAD_CLASS / DIM_STATUS_BAD_FACE are OR-ed in.
  * Outputs (each may be NULL): image (B,3,H,W) = RGB - plane_means3 (the next iteration's image_rendered
  * blob), depth (B,1,H,W) metres, mask (B,1,H,W) = depth > mask_thr, bgr (B,H,W,3) as Render_Py.render
  * returns it, bbox (B,4) of the mask.   Replaces render_py_multi.py:112-147 + tester.py:563-578. */
 long dim_raster_workspace_bytes(int B, int vmax, int H, int W);
-int dim_raster_render(const float* verts, const float* uvs, const int* faces, const int* mesh_table, int vmax, int fmax,
+int dim_raster_render(const float* verts, const float* uvs, const int* faces, const int* mesh_table, int n_classes, int vmax, int fmax,
                       const unsigned char* textures, const int* tex_table, const int* class_index, const float* poses,
                       const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear, const float* plane_means3,
-                      float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox,
+                      float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox, int* status,
                       void* stream);
 /* Lit variant of dim_raster_render: Render_Py_Light_ModelNet_Multi.render
  * (lib/render_glumpy/render_py_light_modelnet_multi.py:36-77 fragment shader, :153-235 render).
  * normals: per-vertex normals in the same table as verts.  light_pos (B,3) in GL camera coordinates, light_int (B,3)
  * (device pointers).  Colour = texel/255 * ((1-ratio) + ratio*clamp(cos(normal, light-position),0,1)) * light_int,
  * clamped to [0,1] and quantised to 8 bits (round to nearest) like the GL framebuffer. */
-int dim_raster_render_lit(const float* verts, const float* normals, const float* uvs, const int* faces, const int* mesh_table, int vmax,
-                          int fmax, const unsigned char* textures, const int* tex_table, const int* class_index, const float* poses,
-                          const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear, const float* light_pos,
-                          const float* light_int, float brightness_ratio, const float* plane_means3, float mask_thr, void* workspace,
-                          float* image, float* depth, float* mask, float* bgr, int* bbox, void* stream);
+int dim_raster_render_lit(const float* verts, const float* normals, const float* uvs, const int* faces, const int* mesh_table,
+                          int n_classes, int vmax, int fmax, const unsigned char* textures, const int* tex_table, const int* class_index,
+                          const float* poses, const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear,
+                          const float* light_pos, const float* light_int, float brightness_ratio, const float* plane_means3,
+                          float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox, int* status,
+                          void* stream);
 
 /* deepim/core/tester.py:204-225 (and batch_updater_py_multi.py:233-255): light_pos[b] = 0.5*(dx,dy,dz) + (tx,-ty,-tz) of poses[b]. */
 int dim_modelnet_light_position(const float* poses, float dx, float dy, float dz, float* light_pos, int B, void* stream);

@@ -119,7 +119,7 @@ class Refiner(object):
                 extra = {"light_intensity": self.light_int[it]} if self.lit else {}
                 self.render_machine.render_batch(b["class_index"], self.poses_iter[it], image=b["image_rendered"], depth=self.depth,
                                                  mask=b["mask_rendered"], bbox=self.bbox, plane_means=net.plane_means, mask_thr=0.2,
-                                                 **extra)
+                                                 status=self.status_iter[it], **extra)
                 if box_update:
                     # data_pair.py:103-114; the rectangle's own bbox comes back with it, so ZoomMask does not scan the mask again
                     ops.box_mask(self.bbox, b["mask_observed"], bbox_of_mask=self.bbox_obs)

@@ -111,7 +111,7 @@ class Render_Py_Light_ModelNet_Multi(Render_Py):
         return out
 
     def render_batch(self, class_index, poses, light_position=None, light_intensity=None, brightness_k=0, K=None, image=None,
-                     depth=None, mask=None, bgr=None, bbox=None, plane_means=None, mask_thr=0.2):
+                     depth=None, mask=None, bgr=None, bbox=None, plane_means=None, mask_thr=0.2, status=None):
         """class_index (B,) int32, poses (B,3,4), light_position / light_intensity (B,3) f32, all cuda.
         light_position None = the loop's rule (idx 2); light_intensity None = white (1,1,1)."""
         B = poses.shape[0]
@@ -123,11 +123,13 @@ class Render_Py_Light_ModelNet_Multi(Render_Py):
         pm = host_f32(plane_means, 3) if plane_means is not None else (None, None)
         ws = self._workspace(B)
         check(lib().dim_raster_render_lit(
-            dptr(self.verts), dptr(self.normals), dptr(self.uvs), dptr(self.faces), dptr(self.mesh_table), self.vmax, self.fmax,
+            dptr(self.verts), dptr(self.normals), dptr(self.uvs), dptr(self.faces), dptr(self.mesh_table), int(self.mesh_table.shape[0]),
+            self.vmax, self.fmax,
             dptr(self.textures), dptr(self.tex_table), dptr(class_index, torch.int32), dptr(poses, torch.float32), kp, B, self.height,
             self.width, float(self.zNear), float(self.zFar), int(self.tex_bilinear), dptr(light_position, torch.float32),
             dptr(light_intensity, torch.float32), float(self.brightness_ratios[brightness_k]), pm[1], float(mask_thr), ws.data_ptr(),
-            dptr(image), dptr(depth), dptr(mask), dptr(bgr), dptr(bbox, torch.int32) if bbox is not None else None, current_stream()))
+            dptr(image), dptr(depth), dptr(mask), dptr(bgr), dptr(bbox, torch.int32) if bbox is not None else None,
+            dptr(status, torch.int32) if status is not None else None, current_stream()))
 
     def render(self, model_idx, r, t, light_position, light_intensity, brightness_k=0, r_type="quat"):
         """Reference signature (:153-235); returns host numpy (bgr uint8, depth float32) like the glReadPixels path."""

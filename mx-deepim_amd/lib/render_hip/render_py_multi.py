@@ -133,17 +133,19 @@ class Render_Py(object):
         self._workspace(B)
 
     def render_batch(self, class_index, poses, K=None, image=None, depth=None, mask=None, bgr=None, bbox=None,
-                     plane_means=None, mask_thr=0.2):
-        """class_index (B,) int32 cuda, poses (B,3,4) f32 cuda.  Any of the output tensors may be None."""
+                     plane_means=None, mask_thr=0.2, status=None):
+        """class_index (B,) int32 cuda, poses (B,3,4) f32 cuda.  Any of the output tensors may be None.
+        status: optional (B,) int32 cuda; DIM_STATUS_BAD_CLASS (4) / DIM_STATUS_BAD_FACE (8) are OR-ed in."""
         B = poses.shape[0]
         keep, kp = host_f32(self.K if K is None else K, 9)
         pm = host_f32(plane_means, 3) if plane_means is not None else (None, None)
         ws = self._workspace(B)
         check(lib().dim_raster_render(
-            dptr(self.verts), dptr(self.uvs), dptr(self.faces), dptr(self.mesh_table), self.vmax, self.fmax, dptr(self.textures),
-            dptr(self.tex_table), dptr(class_index, torch.int32), dptr(poses, torch.float32), kp, B, self.height, self.width,
-            float(self.zNear), float(self.zFar), int(self.tex_bilinear), pm[1], float(mask_thr), ws.data_ptr(), dptr(image),
-            dptr(depth), dptr(mask), dptr(bgr), dptr(bbox, torch.int32) if bbox is not None else None, current_stream()))
+            dptr(self.verts), dptr(self.uvs), dptr(self.faces), dptr(self.mesh_table), int(self.mesh_table.shape[0]), self.vmax, self.fmax,
+            dptr(self.textures), dptr(self.tex_table), dptr(class_index, torch.int32), dptr(poses, torch.float32), kp, B, self.height,
+            self.width, float(self.zNear), float(self.zFar), int(self.tex_bilinear), pm[1], float(mask_thr), ws.data_ptr(), dptr(image),
+            dptr(depth), dptr(mask), dptr(bgr), dptr(bbox, torch.int32) if bbox is not None else None,
+            dptr(status, torch.int32) if status is not None else None, current_stream()))
 
     def render(self, cls_idx, r, t, r_type="quat", K=None):
         """Reference signature (render_py_multi.py:112-147); returns host numpy like glReadPixels did."""

@@ -303,6 +303,36 @@ def test_rasteriser_offscreen_and_clipping(ops):
     assert m.sum() == 0
 
 
+def test_rasteriser_reports_a_class_index_outside_the_mesh_table(ops):
+    """class_index is data: one outside [0, n_classes) must neither read past mesh_table nor pass silently -- the sample renders as
+    background and DIM_STATUS_BAD_CLASS (4) is OR-ed into its status word; the other samples are unaffected."""
+    from lib.render_hip.render_py_multi import Render_Py
+    from lib.utils import synthetic as syn
+
+    models = syn.make_models(seed=3, n_models=2, subdiv=2)
+    rm = Render_Py(None, ["a", "b"], syn.LINEMOD_K, meshes=models)
+    cls, gt, init = syn.sample_pairs(4, 3, n_classes=2)
+    bad = cls.copy()
+    bad[1] = 7
+    out = {}
+    for tag, c in (("good", cls), ("bad", bad)):
+        depth = torch.empty((3, 1, 480, 640), device=DEV)
+        image = torch.empty((3, 3, 480, 640), device=DEV)
+        bbox = torch.empty((3, 4), dtype=torch.int32, device=DEV)
+        status = torch.tensor([0, 1, 0], dtype=torch.int32, device=DEV)  # bits already set by another kernel survive
+        rm.render_batch(cu(c, torch.int32), cu(init), image=image, depth=depth, bbox=bbox, plane_means=syn.plane_means(), status=status)
+        out[tag] = (depth.cpu().numpy(), image.cpu().numpy(), bbox.tolist(), status.tolist())
+    assert out["good"][3] == [0, 1, 0] and out["bad"][3] == [0, 1 | 4, 0]
+    assert out["bad"][0][1].sum() == 0 and out["bad"][2][1] == [640, -1, 480, -1]
+    np.testing.assert_array_equal(out["bad"][1][1], np.broadcast_to(-syn.plane_means().reshape(3, 1, 1), (3, 480, 640)))
+    for b in (0, 2):
+        np.testing.assert_array_equal(out["bad"][0][b], out["good"][0][b])
+        np.testing.assert_array_equal(out["bad"][1][b], out["good"][1][b])
+    with pytest.raises(Exception):  # negative / zero table sizes are argument errors on the host
+        ops.check(ops.lib().dim_raster_render(None, None, None, None, 0, 1, 1, None, None, None, None, None, 1, 480, 640, 0.25, 6.0, 0, None, 0.2,
+                                              None, None, None, None, None, None, None, None))
+
+
 def test_box_mask_end_exclusive(ops):
     bbox = torch.tensor([[10, 20, 30, 50], [5, 5, 7, 9]], dtype=torch.int32, device=DEV)
     m = torch.empty((2, 1, 480, 640), device=DEV)
