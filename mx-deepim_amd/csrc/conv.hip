@@ -49,6 +49,7 @@ struct ConvArgs {
   int tile_off;    // first tile of this launch (tail launch of an "auto" workload)
   int slab_row0;   // split-K slabs hold rows [slab_row0, M)
   long slab_stride;  // elements between the slabs of consecutive splits
+  int bf16;          // weights are packed bf16, products on v_mfma_f32_32x32x16_bf16 (conv_bf16_kernel)
 };
 
 template <int BM, int BN, int WM, int WN, bool CIN8>
@@ -339,6 +340,238 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- bf16 MFMA
+// The same implicit GEMM on v_mfma_f32_32x32x16_bf16 (16x the f32 matrix rate, f32 accumulate): the training mode of BASELINE
+// configs[2].  Activations stay fp32 in HBM (every other kernel of the graph reads them); a thread rounds its float4 to four bf16
+// (v_cvt_pk_bf16_f32, round to nearest even) on the way into LDS, so the LDS traffic and the fragment reads halve.  Weights are the
+// SAME packed [chunk][Cout][32] arrays converted element-wise to bf16 (dim_f32_to_bf16): a lane's B fragment of k-step s is the 16
+// contiguous bytes k = 16 s + 8 h + {0..7} of its output channel -- the operand map of the instruction -- straight from L2.
+// With the matrix pipe 16x faster every layer is bound by its operand traffic (L2 -> LDS for the gathered A tile): the loop is a
+// plain two-buffer pipeline, and occupancy (<= 64 VGPRs at the 64x32 wave tile) does the latency hiding.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
+  bf16x4 p = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  return p;
+}
+
+template <int BM, int BN, int WM, int WN, bool CIN8>
+__global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(ConvArgs a) {
+  constexpr int BK = 32;
+  constexpr int NT = WM * WN * 64;
+  constexpr int RP = NT / 8;        // rows staged per pass (8 threads x float4 = one 32-value row)
+  constexpr int LDH = BK + 8;       // row stride in bf16 elements (80 B): 16 rows x 16 B land on 16 distinct 4-bank slots (ds_read_b128)
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int A_PER_T = BM / RP;
+  static_assert((WM * WN == 4 || WM * WN == 8) && A_PER_T >= 1 && A_PER_T <= 4, "staging plan");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* sA = reinterpret_cast<__bf16*>(smem);  // [2][BM][LDH]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int id = blockIdx.x + a.tile_off;
+  if (a.xcd_chunk > 0) id = (id & 7) * a.xcd_chunk + (id >> 3);
+  const int ntiles_n = a.Cout / BN;
+  const int mtile = id / ntiles_n;
+  const int m0 = mtile * BM;
+  const int n0 = (id - mtile * ntiles_n) * BN;
+  const int split = blockIdx.z;
+  const int kc_begin = split * a.chunks_per_split;
+  const int kc_end = min(a.nchunks, kc_begin + a.chunks_per_split);
+
+  const int q = tid & 7;
+  const int srow = tid >> 3;
+  int a_hi0[A_PER_T], a_wi0[A_PER_T], a_pix[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    int m = m0 + srow + RP * i;
+    bool ok = m < a.M;
+    int mm = ok ? m : 0;
+    int wo = mm % a.Wo;
+    int t = mm / a.Wo;
+    int ho = t % a.Ho;
+    int n = t / a.Ho;
+    a_hi0[i] = ok ? ho * a.stride - a.pad_h : -(1 << 28);
+    a_wi0[i] = wo * a.stride - a.pad_w;
+    a_pix[i] = ((n * a.H + (ok ? a_hi0[i] : 0)) * a.W * a.in_cstride + (wo * a.stride - a.pad_w) * a.in_cstride + (CIN8 ? (q & 1) * 4 : q * 4)) * 4;
+  }
+  const float* xb = a.x + (long)blockIdx.y * a.bx;
+  const char* wb = reinterpret_cast<const char*>(a.w) + (long)blockIdx.y * a.bw * 2;  // bw counts elements; bf16 = 2 bytes
+  float* yb = a.y + (long)blockIdx.y * a.by;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wb), 0, a.w_bytes, 0x00020000);
+  const int wchunk_bytes = a.Cout * BK * 2;
+
+  int kh, kw, c0;
+  if (CIN8) {
+    kw = 4 * kc_begin + (q >> 1);
+    kh = 0;
+    c0 = 0;
+  } else {
+    int taps = a.KH * a.KW;
+    int cc = kc_begin / taps;
+    int tap = kc_begin - cc * taps;
+    c0 = cc << 5;
+    kh = tap / a.KW;
+    kw = tap - kh * a.KW;
+  }
+  float4 ra[A_PER_T];
+  auto load_chunk = [&](bool pf) {
+    const int tkh = CIN8 ? (int)fastdiv((unsigned)kw, a.div_kw) : kh;
+    const int tkw = CIN8 ? kw - tkh * a.KW : kw;
+    const bool pf_ok = pf && (!CIN8 || tkh < a.KH);
+    const int tap_off = ((tkh * a.W + tkw) * a.in_cstride + c0) * 4;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      bool ok = pf_ok && (unsigned)(a_hi0[i] + tkh) < (unsigned)a.H && (unsigned)(a_wi0[i] + tkw) < (unsigned)a.W;
+      ra[i] = buf_load16(rx, ok ? a_pix[i] + tap_off : -1, 0);
+    }
+    if (CIN8) {
+      kw += 4;
+    } else if (++kw == a.KW) {
+      kw = 0;
+      if (++kh == a.KH) { kh = 0; c0 += 32; }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    __bf16* dA = sA + buf * BM * LDH;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) *reinterpret_cast<bf16x4*>(dA + (srow + RP * i) * LDH + q * 4) = to_bf16x4(ra[i]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int khalf = lane >> 5;
+  const int a_off = (wm * (BM / WM) + frow) * LDH + 8 * khalf;
+  const int bf_voff = ((n0 + wn * (BN / WN) + frow) * BK + 8 * khalf) * 2;
+  bf16x8 fb[2][2][TN];  // [set][k-step][tile]
+  auto load_bfrag = [&](int set, int kc) {
+    const int bsoff = kc * wchunk_bytes;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, bf_voff + (32 * j * BK + 16 * s) * 2, bsoff, 0);
+        fb[set][s][j] = *reinterpret_cast<bf16x8*>(&v);
+      }
+  };
+
+  if (kc_begin < kc_end) {
+    load_chunk(true);
+    store_chunk(0);
+    load_bfrag(0, kc_begin);
+  }
+  __syncthreads();
+  load_chunk(kc_begin + 1 < kc_end);
+  int buf = 0;
+#pragma unroll 2
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
+    const int set = (kc - kc_begin) & 1;
+    const __bf16* cA = sA + buf * BM * LDH + a_off;
+    load_bfrag(set ^ 1, min(kc + 1, a.nchunks - 1));
+    bf16x8 fa[2][TM];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(cA + 32 * i * LDH + 16 * s);
+    // the staged registers of chunk kc+1 go to the other buffer (its readers finished before the previous barrier), then the
+    // loads of chunk kc+2 are issued: they fly over the MFMAs below and the next iteration's
+    store_chunk(buf ^ 1);
+    load_chunk(kc + 2 < kc_end);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[set][s][j], acc[i][j], 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    buf ^= 1;
+  }
+
+  // ---- epilogue: as conv_fwd_kernel (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+  const bool final = gridDim.z == 1;
+  const int ldc = final ? a.out_cstride : a.Cout;
+  const int ncol = n0 + wn * (BN / WN) + frow;
+  float bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bv[j] = (final && a.has_bias) ? a.bias[ncol + 32 * j] : 0.f;
+  const float slope = final ? a.slope : 1.0f;
+  const bool acc_out = final && a.accumulate;
+  const int mrow = m0 + wm * (BM / WM) + 4 * khalf;
+  if (!final || a.dense_out) {
+    float* out = (final ? yb + a.out_coff + (long)mrow * ldc : yb + (long)split * a.slab_stride + (long)(mrow - a.slab_row0) * ldc) + ncol;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = 32 * i + (r & 3) + 8 * (r >> 2);
+          if (mrow + dm < a.M) {
+            float v = acc[i][j][r] + bv[j];
+            v = v > 0.f ? v : v * slope;
+            if (acc_out) v += out[(long)dm * ldc + 32 * j];
+            out[(long)dm * ldc + 32 * j] = v;
+          }
+        }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow + 32 * i + (r & 3) + 8 * (r >> 2);
+        if (m < a.M) {
+          int wo = m % a.Wo;
+          int t = m / a.Wo;
+          int ho = t % a.Ho;
+          int n = t / a.Ho;
+          int oy = ho * a.osy + a.ooy + (int)(blockIdx.y >> 1) * a.boy, ox = wo * a.osx + a.oox + (int)(blockIdx.y & 1) * a.box;
+          if ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW) {
+            float* o = yb + a.out_coff + ((long)(n * a.OH + oy) * a.OW + ox) * ldc + ncol;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              float v = acc[i][j][r] + bv[j];
+              v = v > 0.f ? v : v * slope;
+              if (acc_out) v += o[32 * j];
+              o[32 * j] = v;
+            }
+          }
+        }
+      }
+  }
+}
+
+// element-wise f32 -> bf16 (round to nearest even): the packed weight arrays of the bf16 kernels, the flat gradient bucket
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    *reinterpret_cast<bf16x4*>(dst + i) = to_bf16x4(*reinterpret_cast<const float4*>(src + i));
+  } else {
+    for (long k = i; k < n; ++k) dst[k] = (__bf16)src[k];
+  }
+}
+__global__ void bf16_to_f32_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(src + i);
+    *reinterpret_cast<float4*>(dst + i) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  } else {
+    for (long k = i; k < n; ++k) dst[k] = (float)src[k];
+  }
+}
+
 // sum split-K slabs + bias + LeakyReLU.  One float4 per thread.
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ y,
                                      long MC, int Cout, int splits, float slope, int has_bias) {
@@ -575,12 +808,13 @@ __global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict_
 
 template <int BM, int BN, int WM, int WN, bool CIN8>
 static int launch_conv(const ConvArgs& a, int splits, hipStream_t st, int batch = 1, int tile_begin = 0, int tile_count = -1) {
-  constexpr size_t lds = (size_t)2 * BM * (32 + 4) * sizeof(float);  // A tiles only: the weights go global -> registers
+  // A tiles only: the weights go global -> registers.  f32: [2][BM][36] floats; bf16: [2][BM][40] halves
+  const size_t lds = a.bf16 ? (size_t)2 * BM * (32 + 8) * 2 : (size_t)2 * BM * (32 + 4) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<BM, BN, WM, WN, CIN8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * BM * (32 + 4) * sizeof(float)));
+    if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
     attr_set = true;
   }
   const int tiles = ceil_div(a.M, BM) * (a.Cout / BN);
@@ -590,7 +824,10 @@ static int launch_conv(const ConvArgs& a, int splits, hipStream_t st, int batch 
   b.xcd_chunk = (whole && xcd_mode > 0 && tiles % 8 == 0 && tiles >= xcd_mode) ? tiles / 8 : 0;
   b.tile_off = tile_begin;
   dim3 grid(tile_count < 0 ? tiles : tile_count, batch, splits);
-  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, CIN8>), grid, dim3(WM * WN * 64), lds, st, b);
+  if (a.bf16)
+    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN, CIN8>), grid, dim3(WM * WN * 64), lds, st, b);
+  else
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, CIN8>), grid, dim3(WM * WN * 64), lds, st, b);
   return check_launch("conv_fwd");
 }
 
@@ -710,6 +947,7 @@ struct ConvEx {
   int batch = 1;         // > 1: `batch` independent problems, strides below (elements)
   long bx = 0, bw = 0, by = 0;
   int boy = 0, box = 0;  // scattered output: per-problem offset increments (see ConvArgs)
+  int bf16 = 0;          // w_packed holds bf16 (dim_f32_to_bf16 of the f32 packed array): run on the bf16 matrix pipe
 };
 
 static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
@@ -746,7 +984,8 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   a.nchunks = (Cin == 8) ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
   a.div_kw = make_fastdiv((unsigned)KW);
   DIM_REQUIRE((long)a.nchunks * Cout * 32 * 4 < (1L << 31), "packed weights too large for 32-bit byte offsets");
-  a.w_bytes = (unsigned)((long)a.nchunks * Cout * 32 * 4);
+  a.bf16 = ex ? ex->bf16 : 0;
+  a.w_bytes = (unsigned)((long)a.nchunks * Cout * 32 * (a.bf16 ? 2 : 4));
   const bool auto_split = splits == 0;
   if (splits < 1) splits = 1;
   if (splits > a.nchunks) splits = a.nchunks;
@@ -814,6 +1053,46 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
 int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
                    int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile, void* stream) {
   return conv2d_fwd_impl(x, w_packed, bias, y, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, slope, splits, tile, 0, stream);
+}
+
+// ---- bf16 twins: identical arguments, `w_packed` is the bf16 image (dim_f32_to_bf16) of the f32 packed array
+int dim_f32_to_bf16(const float* src, void* dst_bf16, long n, void* stream) {
+  if (n == 0) return DIM_OK;
+  DIM_REQUIRE(src && dst_bf16 && n > 0, "null pointer");
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ceil_div((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), src,
+                     reinterpret_cast<__bf16*>(dst_bf16), n);
+  return check_launch("f32_to_bf16");
+}
+
+int dim_bf16_to_f32(const void* src_bf16, float* dst, long n, void* stream) {
+  if (n == 0) return DIM_OK;
+  DIM_REQUIRE(src_bf16 && dst && n > 0, "null pointer");
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(ceil_div((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const __bf16*>(src_bf16), dst, n);
+  return check_launch("bf16_to_f32");
+}
+
+int dim_conv2d_fwd_bf16(const float* x, const void* w_packed_bf16, const float* bias, float* y, float* workspace, int N, int H, int W,
+                        int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile, void* stream) {
+  ConvEx ex = {};
+  ex.bf16 = 1;
+  DIM_REQUIRE(splits >= 1, "the bf16 path takes an explicit split-K count (>= 1)");
+  return conv2d_fwd_impl(x, reinterpret_cast<const float*>(w_packed_bf16), bias, y, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad,
+                         slope, splits, tile, 0, stream, &ex);
+}
+
+int dim_conv2d_fwd_ex_bf16(const float* x, const void* w_packed_bf16, const float* bias, float* y, int N, int H, int W, int Cin,
+                           int in_cstride, int Cout, int KH, int KW, int stride, int pad, float slope, int tile, int out_cstride,
+                           int out_coff, int OH, int OW, int osy, int osx, int ooy, int oox, int Ho, int Wo, int pad_w, int accumulate,
+                           void* stream) {
+  ConvEx ex = {in_cstride, out_cstride, out_coff, OH, OW, osy, osx, ooy, oox};
+  ex.Ho = Ho;
+  ex.Wo = Wo;
+  ex.pad_w = pad_w;
+  ex.accumulate = accumulate;
+  ex.bf16 = 1;
+  return conv2d_fwd_impl(x, reinterpret_cast<const float*>(w_packed_bf16), bias, y, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, slope,
+                         1, tile, 0, stream, &ex);
 }
 
 int dim_conv2d_fwd_ex(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int in_cstride,
@@ -902,8 +1181,9 @@ int dim_conv2d_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cout,
 }
 
 // dx (N,H,W,dx_cstride)[..., :Cin] (+)= dgrad(dy (N,Ho,Wo,dy_cstride)[..., :Cout]).  accumulate != 0 adds to dx (skip connections).
-int dim_conv2d_dgrad(const float* dy, const float* w_dgrad_packed, float* dx, int N, int H, int W, int Cin, int dx_cstride, int Ho,
-                     int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad, int accumulate, int tile, void* stream) {
+static int conv2d_dgrad_impl(const float* dy, const float* w_dgrad_packed, float* dx, int N, int H, int W, int Cin, int dx_cstride, int Ho,
+                             int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad, int accumulate, int tile, int bf16,
+                             void* stream) {
   if (N == 0) return DIM_OK;
   DIM_REQUIRE(stride == 1 || stride == 2, "dgrad supports stride 1 or 2");
   int CinPad = (Cin + 63) / 64 * 64;
@@ -921,8 +1201,10 @@ int dim_conv2d_dgrad(const float* dy, const float* w_dgrad_packed, float* dx, in
         ex.Ho = Th;
         ex.Wo = Tw;
         ex.accumulate = accumulate;
+        ex.bf16 = bf16;
         if (total > 0) {
-          int rc = conv2d_fwd_impl(dy, w_dgrad_packed + off, nullptr, dx, nullptr, N, Ho, Wo, Cout, CinPad, ah.ntaps, aw.ntaps, 1,
+          int rc = conv2d_fwd_impl(dy, bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(w_dgrad_packed) + 2 * off)
+                                            : w_dgrad_packed + off, nullptr, dx, nullptr, N, Ho, Wo, Cout, CinPad, ah.ntaps, aw.ntaps, 1,
                                    -ah.emin, 1.0f, 1, tile, 0, stream, &ex);
           if (rc != DIM_OK) return rc;
         } else if (!accumulate) {
@@ -932,6 +1214,19 @@ int dim_conv2d_dgrad(const float* dy, const float* w_dgrad_packed, float* dx, in
       off += total;
     }
   return DIM_OK;
+}
+
+int dim_conv2d_dgrad(const float* dy, const float* w_dgrad_packed, float* dx, int N, int H, int W, int Cin, int dx_cstride, int Ho,
+                     int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad, int accumulate, int tile, void* stream) {
+  return conv2d_dgrad_impl(dy, w_dgrad_packed, dx, N, H, W, Cin, dx_cstride, Ho, Wo, Cout, dy_cstride, KH, KW, stride, pad, accumulate, tile,
+                           0, stream);
+}
+
+int dim_conv2d_dgrad_bf16(const float* dy, const void* w_dgrad_packed_bf16, float* dx, int N, int H, int W, int Cin, int dx_cstride,
+                          int Ho, int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad, int accumulate, int tile,
+                          void* stream) {
+  return conv2d_dgrad_impl(dy, reinterpret_cast<const float*>(w_dgrad_packed_bf16), dx, N, H, W, Cin, dx_cstride, Ho, Wo, Cout, dy_cstride,
+                           KH, KW, stride, pad, accumulate, tile, 1, stream);
 }
 
 int dim_conv2d_fwd_partial(const float* x, const float* w_packed, float* workspace, int N, int H, int W, int Cin, int Cout, int KH,
@@ -957,9 +1252,9 @@ int dim_deconv4x4s2_pack_weight(const float* w_iohw, float* w_packed, int Cin, i
 
 // y[:, oy, ox, out_coff : out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x, k=4, s=2, p=0) + bias, offset=(crop,crop)))   (NHWC)
 // x (N,H,W,in_cstride) with Cin valid channels, zero weights for the padding up to a multiple of 32.
-int dim_deconv4x4s2_fwd(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin,
-                        int in_cstride, int Cout, int OH, int OW, int crop, float slope, int out_cstride, int out_coff, int tile,
-                        void* stream) {
+static int deconv4x4s2_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin,
+                                int in_cstride, int Cout, int OH, int OW, int crop, float slope, int out_cstride, int out_coff, int tile,
+                                int bf16, void* stream) {
   if (N == 0) return DIM_OK;
   int CinPad = (Cin + 31) / 32 * 32;
   DIM_REQUIRE(in_cstride >= CinPad, "in_cstride (%d) must cover the padded channel count %d (pad channels must hold zeros)", in_cstride,
@@ -973,7 +1268,22 @@ int dim_deconv4x4s2_fwd(const float* x, const float* w_packed, const float* bias
   ex.bw = per_phase;
   ex.boy = 1;
   ex.box = 1;
+  ex.bf16 = bf16;
   return conv2d_fwd_impl(x, w_packed, bias, y, nullptr, N, H, W, CinPad, Cout, 2, 2, 1, 1, slope, 1, tile, 0, stream, &ex);
+}
+
+int dim_deconv4x4s2_fwd(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin,
+                        int in_cstride, int Cout, int OH, int OW, int crop, float slope, int out_cstride, int out_coff, int tile,
+                        void* stream) {
+  return deconv4x4s2_fwd_impl(x, w_packed, bias, y, N, H, W, Cin, in_cstride, Cout, OH, OW, crop, slope, out_cstride, out_coff, tile, 0,
+                              stream);
+}
+
+int dim_deconv4x4s2_fwd_bf16(const float* x, const void* w_packed_bf16, const float* bias, float* y, int N, int H, int W, int Cin,
+                             int in_cstride, int Cout, int OH, int OW, int crop, float slope, int out_cstride, int out_coff, int tile,
+                             void* stream) {
+  return deconv4x4s2_fwd_impl(x, reinterpret_cast<const float*>(w_packed_bf16), bias, y, N, H, W, Cin, in_cstride, Cout, OH, OW, crop,
+                              slope, out_cstride, out_coff, tile, 1, stream);
 }
 
 int dim_conv_small_cout_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream) {

@@ -62,7 +62,6 @@ class Refiner(object):
         self.se3_iter = torch.zeros((self.test_iter, B, 7), dtype=torch.float32, device=d)
         self.bbox = torch.zeros((B, 4), dtype=torch.int32, device=d)
         self.bbox_obs = torch.zeros((B, 4), dtype=torch.int32, device=d)
-        self.depth = torch.zeros((B, 1, H, W), dtype=torch.float32, device=d)
         self.status_iter = torch.zeros((self.test_iter, B), dtype=torch.int32, device=d)
         # per-iteration head outputs of the full (not FAST_TEST) graph, read by the reference at tester.py:485-491
         self.with_heads = bool(self.net.has_decoder and not cfg.TEST.FAST_TEST)
@@ -117,7 +116,9 @@ class Refiner(object):
             if it < self.test_iter - 1:
                 # render(render_machine, pose_rendered_update, cls_idx) + update_data_batch  (:563-590)
                 extra = {"light_intensity": self.light_int[it]} if self.lit else {}
-                self.render_machine.render_batch(b["class_index"], self.poses_iter[it], image=b["image_rendered"], depth=self.depth,
+                # (the loop needs the depth only for mask_rendered = depth > 0.2, tester.py:575-577: the resolve pass writes the mask itself
+                # and the depth plane is not materialised -- 1.2 MB per pair and render less to write)
+                self.render_machine.render_batch(b["class_index"], self.poses_iter[it], image=b["image_rendered"],
                                                  mask=b["mask_rendered"], bbox=self.bbox, plane_means=net.plane_means, mask_thr=0.2,
                                                  status=self.status_iter[it], **extra)
                 if box_update:
