@@ -133,8 +133,10 @@ def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps):
     res = {"pairs_per_gpu": B, "global_pairs": B * world, "steps": steps,
            "workload": "train graph (encoder + decoder + flow / mask / point-matching losses), backward, all-reduce(SUM) of the 57.75 M "
                        "gradients, SGD momentum + repack; synthetic batch resident in HBM"}
-    for dtype in ("f32",):
-        mod = MutableModule(cfg, params, B, device=dev)
+    # f32 = the reference's precision; bf16 = BASELINE configs[2]: convolutions on the bf16 matrix pipe (f32 accumulate, f32 master
+    # weights / momentum / losses / SE(3)), gradient bucket all-reduced as bf16 -- declared tolerance: tests/test_gpu_train_bf16.py
+    for dtype in ("f32", "bf16"):
+        mod = MutableModule(cfg, params, B, device=dev, compute_dtype=dtype)
         r = {"forward_ms": phase_ms(lambda: mod.forward(batch)), "backward_ms": phase_ms(lambda: mod.backward(batch)),
              "allreduce_update_repack_ms": phase_ms(lambda: mod.update(0.0))}
         preds = mod.forward(batch)

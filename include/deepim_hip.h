@@ -242,6 +242,31 @@ long dim_conv2d_wgrad_workspace_floats(int Cout, int Cin, int KH, int KW, int sp
 int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* workspace, int N, int H, int W, int Cin, int in_cstride,
                      int Ho, int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits,
                      int accumulate, void* stream);
+/* ---------------------------------------------------------------- bf16 matrix pipe (training mode, BASELINE configs[2])
+ * The reference trains in fp32 (deepim/train.py:338-414); these twins of the convolution entry points run the same implicit GEMMs
+ * on v_mfma_f32_32x32x16_bf16 (f32 accumulate, 16x the f32 matrix rate): activations and gradients stay fp32 in HBM and are rounded
+ * to bf16 (nearest even) on the way into LDS; `w_packed_bf16` is the bf16 image -- dim_f32_to_bf16, element by element -- of the
+ * SAME packed array the f32 entry point takes (dim_conv2d_pack_weight, dim_conv2d_dgrad_pack_weight, dim_deconv4x4s2_pack_weight,
+ * dim_conv2d_pack_weight_padded), so every packer is shared.  Arguments otherwise as the f32 functions (dim_conv2d_fwd_bf16:
+ * splits >= 1, no "auto" mode).  dim_conv2d_wgrad_bf16 returns an fp32 gradient in the packed layout, like dim_conv2d_wgrad.
+ * Declared tolerance vs the fp32 path: 2^-8 relative per product, i.e. ~4e-3 L2-relative on a layer output / gradient tensor. */
+int dim_f32_to_bf16(const float* src, void* dst_bf16, long n, void* stream);
+int dim_bf16_to_f32(const void* src_bf16, float* dst, long n, void* stream);
+int dim_conv2d_fwd_bf16(const float* x, const void* w_packed_bf16, const float* bias, float* y, float* workspace, int N, int H, int W,
+                        int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile, void* stream);
+int dim_conv2d_fwd_ex_bf16(const float* x, const void* w_packed_bf16, const float* bias, float* y, int N, int H, int W, int Cin,
+                           int in_cstride, int Cout, int KH, int KW, int stride, int pad, float slope, int tile, int out_cstride,
+                           int out_coff, int OH, int OW, int osy, int osx, int ooy, int oox, int Ho, int Wo, int pad_w, int accumulate,
+                           void* stream);
+int dim_conv2d_dgrad_bf16(const float* dy, const void* w_dgrad_packed_bf16, float* dx, int N, int H, int W, int Cin, int dx_cstride,
+                          int Ho, int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad, int accumulate, int tile,
+                          void* stream);
+int dim_deconv4x4s2_fwd_bf16(const float* x, const void* w_packed_bf16, const float* bias, float* y, int N, int H, int W, int Cin,
+                             int in_cstride, int Cout, int OH, int OW, int crop, float slope, int out_cstride, int out_coff, int tile,
+                             void* stream);
+int dim_conv2d_wgrad_bf16(const float* x, const float* dz, float* dw_packed, float* workspace, int N, int H, int W, int Cin, int in_cstride,
+                          int Ho, int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits,
+                          int accumulate, void* stream);
 /* db[c] (+)= sum_m dz[m][dz_coff + c]   (workspace: dim_bias_grad_workspace_floats) */
 long dim_bias_grad_workspace_floats(int M, int C);
 int dim_bias_grad(const float* dz, float* db, float* workspace, int M, int C, int dz_cstride, int dz_coff, int accumulate, void* stream);

@@ -16,6 +16,7 @@
 // Epilogue: bias + LeakyReLU fused; with gridDim.z > 1 (split-K) raw partials go to a slab
 // and dim_splitk_reduce finishes (deterministic, no atomics).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(ConvArgs a) {
   const int a_off = (wm * (BM / WM) + frow) * LDH + 8 * khalf;
   const int bf_voff = ((n0 + wn * (BN / WN) + frow) * BK + 8 * khalf) * 2;
   bf16x8 fb[2][2][TN];  // [set][k-step][tile]
-  auto load_bfrag = [&](int set, int kc) {
+  auto load_bfrag = [&](const int set, int kc) {  // always called with a literal / constexpr set: inlined, indices fold
     const int bsoff = kc * wchunk_bytes;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -476,9 +477,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(ConvArgs a) {
   __syncthreads();
   load_chunk(kc_begin + 1 < kc_end);
   int buf = 0;
-#pragma unroll 2
-  for (int kc = kc_begin; kc < kc_end; ++kc) {
-    const int set = (kc - kc_begin) & 1;
+  // two chunks per trip so that the B-fragment set (a register array) is indexed by a compile-time constant
+  auto chunk_body = [&](auto SET, int kc) {
+    constexpr int set = decltype(SET)::value;
     const __bf16* cA = sA + buf * BM * LDH + a_off;
     load_bfrag(set ^ 1, min(kc + 1, a.nchunks - 1));
     bf16x8 fa[2][TM];
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(cA + 32 * i * LDH + 16 * s);
     // the staged registers of chunk kc+1 go to the other buffer (its readers finished before the previous barrier), then the
-    // loads of chunk kc+2 are issued: they fly over the MFMAs below and the next iteration's
+    // loads of chunk kc+2 are issued: they fly over the MFMAs below and the next chunk's
     store_chunk(buf ^ 1);
     load_chunk(kc + 2 < kc_end);
 #pragma unroll
@@ -498,6 +499,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(ConvArgs a) {
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[set][s][j], acc[i][j], 0, 0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     buf ^= 1;
+  };
+  for (int kc = kc_begin; kc < kc_end; kc += 2) {
+    chunk_body(std::integral_constant<int, 0>{}, kc);
+    if (kc + 1 < kc_end) chunk_body(std::integral_constant<int, 1>{}, kc + 1);
   }
 
   // ---- epilogue: as conv_fwd_kernel (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))

@@ -30,6 +30,7 @@ struct WgradArgs {
   // Winograd planes (dim_conv2d_wgrad_winograd): the K chunks [p * chunks_per_plane, (p + 1) * chunks_per_plane) belong to plane p,
   // whose dZ operand sits dz_plane_stride channels further in the row (0 / 0: plain convolution)
   int chunks_per_plane, dz_plane_stride;
+  int bf16;  // products on v_mfma_f32_32x32x16_bf16 (conv_wgrad_bf16_kernel); the result is f32 in the same packed layout
 };
 
 template <int NW, bool CIN8, int NCH>
@@ -178,6 +179,161 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- bf16 MFMA
+// The same contraction on v_mfma_f32_32x32x16_bf16 (training mode of BASELINE configs[2]; f32 accumulate, f32 result).
+// Both operands are needed with the CONTRACTION index (pixels) running inside a lane -- A[co][8 consecutive pixels], B[8 consecutive
+// pixels][kin] -- while memory is channel-contiguous.  The tiles are therefore staged in their natural [pixel][channel] layout
+// (float4 -> 4 bf16 -> ds_write_b64) and read back through the transposing LDS read ds_read_b64_tr_b16: a 16-lane group fetches a
+// 4-pixel x 16-channel block and every lane receives one channel's four pixels.  Row strides of 192 / 320 bytes put the four rows of
+// a block on disjoint bank quarters.  One workgroup = 32 NW output channels x NCH chunks (up to 128 packed columns) sharing one dZ
+// tile: with the matrix pipe 16x faster the kernel is bound by L2 -> LDS operand traffic, which is what the wide tile cuts.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ wbf16x4 wg_to_bf16x4(const float4& v) {
+  wbf16x4 p = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  return p;
+}
+
+template <int NW, bool CIN8, int NCH>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
+  constexpr int BP = 32;              // pixels per step = two k-steps of the instruction
+  constexpr int BM = 32 * NW;         // output channels per workgroup
+  constexpr int LDZ = BM + 32;        // bf16 elements per [pixel] row of the dZ tile: 192 B (NW = 2) / 320 B (NW = 4)
+  constexpr int LDX = 32 * NCH + 32;  // ... of the X tile: 128 / 192 / 320 B for NCH = 1 / 2 / 4
+  constexpr int NT = 64 * NW;
+  constexpr int ZQ = BM / 4;          // float4 per dZ row
+  constexpr int ZR_STEP = NT / ZQ;    // = 8
+  constexpr int XP = (BP * 8) / NT;   // pixel rows per thread: 1 (NW = 4) or 2 (NW = 2)
+  constexpr int XR_STEP = NT / 8;
+  static_assert(BP * ZQ / NT == 4 && (XP == 1 || XP == 2) && (NCH == 1 || NCH == 2 || NCH == 4), "staging plan");
+  __shared__ __attribute__((aligned(16))) __bf16 sZ[2][BP * LDZ];
+  __shared__ __attribute__((aligned(16))) __bf16 sX[2][BP * LDX];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kc0 = blockIdx.x * NCH;
+  const int co0 = blockIdx.y * BM;
+  const int split = blockIdx.z;
+  const int step_begin = split * a.steps_per_split;
+  const int step_end = min(a.nsteps, step_begin + a.steps_per_split);
+
+  const int zq = tid % ZQ, zr0 = tid / ZQ;
+  const int xq = tid & 7, xr0 = tid >> 3;
+  int kh[NCH], kw[NCH], tapb[NCH];
+  bool cok[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int kc = kc0 + c;
+    int c0;
+    if (CIN8) {
+      const int t = 4 * kc + (xq >> 1);  // this THREAD's flat tap of the chunk (4 taps x 8 channels)
+      kh[c] = t / a.KW; kw[c] = t - kh[c] * a.KW; c0 = 0;
+      cok[c] = kc < a.nchunks && kh[c] < a.KH;
+    } else {
+      const int taps = a.KH * a.KW;
+      const int cc = kc / taps, tap = kc - cc * taps;
+      c0 = cc << 5; kh[c] = tap / a.KW; kw[c] = tap - kh[c] * a.KW;
+      cok[c] = kc < a.nchunks;
+    }
+    tapb[c] = ((kh[c] * a.W + kw[c]) * a.in_cstride + c0) * 4;
+  }
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz), 0, a.dz_bytes, 0x00020000);
+  const int z_voff = (a.dz_coff + co0 + zq * 4) * 4;
+
+  float4 rz[4], rx[XP][NCH];
+  auto load_step = [&](int st, bool pf) {
+    const int p0 = st * BP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = p0 + zr0 + ZR_STEP * i;
+      rz[i] = buf_load16(rsz, (pf && m < a.M) ? m * (a.dz_cstride * 4) + z_voff : -1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int m = p0 + xr0 + XR_STEP * i;
+      const bool okm = pf && m < a.M;
+      const unsigned mm = okm ? m : 0;
+      const unsigned t = fastdiv(mm, a.div_wo), n = fastdiv(t, a.div_ho);
+      const int wo = mm - t * a.Wo, ho = t - n * a.Ho;
+      const int hb = ho * a.stride - a.pad, wb = wo * a.stride - a.pad;
+      const int pix = (((int)n * a.H + hb) * a.W + wb) * (a.in_cstride * 4) + (CIN8 ? (xq & 1) : xq) * 16;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const bool ok = okm && cok[c] && (unsigned)(hb + kh[c]) < (unsigned)a.H && (unsigned)(wb + kw[c]) < (unsigned)a.W;
+        rx[i][c] = buf_load16(rsx, ok ? pix + tapb[c] : -1, 0);
+      }
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<wbf16x4*>(&sZ[buf][(zr0 + ZR_STEP * i) * LDZ + zq * 4]) = wg_to_bf16x4(rz[i]);
+#pragma unroll
+    for (int i = 0; i < XP; ++i)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        *reinterpret_cast<wbf16x4*>(&sX[buf][(xr0 + XR_STEP * i) * LDX + c * 32 + xq * 4]) = wg_to_bf16x4(rx[i][c]);
+  };
+
+  f32x16 acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  // transposing-read addresses: lane 4q+p of 16-lane group g points at pixel row 8 (g >> 1) + q, channels 16 (g & 1) + 4p .. +3 of
+  // the block; it receives channel 16 (g & 1) + (lane & 15) for the four pixels 8 (g >> 1) + {0..3} (+4 for the second read)
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  const int z_el = (8 * (g >> 1) + tq) * LDZ + wave * 32 + 16 * (g & 1) + 4 * tp;
+  const int x_el = (8 * (g >> 1) + tq) * LDX + 16 * (g & 1) + 4 * tp;
+  typedef ws16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+  if (step_begin < step_end) {
+    load_step(step_begin, true);
+    store_step(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int st = step_begin; st < step_end; ++st) {
+    load_step(min(st + 1, a.nsteps - 1), st + 1 < step_end);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      union { ws16x4 h[2]; wbf16x8 v; } fa;
+      const __bf16* pz = &sZ[buf][z_el + 16 * ks * LDZ];
+      fa.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pz));
+      fa.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pz + 4 * LDZ));
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        union { ws16x4 h[2]; wbf16x8 v; } fb;
+        const __bf16* px = &sX[buf][x_el + 16 * ks * LDX + 32 * c];
+        fb.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(px));
+        fb.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(px + 4 * LDX));
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[c], 0, 0, 0);
+      }
+    }
+    store_step(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // D: col = lane&31 -> kin, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co within the wave's 32
+  const int fi = lane & 31, fh = lane >> 5;
+  const bool add = gridDim.z == 1 && a.accumulate;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (kc0 + c >= a.nchunks) break;
+    float* out = (gridDim.z == 1 ? a.dw : a.dw + (long)split * a.nchunks * a.Cout * 32) +
+                 ((long)(kc0 + c) * a.Cout + co0 + wave * 32 + 4 * fh) * 32 + fi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* o = out + (long)((r & 3) + 8 * (r >> 2)) * 32;
+      float v = acc[c][r];
+      if (add) v += *o;
+      *o = v;
+    }
+  }
+}
+
 // column sums: db[c] = sum_m dz[m][coff + c]; grid (C/64, nsplit) -> partial[nsplit][C]; then a tiny reduce
 // thread = 4 adjacent channels (one 16-byte load per row); workgroup = 64 channels x 16 row lanes, 4 rows in flight per lane
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dz, int M, int C, int cstride, int coff,
@@ -293,6 +449,30 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   return wgrad_launch(a, dw_packed, workspace, splits, accumulate, stream);
 }
 
+int dim_conv2d_wgrad_bf16(const float* x, const float* dz, float* dw_packed, float* workspace, int N, int H, int W, int Cin, int in_cstride,
+                          int Ho, int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits,
+                          int accumulate, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(x && dz && dw_packed, "null pointer");
+  DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
+  DIM_REQUIRE(Cout % 64 == 0, "Cout must be a multiple of 64 (got %d)", Cout);
+  DIM_REQUIRE((long)N * H * W * in_cstride < (1L << 29) && (long)N * Ho * Wo * dz_cstride < (1L << 29),
+              "tensor too large for 32-bit byte offsets");
+  DIM_REQUIRE(dz_cstride % 4 == 0 && dz_coff % 4 == 0 && in_cstride % 4 == 0, "channel strides / offsets must be multiples of 4");
+  WgradArgs a = {};
+  a.x = x; a.dz = dz;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_cstride = in_cstride; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+  a.dz_cstride = dz_cstride; a.dz_coff = dz_coff; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.M = N * Ho * Wo;
+  a.x_bytes = (unsigned)((long)N * H * W * in_cstride * 4);
+  a.dz_bytes = (unsigned)((long)N * Ho * Wo * dz_cstride * 4);
+  a.div_wo = make_fastdiv((unsigned)Wo);
+  a.div_ho = make_fastdiv((unsigned)Ho);
+  a.nchunks = (Cin == 8) ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
+  a.bf16 = 1;
+  return wgrad_launch(a, dw_packed, workspace, splits, accumulate, stream);
+}
+
 }  // extern "C"
 
 namespace dim {
@@ -309,6 +489,23 @@ int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, i
   a.accumulate = accumulate;
   hipStream_t st = as_stream(stream);
   const bool nw4 = Cout % 128 == 0;
+  if (a.bf16) {
+    const int nch = a.nchunks >= 4 ? 4 : a.nchunks >= 2 ? 2 : 1;  // chunks (x 32 packed columns) per workgroup sharing one dZ tile
+    dim3 gridb(ceil_div(a.nchunks, nch), Cout / (nw4 ? 128 : 64), splits);
+#define DIM_WGB_LAUNCH(NW, C8, NCH) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<NW, C8, NCH>), gridb, dim3(64 * NW), 0, st, a)
+#define DIM_WGB_NCH(NW, C8) { if (nch == 4) DIM_WGB_LAUNCH(NW, C8, 4); else if (nch == 2) DIM_WGB_LAUNCH(NW, C8, 2); else DIM_WGB_LAUNCH(NW, C8, 1); }
+    if (Cin == 8) { if (nw4) DIM_WGB_NCH(4, true) else DIM_WGB_NCH(2, true) }
+    else { if (nw4) DIM_WGB_NCH(4, false) else DIM_WGB_NCH(2, false) }
+#undef DIM_WGB_NCH
+#undef DIM_WGB_LAUNCH
+    int rcb = check_launch("conv_wgrad_bf16");
+    if (rcb != DIM_OK) return rcb;
+    if (splits > 1) {
+      DIM_REQUIRE(!accumulate, "accumulate with splits > 1 is not supported");
+      return dim_splitk_reduce(workspace, nullptr, dw_packed, (long)a.nchunks * Cout * 32 / 4, 4, splits, 1.0f, stream);
+    }
+    return DIM_OK;
+  }
   const bool two = a.nchunks >= 2;  // two K chunks (64 packed columns) per workgroup share one dZ tile
   dim3 grid(two ? (a.nchunks + 1) / 2 : a.nchunks, Cout / (nw4 ? 128 : 64), splits);
 #define DIM_WG_LAUNCH(NW, C8, NCH) hipLaunchKernelGGL((conv_wgrad_kernel<NW, C8, NCH>), grid, dim3(64 * NW), 0, st, a)

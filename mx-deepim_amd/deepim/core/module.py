@@ -27,8 +27,15 @@ FROZEN = ("upsampling_weight", "mask_upsampling_weight")  # attr lr_mult 0.0 (de
 
 
 class MutableModule(object):
-    def __init__(self, config, arg_params, batch_size, device="cuda:0", process_group=None):
+    def __init__(self, config, arg_params, batch_size, device="cuda:0", process_group=None, compute_dtype="f32"):
+        """compute_dtype "f32": the reference's precision (deepim/train.py:338-414 trains in fp32).
+        "bf16": BASELINE configs[2] -- every convolution / large deconvolution forward, input gradient and weight gradient on the bf16
+        matrix pipe with f32 accumulation; master weights, momentum, gradients, losses, SE(3) and every small kernel stay fp32; the
+        gradient bucket crosses the ranks as bf16 (115.5 MB instead of 231 MB).  New functionality with a declared tolerance against
+        the fp32 path (tests/test_gpu_bf16.py, tests/test_gpu_train_bf16.py)."""
         cfg = config
+        assert compute_dtype in ("f32", "bf16"), compute_dtype
+        self.bf16 = compute_dtype == "bf16"
         if not (cfg.network.PRED_FLOW and cfg.network.PRED_MASK and cfg.train_iter.SE3_PM_LOSS and not cfg.train_iter.SE3_DIST_LOSS):
             raise NotImplementedError("the HIP training graph covers the shipped configuration: PRED_FLOW, PRED_MASK, SE3_PM_LOSS (L1)")
         if cfg.train_iter.SE3_PM_LOSS_TYPE != "L1":
@@ -52,6 +59,8 @@ class MutableModule(object):
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=d)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=d)
         self.flat_v = None  # second Adam state, allocated on first use
+        self.flat_g16 = None  # bf16 image of the gradient bucket (bf16 mode, more than one rank)
+        self.force_bf16_bucket = False  # tests: round the bucket through bf16 in a single process too
         self.w, self.g, self.m = {}, {}, {}
         self.n_weight = sum(sz for n, sz in zip(self.names, sizes) if n not in FROZEN and n.endswith("_weight"))
         self.n_bias = sum(sz for n, sz in zip(self.names, sizes) if n not in FROZEN and not n.endswith("_weight"))
@@ -71,7 +80,8 @@ class MutableModule(object):
     # ------------------------------------------------------------------------------------------------------------
     def _init_forward(self, cfg, B):
         net = self.net
-        FlowNetHip.__init__(net, cfg, {n: self.w[n].cpu().numpy() for n in self.names}, B, device=str(self.device), winograd=True)
+        FlowNetHip.__init__(net, cfg, {n: self.w[n].cpu().numpy() for n in self.names}, B, device=str(self.device), winograd=True,
+                            bf16=self.bf16)
         net.params = self.w  # the executor reads biases / small weights straight from the master vector
         d = self.device
         H, W = 480, 640
@@ -110,6 +120,9 @@ class MutableModule(object):
             blocks = nchunks * (cout // 128 if cout % 128 == 0 else cout // 64)
             nsteps = -(-B * ho * wo // 32)
             sp = max(1, min(-(-4096 // blocks), max(1, nsteps // 4)))
+            if self.bf16:  # a workgroup covers four K chunks (128 packed columns); ~2048 workgroups, each at least 4 pixel steps long
+                blocks = -(-nchunks // 4) * (cout // 128 if cout % 128 == 0 else cout // 64)
+                sp = max(1, min(-(-2048 // blocks), max(1, nsteps // 4)))
             self.wgrad_splits[name] = sp
             max_ws = max(max_ws, ops.lib().dim_conv2d_wgrad_workspace_floats(cout, c, k, k, sp))
             max_pack = max(max_pack, ops.lib().dim_conv2d_packed_weight_floats(cout, c, k, k))
@@ -139,7 +152,7 @@ class MutableModule(object):
         # Winograd weight gradients (3x3 / stride-1 and 5x5 / stride-2 layers whose maps are large enough: at 8x10 the 36 plane
         # products are 3 pixel steps long and their 151 MB of dM cost more than the direct kernel saves): {layer: (S, pixel splits)}
         self.wino_wgrad = {}
-        if os.environ.get("DIM_WINO_WGRAD", "1") != "0":
+        if os.environ.get("DIM_WINO_WGRAD", "1") != "0" and not self.bf16:
             need, h, w, c = 4, 480, 640, 8
             for name, cout, k, s, p in ENCODER:
                 ho, wo = ops.conv_out_hw(h, w, k, k, s, p)
@@ -156,8 +169,10 @@ class MutableModule(object):
 
     # ------------------------------------------------------------------------------------------------------------
     def repack(self, forward=True):
-        """master (MXNet layout) -> the kernels' packed copies: forward layouts (FlowNetHip.packed) and dgrad layouts"""
+        """master (MXNet layout) -> the kernels' packed copies: forward layouts (FlowNetHip.packed) and dgrad layouts
+        (bf16 mode: bf16 images of the same packed arrays)"""
         net, w = self.net, self.w
+        cvt = ops.to_bf16 if self.bf16 else (lambda t: t)
         for name, cout, k, s, p in ENCODER:
             if forward:
                 if name in net.wino:   # 3x3 / stride-1 layers run their forward through Winograd: re-transform the weights
@@ -165,23 +180,23 @@ class MutableModule(object):
                 elif name in net.wino5:  # 5x5 / stride-2 layers: phase-image Winograd forward (backward: wino5_dgrad below)
                     net.wino5[name] = ops.winograd5x5s2_pack_weight(w[name + "_weight"])
                 else:
-                    net.packed[name] = ops.conv2d_pack_weight(w[name + "_weight"])
+                    net.packed[name] = net.pack_conv(w[name + "_weight"])
             if name in net.wino:
                 self.wino_dgrad[name] = ops.winograd_pack_weight(w[name + "_weight"].flip(2, 3).transpose(0, 1).contiguous(), m=net.wino_m[name])
             elif name in net.wino5:  # 5x5 / stride-2 layers: input gradient through Winograd too (four phase images of dX)
                 self.wino5_dgrad[name] = ops.winograd5x5s2_dgrad_pack_weight(w[name + "_weight"])
             elif name != "flow_conv1":
-                self.dgrad_packed[name] = ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p)
+                self.dgrad_packed[name] = cvt(ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p))
         if forward:
             net.packed["fc6"] = ops.fc_pack_weight(w["fc6_weight"], 1024, 8, 10)
-            net.packed["deconv5"] = ops.deconv4x4s2_pack_weight(w["deconv5_weight"])
-            net.packed["deconv4"] = ops.deconv4x4s2_pack_weight(w["deconv4_weight"])
+            net.packed["deconv5"] = net.pack_deconv(w["deconv5_weight"])
+            net.packed["deconv4"] = net.pack_deconv(w["deconv4_weight"])
             for n in ("Convolution1", "Convolution2", "Convolution3", "mask_conv3"):
                 net.packed[n] = ops.conv_small_cout_pack_weight(w[n + "_weight"])
-        self.dgrad_packed["fc6"] = ops.fc_dgrad_pack_weight(w["fc6_weight"], 1024, 8, 10)
+        self.dgrad_packed["fc6"] = cvt(ops.fc_dgrad_pack_weight(w["fc6_weight"], 1024, 8, 10))
         # deconv dgrad = a plain stride-2 convolution of the output gradient with the deconv weight read as (O=Cin, I=Cout, 4, 4)
-        self.dgrad_packed["deconv5"] = ops.conv2d_pack_weight_padded(w["deconv5_weight"], 1024)
-        self.dgrad_packed["deconv4"] = ops.conv2d_pack_weight_padded(w["deconv4_weight"], ops.pad64(1026))
+        self.dgrad_packed["deconv5"] = cvt(ops.conv2d_pack_weight_padded(w["deconv5_weight"], 1024))
+        self.dgrad_packed["deconv4"] = cvt(ops.conv2d_pack_weight_padded(w["deconv4_weight"], ops.pad64(1026)))
 
     # ------------------------------------------------------------------------------------------------------------
     def forward(self, batch):
@@ -259,7 +274,7 @@ class MutableModule(object):
         ops.fc_wgrad(d_t, net.fc7, g["trans_weight"], g["trans_bias"])
         ops.fc_wgrad(self.dz7, fc6a, g["fc7_weight"], g["fc7_bias"])
         dz6 = self.dz6.view(B, 1, 1, 256)
-        ops.conv2d_wgrad(net.acts["conv6_1"], 1024, dz6, 256, 8, 10, 1, 0, self.gpack)
+        ops.conv2d_wgrad(net.acts["conv6_1"], 1024, dz6, 256, 8, 10, 1, 0, self.gpack, bf16_mfma=self.bf16)
         ops.fc_unpack_weight(self.gpack, g["fc6_weight"], 1024, 8, 10)
         torch.sum(self.dz6, dim=0, out=g["fc6_bias"])
         # d(ReLU10) += dz6 * W6  (fc6 dgrad as a 1x1 convolution to 81920 "channels" = the NHWC feature map)
@@ -283,7 +298,8 @@ class MutableModule(object):
                 S, sp = self.wino_wgrad[name]
                 ops.conv2d_wgrad_winograd(x, cin[name], dy, cout, g[name + "_weight"], S=S, splits=sp, workspace=self.wino_wgrad_ws)
             else:
-                ops.conv2d_wgrad(x, cin[name], dy, cout, k, k, s, p, self.gpack, splits=self.wgrad_splits[name], workspace=self.ws)
+                ops.conv2d_wgrad(x, cin[name], dy, cout, k, k, s, p, self.gpack, splits=self.wgrad_splits[name], workspace=self.ws,
+                                 bf16_mfma=self.bf16)
                 ops.conv2d_unpack_weight(self.gpack, g[name + "_weight"])
             ops.bias_grad(dy, cout, g[name + "_bias"], workspace=self.bias_ws)
             if prev[name]:
@@ -307,7 +323,7 @@ class MutableModule(object):
         g, w = self.g, self.w
         N, h, wd, _ = x.shape
         # weight gradient through the convolution view: conv'(input = dz, k4, s2, pad 1) with "output gradient" = x
-        ops.conv2d_wgrad_ex(dz, dz_coff, cout, x, 0, x_cpad, 4, 4, 2, 1, self.gpack)
+        ops.conv2d_wgrad_ex(dz, dz_coff, cout, x, 0, x_cpad, 4, 4, 2, 1, self.gpack, bf16_mfma=self.bf16)
         ops.conv2d_unpack_weight(self.gpack, g[name + "_weight"], CoutPad=x_cpad)
         ops.bias_grad(dz, cout, g[name + "_bias"], dz_coff=dz_coff, workspace=self.bias_ws)
         # data gradient: the same convolution applied to dz
@@ -324,7 +340,15 @@ class MutableModule(object):
         every rank.  Two launches: weights (weight decay) and biases (MXNet sets wd_mult 0 for *_bias); frozen tensors are skipped.
         `lr` is this update's learning rate (a WarmupMultiFactorScheduler value)."""
         cfg = self.cfg
-        allreduce_sum_(self.flat_g, group=self.pg)
+        if self.bf16 and (self.world_size() > 1 or self.force_bf16_bucket):
+            # the bucket crosses xGMI as bf16 (115.5 MB instead of 231 MB); summed by RCCL in bf16, widened again for the f32 update
+            if self.flat_g16 is None:
+                self.flat_g16 = torch.empty(self.flat_g.shape, dtype=torch.bfloat16, device=self.device)
+            ops.to_bf16(self.flat_g, out=self.flat_g16)
+            allreduce_sum_(self.flat_g16, group=self.pg)
+            ops.from_bf16(self.flat_g16, out=self.flat_g)
+        else:
+            allreduce_sum_(self.flat_g, group=self.pg)
         self.num_update += 1
         nw, nb = self.n_weight, self.n_bias
         seg = ((0, nw, True), (nw, nw + nb, False))

@@ -162,11 +162,19 @@ class FlowNetHip(object):
 
     H, W = 480, 640
 
-    def __init__(self, cfg, arg_params, batch_size, device="cuda:0", conv_plan=None, winograd=True, wino_m=None, wino_tile=None):
+    def __init__(self, cfg, arg_params, batch_size, device="cuda:0", conv_plan=None, winograd=True, wino_m=None, wino_tile=None,
+                 bf16=False):
         """winograd: run the 3x3 / stride-1 layers (conv3_1, conv4_1, conv5_1, conv6_1) through Winograd F(4x4,3x3) / F(2x2,3x3)
         (same f32 result within 1e-4 relative, 4x / 2.25x fewer multiply-adds) and the 5x5 / stride-2 layers (conv2, conv3) through
         their four phase images and F(4x4,3x3) (2.78x fewer).  False = direct kernel for every layer.
-        wino_m / wino_tile: optional {layer: output tile edge 2|4} / {layer: GEMM workgroup tile 3|4} overrides."""
+        wino_m / wino_tile: optional {layer: output tile edge 2|4} / {layer: GEMM workgroup tile 3|4} overrides.
+        bf16: the convolutions and the two large deconvolutions run on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, f32 accumulate;
+        activations stay fp32 in HBM, weights are kept as bf16 copies of the packed arrays).  Direct form for every layer -- with the
+        matrix pipe 16x faster the Winograd transforms would cost more than they save.  Training mode of BASELINE configs[2]; the
+        inference headline stays fp32."""
+        self.bf16 = bool(bf16)
+        if self.bf16:
+            winograd = False
         self.cfg = cfg
         self.B = batch_size
         self.device = torch.device(device)
@@ -177,7 +185,7 @@ class FlowNetHip(object):
         self.params = {k: torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float32).to(d) for k, v in arg_params.items()}
         self.packed = {}
         for name, cout, k, s, p in ENCODER:
-            self.packed[name] = ops.conv2d_pack_weight(self.params[name + "_weight"])
+            self.packed[name] = self.pack_conv(self.params[name + "_weight"])
         self.packed["fc6"] = ops.fc_pack_weight(self.params["fc6_weight"], 1024, 8, 10)
         self.wino, self.wino_m, self.wino5 = {}, {}, {}
         if winograd:
@@ -192,6 +200,15 @@ class FlowNetHip(object):
         self.plane_means = np.asarray(cfg.network.PIXEL_MEANS, dtype=np.float32).reshape(3)[::-1].copy()
         # tile / split-K plan per layer: (tile, splits); 0 = library heuristic
         self.conv_plan = {"fc6": (3, 40)}
+        if self.bf16:
+            # operand-traffic bound: 128 x 128 tiles (8 waves) wherever Cout allows, no split-K except on the 8 x 10 / 15 x 20 maps
+            c = 8
+            h, w = self.H, self.W
+            for name, cout, k, s, p in ENCODER:
+                h, w = ops.conv_out_hw(h, w, k, k, s, p)
+                tiles = -(-batch_size * h * w // 128) * (cout // 128) if cout % 128 == 0 else 0
+                self.conv_plan[name] = (4 if (cout % 128 == 0 and c != 8) else 3, 1 if (tiles == 0 or tiles >= 256) else min(4, -(-512 // tiles)))
+                c = cout
         if conv_plan:
             self.conv_plan.update(conv_plan)
         B, H, W = batch_size, self.H, self.W
@@ -233,8 +250,8 @@ class FlowNetHip(object):
         # ---- decoder + flow / mask heads (only in the graph when not FAST_TEST, reference :840-954)
         self.has_decoder = "deconv5_weight" in self.params
         if self.has_decoder:
-            self.packed["deconv5"] = ops.deconv4x4s2_pack_weight(self.params["deconv5_weight"])
-            self.packed["deconv4"] = ops.deconv4x4s2_pack_weight(self.params["deconv4_weight"])
+            self.packed["deconv5"] = self.pack_deconv(self.params["deconv5_weight"])
+            self.packed["deconv4"] = self.pack_deconv(self.params["deconv4_weight"])
             for n in ("Convolution1", "Convolution2", "Convolution3", "mask_conv3"):
                 if n + "_weight" in self.params:
                     self.packed[n] = ops.conv_small_cout_pack_weight(self.params[n + "_weight"])
@@ -256,6 +273,15 @@ class FlowNetHip(object):
         self.bbox_ren = torch.empty((B, 4), dtype=torch.int32, device=d)
         self.status = torch.zeros((B,), dtype=torch.int32, device=d)
         torch.cuda.synchronize(d)
+
+    def pack_conv(self, w_oihw):
+        """MXNet (Cout,Cin,kh,kw) -> the forward kernel's packed array (bf16 copy in bf16 mode)"""
+        wp = ops.conv2d_pack_weight(w_oihw)
+        return ops.to_bf16(wp) if self.bf16 else wp
+
+    def pack_deconv(self, w_iohw):
+        wp = ops.deconv4x4s2_pack_weight(w_iohw)
+        return ops.to_bf16(wp) if self.bf16 else wp
 
     @staticmethod
     def _wino_tile(cout, tiles):

@@ -11,6 +11,28 @@ from .capi import check, current_stream, dptr, host_f32, lib
 
 f32 = torch.float32
 i32 = torch.int32
+bf16 = torch.bfloat16
+
+
+def to_bf16(src, out=None):
+    """element-wise f32 -> bf16 (round to nearest even) as a kernel launch: the packed weight arrays of the bf16 convolution
+    entry points, the flat gradient bucket"""
+    out = out if out is not None else torch.empty(src.shape, dtype=bf16, device=src.device)
+    check(lib().dim_f32_to_bf16(dptr(src, f32), dptr(out, bf16), src.numel(), current_stream()))
+    return out
+
+
+def from_bf16(src, out=None):
+    out = out if out is not None else torch.empty(src.shape, dtype=f32, device=src.device)
+    check(lib().dim_bf16_to_f32(dptr(src, bf16), dptr(out, f32), src.numel(), current_stream()))
+    return out
+
+
+def _wp(w):
+    """(device pointer, is_bf16) of a packed weight array: bf16 arrays select the bf16 matrix-pipe twin of the entry point"""
+    if w.dtype == bf16:
+        return dptr(w, bf16), True
+    return dptr(w, f32), False
 
 
 def _new(shape, like, dtype=f32):
@@ -341,8 +363,10 @@ def conv2d_fwd(x_nhwc, w_packed, bias, Cout, KH, KW, stride, pad, slope=0.1, spl
                 n_launch = 2 if ts.value >= 2 else 1
             events.append(("conv", e0, ev(), n_launch))
         return out
-    check(lib().dim_conv2d_fwd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), dptr(workspace, f32), N, H, W,
-                               Cin, Cout, KH, KW, stride, pad, float(slope), splits, tile, current_stream()))
+    wp, is16 = _wp(w_packed)
+    fn = lib().dim_conv2d_fwd_bf16 if is16 else lib().dim_conv2d_fwd
+    check(fn(dptr(x_nhwc, f32), wp, dptr(bias, f32), dptr(out, f32), dptr(workspace, f32), N, H, W,
+             Cin, Cout, KH, KW, stride, pad, float(slope), splits, tile, current_stream()))
     return out
 
 
@@ -372,8 +396,10 @@ def deconv4x4s2_fwd(x_nhwc, Cin, w_packed, bias, y_nhwc, Cout, crop, slope, out_
     """y[..., out_coff:out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x[..., :Cin]) + bias)); y's H,W define the crop window."""
     N, H, W, in_cs = x_nhwc.shape
     _, OH, OW, out_cs = y_nhwc.shape
-    check(lib().dim_deconv4x4s2_fwd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(y_nhwc, f32), N, H, W, Cin, in_cs, Cout,
-                                    OH, OW, crop, float(slope), out_cs, out_coff, tile, current_stream()))
+    wp, is16 = _wp(w_packed)
+    fn = lib().dim_deconv4x4s2_fwd_bf16 if is16 else lib().dim_deconv4x4s2_fwd
+    check(fn(dptr(x_nhwc, f32), wp, dptr(bias, f32), dptr(y_nhwc, f32), N, H, W, Cin, in_cs, Cout,
+             OH, OW, crop, float(slope), out_cs, out_coff, tile, current_stream()))
     return y_nhwc
 
 
@@ -424,17 +450,21 @@ def conv2d_dgrad(dy_nhwc, Cout, w_dgrad_packed, dx_nhwc, Cin, KH, KW, stride, pa
     """dx[..., :Cin] (+)= dgrad(dy[..., :Cout]); dx / dy may be wider concat buffers."""
     N, Ho, Wo, dy_cs = dy_nhwc.shape
     _, H, W, dx_cs = dx_nhwc.shape
-    check(lib().dim_conv2d_dgrad(dptr(dy_nhwc, f32), dptr(w_dgrad_packed, f32), dptr(dx_nhwc, f32), N, H, W, Cin, dx_cs, Ho, Wo, Cout, dy_cs,
-                                 KH, KW, stride, pad, int(accumulate), tile, current_stream()))
+    wp, is16 = _wp(w_dgrad_packed)
+    fn = lib().dim_conv2d_dgrad_bf16 if is16 else lib().dim_conv2d_dgrad
+    check(fn(dptr(dy_nhwc, f32), wp, dptr(dx_nhwc, f32), N, H, W, Cin, dx_cs, Ho, Wo, Cout, dy_cs,
+             KH, KW, stride, pad, int(accumulate), tile, current_stream()))
     return dx_nhwc
 
 
-def conv2d_wgrad(x_nhwc, Cin, dz_nhwc, Cout, KH, KW, stride, pad, dw_packed, splits=1, dz_coff=0, workspace=None, accumulate=False):
+def conv2d_wgrad(x_nhwc, Cin, dz_nhwc, Cout, KH, KW, stride, pad, dw_packed, splits=1, dz_coff=0, workspace=None, accumulate=False,
+                 bf16_mfma=False):
+    """bf16_mfma: products on the bf16 matrix pipe (operands rounded on the way into LDS; f32 accumulate, f32 result)"""
     N, H, W, in_cs = x_nhwc.shape
     _, Ho, Wo, dz_cs = dz_nhwc.shape
     if splits > 1 and workspace is None:
         workspace = _new((lib().dim_conv2d_wgrad_workspace_floats(Cout, Cin, KH, KW, splits),), x_nhwc)
-    check(lib().dim_conv2d_wgrad(dptr(x_nhwc, f32), dptr(dz_nhwc, f32), dptr(dw_packed, f32), dptr(workspace, f32), N, H, W, Cin, in_cs, Ho,
+    check((lib().dim_conv2d_wgrad_bf16 if bf16_mfma else lib().dim_conv2d_wgrad)(dptr(x_nhwc, f32), dptr(dz_nhwc, f32), dptr(dw_packed, f32), dptr(workspace, f32), N, H, W, Cin, in_cs, Ho,
                                  Wo, Cout, dz_cs, dz_coff, KH, KW, stride, pad, splits, int(accumulate), current_stream()))
     return dw_packed
 
@@ -491,17 +521,19 @@ def conv2d_fwd_ex(x, x_coff, Cin, w_packed, bias, y, y_coff, Cout, KH, KW, strid
     """dense generalised conv: channel windows [x_coff, x_coff+Cin) of x and [y_coff, y_coff+Cout) of y (NHWC concat buffers)."""
     N, H, W, in_cs = x.shape
     out_cs = y.shape[-1]
-    check(lib().dim_conv2d_fwd_ex(_p(x, x_coff), dptr(w_packed, f32), dptr(bias, f32), dptr(y, f32), N, H, W, Cin, in_cs, Cout, KH, KW, stride,
-                                  pad, float(slope), tile, out_cs, y_coff, 0, 0, 0, 0, 0, 0, Ho, Wo, -1, int(accumulate), current_stream()))
+    wp, is16 = _wp(w_packed)
+    fn = lib().dim_conv2d_fwd_ex_bf16 if is16 else lib().dim_conv2d_fwd_ex
+    check(fn(_p(x, x_coff), wp, dptr(bias, f32), dptr(y, f32), N, H, W, Cin, in_cs, Cout, KH, KW, stride,
+             pad, float(slope), tile, out_cs, y_coff, 0, 0, 0, 0, 0, 0, Ho, Wo, -1, int(accumulate), current_stream()))
     return y
 
 
-def conv2d_wgrad_ex(x, x_coff, Cin, dz, dz_coff, Cout, KH, KW, stride, pad, dw_packed, splits=1, workspace=None):
+def conv2d_wgrad_ex(x, x_coff, Cin, dz, dz_coff, Cout, KH, KW, stride, pad, dw_packed, splits=1, workspace=None, bf16_mfma=False):
     N, H, W, in_cs = x.shape
     _, Ho, Wo, dz_cs = dz.shape
     if splits > 1 and workspace is None:
         workspace = _new((lib().dim_conv2d_wgrad_workspace_floats(Cout, Cin, KH, KW, splits),), x)
-    check(lib().dim_conv2d_wgrad(_p(x, x_coff), dptr(dz, f32), dptr(dw_packed, f32), dptr(workspace, f32), N, H, W, Cin, in_cs, Ho, Wo, Cout,
+    check((lib().dim_conv2d_wgrad_bf16 if bf16_mfma else lib().dim_conv2d_wgrad)(_p(x, x_coff), dptr(dz, f32), dptr(dw_packed, f32), dptr(workspace, f32), N, H, W, Cin, in_cs, Ho, Wo, Cout,
                                  dz_cs, dz_coff, KH, KW, stride, pad, splits, 0, current_stream()))
     return dw_packed
 

@@ -1,0 +1,175 @@
+"""bf16 matrix-pipe twins of the convolution kernels (training mode of BASELINE configs[2]; the reference trains in fp32, so this is new
+functionality with a DECLARED tolerance).
+
+Two bars per kernel:
+  exact   -- vs torch-CPU float64 on operands rounded to bf16 first: bf16 x bf16 products are exact in f32, so the kernel must agree to
+             f32 accumulation error (1e-4 relative): this pins indexing, operand maps and the rounding mode (nearest even);
+  declared -- vs the unrounded float64 result: per-tensor L2-relative error <= 6e-3 (2^-8 per operand, two operands, random signs).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+L2_BAR = 6e-3
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    assert torch.cuda.is_available()
+    from lib.hip import ops as _ops
+
+    return _ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def r16(t):
+    """round to bf16 (nearest even) and back to float64"""
+    return t.float().bfloat16().double()
+
+
+def l2rel(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+
+
+def test_f32_bf16_round_trip(ops):
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(100003, generator=g) * 3).to(DEV)
+    h = ops.to_bf16(x)
+    assert h.dtype == torch.bfloat16 and torch.equal(h, x.bfloat16())
+    assert torch.equal(ops.from_bf16(h), x.bfloat16().float())
+
+
+FWD_CASES = [
+    # N, H, W, Cin, Cout, k, s, p, tile, splits
+    (2, 60, 80, 8, 64, 7, 2, 3, 3, 1),
+    (1, 37, 53, 8, 64, 7, 2, 3, 2, 1),
+    (2, 30, 40, 64, 128, 5, 2, 2, 4, 1),
+    (1, 23, 31, 64, 128, 5, 2, 2, 3, 1),
+    (2, 15, 20, 256, 256, 3, 1, 1, 4, 1),
+    (2, 15, 20, 256, 512, 3, 2, 1, 1, 1),
+    (2, 15, 20, 512, 512, 3, 1, 1, 3, 3),
+    (2, 8, 10, 512, 1024, 3, 2, 1, 4, 4),
+    (1, 9, 11, 32, 64, 3, 1, 0, 2, 1),
+]
+
+
+@pytest.mark.parametrize("case", FWD_CASES)
+def test_conv_fwd_bf16(ops, case):
+    N, H, W, Cin, Cout, k, s, p, tile, splits = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn((Cout,), generator=g) * 0.1
+    ref_exact = F.leaky_relu(F.conv2d(r16(x), r16(w), b.double(), stride=s, padding=p), 0.1).permute(0, 2, 3, 1).numpy()
+    ref_full = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p), 0.1).permute(0, 2, 3, 1).numpy()
+    wp = ops.to_bf16(ops.conv2d_pack_weight(w.to(DEV)))
+    y = ops.conv2d_fwd(nhwc(x), wp, b.to(DEV), Cout, k, k, s, p, slope=0.1, splits=splits, tile=tile).cpu().numpy()
+    assert np.abs(y - ref_exact).max() <= 1e-4 * np.abs(ref_exact).max() + 2e-5
+    assert l2rel(y, ref_full) <= L2_BAR
+
+
+BWD_CASES = [
+    # N, H, W, Cin, Cout, k, s, p, wgrad splits
+    (2, 15, 20, 64, 64, 3, 1, 1, 1),
+    (2, 15, 20, 64, 128, 3, 2, 1, 2),
+    (1, 30, 40, 64, 128, 5, 2, 2, 3),
+    (2, 9, 11, 128, 64, 3, 2, 1, 1),
+    (1, 17, 23, 64, 128, 5, 2, 2, 1),
+    (2, 8, 10, 256, 512, 3, 1, 1, 1),
+    (3, 13, 9, 32, 64, 3, 1, 1, 2),    # one chunk column group only partly filled (9 chunks, 4 per workgroup)
+]
+
+
+@pytest.mark.parametrize("case", BWD_CASES)
+def test_dgrad_wgrad_bf16(ops, case):
+    N, H, W, Cin, Cout, k, s, p, splits = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((N, Cin, H, W), generator=g, dtype=torch.float64)
+    w = torch.randn((Cout, Cin, k, k), generator=g, dtype=torch.float64) / np.sqrt(Cin * k * k)
+    xr, wr = r16(x).requires_grad_(), r16(w).requires_grad_()
+    y = F.conv2d(xr, wr, None, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(r16(dy))                      # exact bar: every operand of every product is a bf16 value
+    xf, wf = x.clone().requires_grad_(), w.clone().requires_grad_()
+    F.conv2d(xf, wf, None, stride=s, padding=p).backward(dy)   # declared bar: the unrounded gradients
+    wd = ops.to_bf16(ops.conv2d_dgrad_pack_weight(w.float().to(DEV), s, p))
+    dx = torch.empty((N, H, W, ops.pad64(Cin)), device=DEV)
+    ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dx, Cin, k, k, s, p, accumulate=False)
+    got = dx[..., :Cin].permute(0, 3, 1, 2).cpu().double().numpy()
+    assert np.abs(got - xr.grad.numpy()).max() <= 1e-4 * xr.grad.abs().max().item() + 1e-5
+    assert l2rel(got, xf.grad.numpy()) <= L2_BAR
+    dwp = torch.zeros_like(ops.conv2d_pack_weight(w.float().to(DEV)))
+    ops.conv2d_wgrad(nhwc(x.float()), Cin, nhwc(dy.float()), Cout, k, k, s, p, dwp, splits=splits, bf16_mfma=True)
+    ref = ops.conv2d_pack_weight(wr.grad.float().to(DEV))
+    assert (dwp - ref).abs().max().item() <= 1e-4 * wr.grad.abs().max().item() + 1e-5
+    assert l2rel(dwp.cpu().numpy(), ops.conv2d_pack_weight(wf.grad.float().to(DEV)).cpu().numpy()) <= L2_BAR
+
+
+def test_wgrad_bf16_first_layer_cin8_and_fc6(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 8, 33, 41), generator=g, dtype=torch.float64)
+    w = torch.randn((64, 8, 7, 7), generator=g, dtype=torch.float64)
+    xr, wr = r16(x), r16(w).requires_grad_()
+    y = F.conv2d(xr, wr, None, stride=2, padding=3)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(r16(dy))
+    dwp = torch.zeros_like(ops.conv2d_pack_weight(w.float().to(DEV)))
+    ops.conv2d_wgrad(nhwc(x.float()), 8, nhwc(dy.float()), 64, 7, 7, 2, 3, dwp, splits=4, bf16_mfma=True)
+    ref = ops.conv2d_pack_weight(wr.grad.float().to(DEV))
+    assert (dwp - ref).abs().max().item() <= 1e-4 * wr.grad.abs().max().item() + 1e-5
+    B = 3
+    feat = torch.randn((B, 1024, 8, 10), generator=g, dtype=torch.float64)
+    w6 = torch.randn((256, 81920), generator=g, dtype=torch.float64, requires_grad=True)
+    out = F.linear(r16(feat).reshape(B, -1), w6)
+    dz = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(r16(dz))
+    dwp6 = torch.zeros(256 * 81920, device=DEV)
+    ops.conv2d_wgrad(nhwc(feat.float()), 1024, dz.float().reshape(B, 1, 1, 256).to(DEV), 256, 8, 10, 1, 0, dwp6, bf16_mfma=True)
+    ref6 = ops.fc_pack_weight(w6.grad.float().to(DEV), 1024, 8, 10)
+    assert (dwp6 - ref6).abs().max().item() <= 1e-4 * w6.grad.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 8, 10, 64, 15, 20), (1, 70, 15, 20, 128, 30, 40)])
+def test_deconv4x4s2_bf16_forward_and_backward(ops, shape):
+    N, Cin, H, W, Cout, OH, OW = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn((N, Cin, H, W), generator=g, dtype=torch.float64)
+    w = torch.randn((Cin, Cout, 4, 4), generator=g, dtype=torch.float64) / np.sqrt(Cin * 4)
+    b = torch.randn((Cout,), generator=g, dtype=torch.float64)
+    xr, wr = r16(x).requires_grad_(), r16(w).requires_grad_()
+    pre = F.conv_transpose2d(xr, wr, b, stride=2)[:, :, 1:1 + OH, 1:1 + OW]
+    ref = F.leaky_relu(pre, 0.1)
+    cs = ops.pad32(Cin)
+    xin = torch.zeros((N, H, W, cs), device=DEV)
+    xin[..., :Cin] = nhwc(x.float())
+    y = torch.full((N, OH, OW, Cout + 40), -7.0, device=DEV)
+    ops.deconv4x4s2_fwd(xin, Cin, ops.to_bf16(ops.deconv4x4s2_pack_weight(w.float().to(DEV))), b.float().to(DEV), y, Cout, crop=1, slope=0.1,
+                        out_coff=8)
+    got = y[..., 8:8 + Cout].permute(0, 3, 1, 2).cpu().double()
+    assert (got - ref.detach()).abs().max().item() <= 1e-4 * ref.abs().max().item() + 2e-5
+    assert (y[..., :8] == -7).all() and (y[..., 8 + Cout:] == -7).all()
+    # backward through the convolution view (decoder): dgrad = stride-2 conv of dz with the weight read as (O = Cin, I = Cout)
+    dz = torch.randn(pre.shape, generator=g, dtype=torch.float64)
+    pre.backward(r16(dz))
+    cpad = ops.pad64(Cin)
+    dzb = torch.zeros((N, OH, OW, Cout + 64), device=DEV)
+    dzb[..., 32:32 + Cout] = nhwc(dz.float())
+    dx = torch.empty((N, H, W, cpad), device=DEV)
+    wd = ops.to_bf16(ops.conv2d_pack_weight_padded(w.float().to(DEV), cpad))
+    ops.conv2d_fwd_ex(dzb, 32, Cout, wd, None, dx, 0, cpad, 4, 4, 2, 1, Ho=H, Wo=W)
+    gotx = dx[..., :Cin].permute(0, 3, 1, 2).cpu().double()
+    assert (gotx - xr.grad).abs().max().item() <= 1e-4 * xr.grad.abs().max().item() + 1e-6
+    xin2 = torch.zeros((N, H, W, cpad), device=DEV)
+    xin2[..., :Cin] = nhwc(x.float())
+    gp = torch.empty(16 * Cout * cpad, device=DEV)
+    ops.conv2d_wgrad_ex(dzb, 32, Cout, xin2, 0, cpad, 4, 4, 2, 1, gp, bf16_mfma=True)
+    dw = torch.empty((Cin, Cout, 4, 4), device=DEV)
+    ops.conv2d_unpack_weight(gp, dw, CoutPad=cpad)
+    assert (dw.cpu().double() - wr.grad).abs().max().item() <= 1e-4 * wr.grad.abs().max().item() + 1e-6

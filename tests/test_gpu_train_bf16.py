@@ -1,0 +1,109 @@
+"""bf16 training mode (BASELINE configs[2]: "bf16") of the training executor against the fp32 executor on the same batch.
+
+The reference trains in fp32 only (deepim/train.py:338-414), so there is no reference behaviour to match: the bar is DECLARED here.
+Every convolution / large deconvolution (forward, input gradient, weight gradient) rounds its two operands to bf16 (2^-9 relative
+each, nearest even) and accumulates in f32; 10 encoder layers deep that compounds to ~1e-2 on activations and gradients, plus the
+LeakyReLU' flips of pre-activations that sit within that noise of zero.
+
+  outputs    rot_est_norm, trans_est            |bf16 - f32| <= 2e-2
+             flow_est_crop, mask_logit          L2-relative  <= 5e-2
+  gradients  every learnable tensor             L2-relative  <= 1e-1, median over the tensors <= 4e-2
+  update     one SGD step from the bf16 gradients moves every tensor within 15 % (L2) of the fp32 step
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from scene import make_train_config, make_train_scene  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def l2rel(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+
+
+def test_bf16_training_step_vs_fp32(hip_lib):
+    from deepim.core.module import MutableModule
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+
+    cfg = make_train_config()
+    sym = deepIM_flownet()
+    sym.get_symbol(cfg, is_train=True)
+    params = sym.init_weights(cfg, {}, {}, seed=0)
+    rng = np.random.RandomState(1)
+    params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
+    params["rot_weight"][1:] = (rng.randn(3, 256) * 0.01).astype(np.float32)
+    params["mask_conv3_weight"] = (rng.randn(1, 770, 3, 3) * 0.02).astype(np.float32)
+    B = 2
+    scene = make_train_scene(B=B, seed=99, subdiv=3)
+    batch = {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in scene["blobs"].items()}
+    m32 = MutableModule(cfg, params, B)
+    m16 = MutableModule(cfg, params, B, compute_dtype="bf16")
+    assert m16.net.bf16 and not m16.net.wino and m16.net.packed["conv3"].dtype == torch.bfloat16
+    o32 = {k: v.clone() for k, v in m32.forward_backward(batch).items()}
+    o16 = {k: v.clone() for k, v in m16.forward_backward(batch).items()}
+    for k in ("rot_est_norm", "trans_est"):
+        d = (o16[k] - o32[k]).abs().max().item()
+        print("{:16s} max |bf16 - f32| = {:.2e}".format(k, d))
+        assert d <= 2e-2, (k, d)
+    for k in ("flow_est_crop", "mask_logit"):
+        e = l2rel(o16[k].cpu().numpy(), o32[k].cpu().numpy())
+        print("{:16s} L2-relative    = {:.2e}".format(k, e))
+        assert e <= 5e-2, (k, e)
+    g32, g16 = m32.get_grads(), m16.get_grads()
+    errs = {}
+    for k, a in g32.items():
+        if np.abs(a).max() == 0:
+            continue
+        errs[k] = l2rel(g16[k], a)
+        print("grad {:28s} L2-relative = {:.2e}".format(k, errs[k]))
+    assert all(np.isfinite(v) for v in errs.values())
+    assert max(errs.values()) <= 1e-1, max(errs.items(), key=lambda kv: kv[1])
+    assert float(np.median(list(errs.values()))) <= 4e-2
+    # one SGD step each
+    before = m32.get_params()
+    m32.update(cfg.TRAIN.lr)
+    m16.force_bf16_bucket = True   # round the gradient bucket through bf16 as the multi-rank path does
+    m16.update(cfg.TRAIN.lr)
+    p32, p16 = m32.get_params(), m16.get_params()
+    for k in before:
+        step = p32[k] - before[k]
+        if np.abs(step).max() == 0:
+            np.testing.assert_array_equal(p16[k], before[k])   # frozen tensors
+            continue
+        assert l2rel(p16[k] - before[k], step) <= 0.15, k
+    # the refreshed bf16 copies are what a fresh bf16 executor would build from the updated master weights
+    o_next = m16.forward(batch)["rot_est_norm"].clone()
+    fresh = MutableModule(cfg, p16, B, compute_dtype="bf16")
+    np.testing.assert_array_equal(fresh.forward(batch)["rot_est_norm"].cpu().numpy(), o_next.cpu().numpy())
+
+
+def test_bf16_training_batch16_runs_and_stays_finite(hip_lib):
+    """BASELINE configs[2] per-GPU size: 16 pairs, four chained optimizer steps in bf16 mode; the loss sums stay finite and the
+    parameters move (throughput of this configuration: bench.py `train.bf16`)."""
+    from deepim.core.module import MutableModule, fit_batch
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+    from lib.pair_matching.batch_updater_py_multi import batchUpdaterPyMulti
+    from lib.render_hip.render_py_multi import Render_Py
+    from lib.utils import synthetic as syn
+
+    cfg = make_train_config()
+    sym = deepIM_flownet()
+    sym.get_symbol(cfg, is_train=True)
+    params = sym.init_weights(cfg, {}, {}, seed=0)
+    B = 16
+    models = syn.make_models(seed=2333, n_models=1, subdiv=3)
+    rm = Render_Py(None, cfg.dataset.class_name, syn.LINEMOD_K, meshes=models)
+    batch = syn.build_device_train_batch(rm, B, seed=5, models=models)
+    mod = MutableModule(cfg, params, B, compute_dtype="bf16")
+    upd = batchUpdaterPyMulti(cfg, 480, 640, render_machine=rm)
+    outs = fit_batch(mod, batch, upd, cfg.TRAIN.lr)
+    assert len(outs) == 4 and mod.num_update == 4
+    for o in outs:
+        assert torch.isfinite(o["loss_sums"]).all()
+    assert torch.isfinite(mod.flat_w).all()
+    new = mod.get_params()
+    assert np.abs(new["conv3_weight"] - params["conv3_weight"]).max() > 0
