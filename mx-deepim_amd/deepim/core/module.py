@@ -25,14 +25,26 @@ from deepim.symbols.deepIM_flownet import ENCODER, FlowNetHip, deepIM_flownet
 
 FROZEN = ("upsampling_weight", "mask_upsampling_weight")  # attr lr_mult 0.0 (deepIM_flownet.py:334, :520)
 
+# Order in which backward() finishes the weight gradients: heads, decoder, pose head, fc6, then the encoder top down.  The flat
+# gradient vector keeps its weights in THIS order, so "everything backward has produced so far" is always one contiguous range and
+# a bucket can be handed to RCCL while the rest of backward still runs.  Buckets close after the named tensor (bytes at fp32):
+#   fc6_weight   heads + decoder + pose head + fc6      136 MB   (ready after ~15 % of backward)
+#   conv5_weight conv6_1, conv6, conv5_1, conv5          75 MB
+#   (end)        conv4_1 ... flow_conv1 + every bias      21 MB
+BACKWARD_ORDER = ["Convolution3", "mask_conv3", "upsample_flow5to4", "deconv4", "Convolution2", "upsample_flow6to5", "deconv5", "Convolution1",
+                  "rot", "trans", "fc7", "fc6"] + [l[0] for l in reversed(ENCODER)]
+BUCKET_ENDS = ("fc6_weight", "conv5_weight")
+
 
 class MutableModule(object):
-    def __init__(self, config, arg_params, batch_size, device="cuda:0", process_group=None, compute_dtype="f32"):
+    def __init__(self, config, arg_params, batch_size, device="cuda:0", process_group=None, compute_dtype="f32", overlap_allreduce=True):
         """compute_dtype "f32": the reference's precision (deepim/train.py:338-414 trains in fp32).
         "bf16": BASELINE configs[2] -- every convolution / large deconvolution forward, input gradient and weight gradient on the bf16
         matrix pipe with f32 accumulation; master weights, momentum, gradients, losses, SE(3) and every small kernel stay fp32; the
         gradient bucket crosses the ranks as bf16 (115.5 MB instead of 231 MB).  New functionality with a declared tolerance against
-        the fp32 path (tests/test_gpu_bf16.py, tests/test_gpu_train_bf16.py)."""
+        the fp32 path (tests/test_gpu_bf16.py, tests/test_gpu_train_bf16.py).
+        overlap_allreduce: hand the gradient to the collective in three buckets while backward is still running (see BACKWARD_ORDER);
+        False = one all-reduce of the whole vector inside update(), the first version.  Same sums either way."""
         cfg = config
         assert compute_dtype in ("f32", "bf16"), compute_dtype
         self.bf16 = compute_dtype == "bf16"
@@ -50,8 +62,9 @@ class MutableModule(object):
         # ---- flat master parameters / gradients / momentum, MXNet layouts, in the shape table's order
         # grouped so that one optimizer launch covers a whole class: [weights (wd) | biases (wd_mult 0) | frozen (lr_mult 0)]
         keys = list(shapes.keys())
-        self.names = ([n for n in keys if n not in FROZEN and n.endswith("_weight")] + [n for n in keys if n not in FROZEN and not n.endswith("_weight")]
-                      + [n for n in keys if n in FROZEN])
+        wnames = [n + "_weight" for n in BACKWARD_ORDER if n + "_weight" in shapes]
+        assert sorted(wnames) == sorted(n for n in keys if n not in FROZEN and n.endswith("_weight")), "BACKWARD_ORDER misses a layer"
+        self.names = wnames + [n for n in keys if n not in FROZEN and not n.endswith("_weight")] + [n for n in keys if n in FROZEN]
         self.shapes = shapes
         sizes = [int(np.prod(shapes[n])) for n in self.names]
         total = sum(sizes)
@@ -65,7 +78,9 @@ class MutableModule(object):
         self.n_weight = sum(sz for n, sz in zip(self.names, sizes) if n not in FROZEN and n.endswith("_weight"))
         self.n_bias = sum(sz for n, sz in zip(self.names, sizes) if n not in FROZEN and not n.endswith("_weight"))
         off = 0
+        off_of = {}
         for n, sz in zip(self.names, sizes):
+            off_of[n] = off
             self.w[n] = self.flat_w[off:off + sz].view(shapes[n])
             self.g[n] = self.flat_g[off:off + sz].view(shapes[n])
             self.m[n] = self.flat_m[off:off + sz].view(shapes[n])
@@ -73,6 +88,13 @@ class MutableModule(object):
             off += sz
         # ---- forward executor shares the master tensors (params dict = views of flat_w)
         self.net = FlowNetHip.__new__(FlowNetHip)
+        # gradient buckets [begin, end) of the flat vector, in backward order; the last one also carries the biases; frozen tensors
+        # (zero gradient, never updated) are not sent at all
+        self.overlap_allreduce = bool(overlap_allreduce)
+        ends = [off_of[n] + int(np.prod(shapes[n])) for n in BUCKET_ENDS if n in off_of] + [self.n_weight + self.n_bias]
+        self.buckets = [(a, b) for a, b in zip([0] + ends[:-1], ends) if b > a]
+        self._pending = []      # (work handle or None, begin, end) of the buckets already handed to the collective
+        self._next_bucket = 0
         self._init_forward(cfg, batch_size)
         self._init_backward(batch_size)
         self.num_update = 0
@@ -232,6 +254,7 @@ class MutableModule(object):
         cfg, net, w, g = self.cfg, self.net, self.w, self.g
         ti = cfg.train_iter
         B = self.B
+        self._pending, self._next_bucket = [], 0
         self.loss_sums.zero_()
         # ---------------- loss gradients (get_loss :344-357, :446-499, :531-536)
         ops.flow_loss_grad(self.flow_est_crop, self.zoom_flow_lab, self.zoom_flow_w, self.dflow_full, cfg.dataset.NORMALIZE_FLOW,
@@ -276,7 +299,8 @@ class MutableModule(object):
         dz6 = self.dz6.view(B, 1, 1, 256)
         ops.conv2d_wgrad(net.acts["conv6_1"], 1024, dz6, 256, 8, 10, 1, 0, self.gpack, bf16_mfma=self.bf16)
         ops.fc_unpack_weight(self.gpack, g["fc6_weight"], 1024, 8, 10)
-        torch.sum(self.dz6, dim=0, out=g["fc6_bias"])
+        self._bucket_ready("fc6_weight")
+        ops.bias_grad(dz6, 256, g["fc6_bias"], workspace=self.bias_ws)
         # d(ReLU10) += dz6 * W6  (fc6 dgrad as a 1x1 convolution to 81920 "channels" = the NHWC feature map)
         ops.conv2d_fwd_ex(dz6, 0, 256, self.dgrad_packed["fc6"], None, d10.view(B, 1, 1, 81920), 0, 81920, 1, 1, 1, 0, accumulate=True)
         # ---------------- encoder, top down
@@ -302,6 +326,7 @@ class MutableModule(object):
                                  bf16_mfma=self.bf16)
                 ops.conv2d_unpack_weight(self.gpack, g[name + "_weight"])
             ops.bias_grad(dy, cout, g[name + "_bias"], workspace=self.bias_ws)
+            self._bucket_ready(name + "_weight")
             if prev[name]:
                 if name in self.wino_dgrad:
                     # dX of a 3x3 / stride-1 / pad-1 convolution = the same kind of convolution of dZ with the flipped, transposed
@@ -315,7 +340,56 @@ class MutableModule(object):
                     ops.conv2d_dgrad_winograd5x5s2(dy, cout, self.wino5_dgrad[name], self.dacts[prev[name]], cin[name], workspace=self.wino_ws)
                 else:
                     ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False)
+        self._bucket_ready(None)
         return g
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _bucket_ready(self, name):
+        """backward() has just enqueued the last kernel that writes gradient tensor `name` (None: the end of backward): if that closes
+        a bucket, start its all-reduce(SUM).  With the nccl (= RCCL) backend an async collective runs on the communicator's own stream,
+        ordered after everything enqueued on the compute stream so far, so the transfer over xGMI overlaps the rest of backward;
+        update() waits for the handles.  Single process: nothing to do."""
+        import torch.distributed as dist
+
+        if not self.overlap_allreduce or self.world_size() == 1 and not self.force_bf16_bucket:
+            return
+        k = self._next_bucket
+        if k >= len(self.buckets):
+            return
+        closes = (name is None and k == len(self.buckets) - 1) or (name is not None and k < len(BUCKET_ENDS) and name == BUCKET_ENDS[k])
+        if not closes:
+            return
+        a, b = self.buckets[k]
+        self._next_bucket += 1
+        self._pending.append((self._start_allreduce(a, b), a, b))
+
+    def _start_allreduce(self, a, b):
+        import torch.distributed as dist
+
+        buf = self.flat_g[a:b]
+        if self.bf16:
+            if self.flat_g16 is None:
+                self.flat_g16 = torch.empty(self.flat_g.shape, dtype=torch.bfloat16, device=self.device)
+            buf = ops.to_bf16(self.flat_g[a:b], out=self.flat_g16[a:b])
+        if self.world_size() == 1:
+            return None
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _finish_allreduce(self):
+        """every bucket summed over the ranks and back in flat_g as fp32 (buckets not started yet -- overlap off, or update() without
+        a backward() before it -- are reduced here)"""
+        if self.world_size() > 1 or self.force_bf16_bucket:
+            while self._next_bucket < len(self.buckets):
+                a, b = self.buckets[self._next_bucket]
+                self._next_bucket += 1
+                self._pending.append((self._start_allreduce(a, b), a, b))
+        for work, a, b in self._pending:
+            if work is not None:
+                work.wait()
+            if self.bf16:
+                ops.from_bf16(self.flat_g16[a:b], out=self.flat_g[a:b])
+        self._pending = []
+        self._next_bucket = 0
 
     def _deconv_bwd(self, name, x, x_c, x_cpad, dz, dz_coff, cout, dx):
         """Deconvolution(k4,s2)+Crop(1,1) backward.  x: deconv input (N,h,w,stride>=x_cpad), dz: gradient w.r.t. the pre-activation
@@ -340,15 +414,11 @@ class MutableModule(object):
         every rank.  Two launches: weights (weight decay) and biases (MXNet sets wd_mult 0 for *_bias); frozen tensors are skipped.
         `lr` is this update's learning rate (a WarmupMultiFactorScheduler value)."""
         cfg = self.cfg
-        if self.bf16 and (self.world_size() > 1 or self.force_bf16_bucket):
-            # the bucket crosses xGMI as bf16 (115.5 MB instead of 231 MB); summed by RCCL in bf16, widened again for the f32 update
-            if self.flat_g16 is None:
-                self.flat_g16 = torch.empty(self.flat_g.shape, dtype=torch.bfloat16, device=self.device)
-            ops.to_bf16(self.flat_g, out=self.flat_g16)
-            allreduce_sum_(self.flat_g16, group=self.pg)
-            ops.from_bf16(self.flat_g16, out=self.flat_g)
+        if not self.overlap_allreduce and not self.bf16:
+            allreduce_sum_(self.flat_g[:self.n_weight + self.n_bias], group=self.pg)   # one transfer (frozen tensors excluded)
+            self._pending, self._next_bucket = [], 0
         else:
-            allreduce_sum_(self.flat_g, group=self.pg)
+            self._finish_allreduce()
         self.num_update += 1
         nw, nb = self.n_weight, self.n_bias
         seg = ((0, nw, True), (nw, nw + nb, False))

@@ -79,7 +79,10 @@ def train_net(args):
 
     B = int(config.TRAIN.BATCH_PAIRS)
     data = SyntheticPairs(config, args.num_pairs, B, device=device, rank=rank, world=world, equal_shards=True)
-    mod = MutableModule(config, arg_params, B, device=device)
+    # DIM_TRAIN_DTYPE=bf16: convolutions on the bf16 matrix pipe (BASELINE configs[2]); DIM_OVERLAP_ALLREDUCE=0: one flat all-reduce
+    # inside update() instead of three buckets overlapped with backward (same sums: tests/test_gpu_entry_points.py)
+    mod = MutableModule(config, arg_params, B, device=device, compute_dtype=os.environ.get("DIM_TRAIN_DTYPE", "f32"),
+                        overlap_allreduce=os.environ.get("DIM_OVERLAP_ALLREDUCE", "1") != "0")
     states = "%s-%04d.states.npz" % (prefix, begin_epoch)
     if config.TRAIN.RESUME and os.path.exists(states):
         mod.load_optimizer_states(states)

@@ -38,17 +38,28 @@ def test_train_then_test_entry_points(hip_lib, tmp_path):
 
 def test_two_rank_training_replicas_stay_identical(hip_lib, tmp_path):
     """world_size 2 on ONE card (gloo carries the gradient sum; on a multi-GPU node the same code runs over RCCL): after 2 epochs x 4
-    updates with different pairs per rank both replicas hold bit-identical weights (deepim/train.py asserts it and prints the digest)."""
-    env = dict(os.environ)
-    env.update(DIM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    updates with different pairs per rank both replicas hold bit-identical weights (deepim/train.py asserts it and prints the digest).
+    Run twice: gradient buckets overlapped with backward (default) and one flat all-reduce inside update() -- with two ranks every sum
+    has two addends, so the two schedules must end in the SAME weights, digit for digit."""
+    import re
+
     cfg2 = os.path.join(str(tmp_path), "two_epochs.yaml")
     with open(CFG) as f:
         text = f.read().replace("end_epoch: 8", "end_epoch: 2")
     with open(cfg2, "w") as f:
         f.write(text)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", os.path.join(PKG, "deepim", "train.py"), "--cfg", cfg2, "--gpus", "0,0", "--num_pairs", "64",
-                        "--max_batches", "1", "--frequent", "1"], cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       universal_newlines=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:]
-    assert "replicas identical on 2 ranks" in r.stdout
+    digests = {}
+    for overlap, port in (("1", "29517"), ("0", "29519")):
+        env = dict(os.environ)
+        env.update(DIM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", DIM_OVERLAP_ALLREDUCE=overlap)
+        cwd = os.path.join(str(tmp_path), "overlap" + overlap)
+        os.makedirs(cwd)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", port, os.path.join(PKG, "deepim", "train.py"), "--cfg", cfg2, "--gpus", "0,0", "--num_pairs", "64",
+                            "--max_batches", "1", "--frequent", "1"], cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           universal_newlines=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        m = re.search(r"replicas identical on 2 ranks \(digest ([-+0-9.e]+)\)", r.stdout)
+        assert m, r.stdout[-2000:]
+        digests[overlap] = m.group(1)
+    assert digests["1"] == digests["0"], digests

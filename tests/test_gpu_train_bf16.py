@@ -48,11 +48,11 @@ def test_bf16_training_step_vs_fp32(hip_lib):
     for k in ("rot_est_norm", "trans_est"):
         d = (o16[k] - o32[k]).abs().max().item()
         print("{:16s} max |bf16 - f32| = {:.2e}".format(k, d))
-        assert d <= 2e-2, (k, d)
+        assert d <= 1e-3, (k, d)
     for k in ("flow_est_crop", "mask_logit"):
         e = l2rel(o16[k].cpu().numpy(), o32[k].cpu().numpy())
         print("{:16s} L2-relative    = {:.2e}".format(k, e))
-        assert e <= 5e-2, (k, e)
+        assert e <= 2e-2, (k, e)
     g32, g16 = m32.get_grads(), m16.get_grads()
     errs = {}
     for k, a in g32.items():
@@ -61,8 +61,11 @@ def test_bf16_training_step_vs_fp32(hip_lib):
         errs[k] = l2rel(g16[k], a)
         print("grad {:28s} L2-relative = {:.2e}".format(k, errs[k]))
     assert all(np.isfinite(v) for v in errs.values())
-    assert max(errs.values()) <= 1e-1, max(errs.items(), key=lambda kv: kv[1])
-    assert float(np.median(list(errs.values()))) <= 4e-2
+    assert max(errs.values()) <= 1.2e-1, max(errs.items(), key=lambda kv: kv[1])
+    assert float(np.median(list(errs.values()))) <= 6e-2
+    for k in errs:
+        a, b = g16[k].ravel().astype(np.float64), g32[k].ravel().astype(np.float64)
+        assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) >= 0.99, k
     # one SGD step each
     before = m32.get_params()
     m32.update(cfg.TRAIN.lr)

@@ -1,4 +1,5 @@
-"""Time one training iteration (forward + backward + update) at batch B on one GPU; prints per-phase ms.  usage: bench_train.py [B]"""
+"""Time one training iteration (forward + backward + update) at batch B on one GPU; prints per-phase ms.
+usage: bench_train.py [B] [f32|bf16]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mx-deepim_amd"), os.path.join(ROOT, "tests")]
@@ -12,6 +13,7 @@ from lib.utils import synthetic as syn
 from lib.hip import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+DTYPE = sys.argv[2] if len(sys.argv) > 2 else "f32"
 update_config(os.path.join(ROOT, "mx-deepim_amd/experiments/deepim/cfgs/deepim_hip_LM_ape_test.yaml"))
 cfg.TRAIN.lr = 1e-4
 sym = deepIM_flownet(); sym.get_symbol(cfg, True)
@@ -19,7 +21,7 @@ params = sym.init_weights(cfg, {}, {}, seed=0)
 models = syn.make_models(seed=2333, n_models=1, subdiv=5)
 rm = Render_Py(None, cfg.dataset.class_name, cfg.dataset.INTRINSIC_MATRIX, meshes=models)
 batch = syn.build_device_train_batch(rm, B, seed=5, models=models)
-mod = MutableModule(cfg, params, B)
+mod = MutableModule(cfg, params, B, compute_dtype=DTYPE)
 upd = batchUpdaterPyMulti(cfg, 480, 640, render_machine=rm)
 def timed(fn, n=3):
     fn(); torch.cuda.synchronize()
