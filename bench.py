@@ -50,6 +50,7 @@ def parse_args():
                     "multi-rank path on a box with fewer GPUs than ranks, together with DIM_BENCH_DEVICE)")
     ap.add_argument("--no-winograd", action="store_true", help="run every encoder layer through the direct kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fresh-batch", action="store_true", help="skip the (non-headline) `fresh_batch` object: a new batch uploaded every step")
     ap.add_argument("--no-train", action="store_true", help="skip the (non-headline) `train` object: timed training iterations at 16 pairs per GPU")
     ap.add_argument("--train-steps", type=int, default=5, help="timed training iterations per phase for the `train` object")
     ap.add_argument("--autotune", action="store_true", help="time tile/split-K candidates per layer first (untimed); default: fixed plan")
@@ -92,6 +93,48 @@ def cpu_baseline(cfg, params, models, batch, n_pairs):
     return {"value": n_pairs / dt, "unit": "pose-refinements/sec", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": "{} pairs x {} iters, batch 1 (torch-CPU f32 convs + numpy zoom + C rasteriser), {:.1f} s".format(
                 n_pairs, int(cfg.TEST.test_iter), dt)}
+
+
+def fresh_batch_bench(cfg, rm, refiner, B, dev, steps, warmup):
+    """Non-headline `fresh_batch` object: the same 4-iteration refinement, but every step takes a NEW batch from host memory through
+    the data layer (deepim/core/loader.py): raw pixels as the image files hold them (8-bit BGR, 16-bit depth: 2.15 MB per pair) ->
+    pinned staging -> copy stream -> dim_test_blobs_from_raw + dim_box_mask build the float blobs in HBM -> graph replay.  Two staging
+    sets alternate, so batch k+1 is staged and uploaded while batch k is refined.  File decoding is not in the loop (the pixels of four
+    distinct synthetic batches sit in RAM): this is the PCIe-inclusive rate of the refinement path."""
+    from deepim.core.loader import ArraySource, TestDataLoader, raw_from_device_batch
+    from lib.utils import synthetic as syn
+
+    raws = []
+    for k in range(4):
+        b = syn.build_device_batch(rm, B, seed=7000 + k, n_classes=len(cfg.dataset.class_name), pixel_means=cfg.network.PIXEL_MEANS, device=dev)
+        depth = torch.empty((B, 1, rm.height, rm.width), device=dev)
+        rm.render_batch(b["class_index"], b["src_pose"], depth=depth)
+        raws.append(raw_from_device_batch(b, cfg.network.PIXEL_MEANS, depth, float(cfg.dataset.DEPTH_FACTOR)))
+    cat = [np.concatenate([r[i] for r in raws]) for i in range(6)]
+    need = steps + warmup + 2
+    loader = TestDataLoader(None, cfg, batch_size=B, device=dev, workers=min(8, host_cores()),
+                            source=ArraySource(*cat, repeat=-(-need // 4)))
+
+    def step():
+        st = loader.next_raw()
+        refiner.load_staged(loader, st)
+        refiner.refine()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    loader.close()
+    per_pair = 2 * rm.height * rm.width * 3 + rm.height * rm.width * 2
+    return {"value": round(B * steps / el, 2), "unit": "pose-refinements/sec", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+            "h2d_bytes_per_pair": per_pair, "h2d_bytes_per_pair_as_float_blobs": 8 * rm.height * rm.width * 4,
+            "status_flags": int(refiner.status_iter.abs().sum().item()),
+            "pipeline": "host RAM (uint8 BGR x2 + uint16 depth) -> pinned staging (2 sets) -> copy stream -> dim_test_blobs_from_raw + "
+                        "dim_box_mask -> hipGraph replay; decode of image files not included"}
 
 
 def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps):
@@ -310,6 +353,8 @@ def main():
                    "conv_plan": {k: list(v) for k, v in net.conv_plan.items()}},
         "roofline": roofline,
     }
+    if world == 1 and not args.no_fresh_batch and not args.no_graph:
+        out["fresh_batch"] = fresh_batch_bench(cfg, rm, refiner, B, dev, args.steps, args.warmup)
     if not args.no_train:
         del refiner, pred
         torch.cuda.empty_cache()

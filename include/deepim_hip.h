@@ -84,6 +84,9 @@ int dim_se3_compose(const float* pose_src, const float* se3, float* pose_out, do
 /* (rot_quat, trans) = calc_RT_delta(pose_src, pose_tgt, rot_type="QUAT")  (RT_transform.py:16-48) */
 int dim_se3_delta(const float* pose_src, const float* pose_tgt, float* rot_quat, float* trans, int B, int rot_coord,
                   const float* T_means3, const float* T_stds3, void* stream);
+/* the same residual with the rotation as a 3x3 matrix (calc_RT_delta(..., rot_type="MATRIX"), RT_transform.py:16-48): rot_mat (B,3,3) */
+int dim_se3_delta_matrix(const float* pose_src, const float* pose_tgt, float* rot_mat, float* trans, int B, int rot_coord,
+                         const float* T_means3, const float* T_stds3, void* stream);
 /* KT (B,3,4) = K * calc_se3(pose_src, pose_tgt): the per-sample matrix dim_depth_to_flow needs (batch_updater_py_multi.py:306-312) */
 int dim_pose_to_KT(const float* pose_src, const float* pose_tgt, const float* K9, float* KT, int B, void* stream);
 /* Transform3D custom op (transform3d.py:42-327); points/out/out_grad are (B,3,Npts). */
@@ -97,6 +100,16 @@ int dim_transform3d_bwd(const float* out_grad, const float* points, const float*
  * device-pointer version of _flow (lib/flow_c/gpu_flow.hpp:1-3): flow (B,2,H,W) in (dy,dx), valid (B,1,H,W). */
 int dim_depth_to_flow(const float* depth_src, const float* depth_tgt, const float* KT, const float* Kinv9, int B, int H, int W,
                       float* flow, float* valid, void* stream);
+
+/* ---------------------------------------------------------------- data layer (test batches from raw file pixels)
+ * The loader uploads what the image files hold -- obs_bgr / ren_bgr (B,H,W,3) uint8 in B,G,R order (cv2.IMREAD_COLOR), depth_rendered
+ * (B,H,W) uint16 = metres * depth_factor -- and the blobs of get_data_pair_test_batch are built on the device:
+ * image_observed / image_rendered (B,3,H,W) = RGB planes minus PIXEL_MEANS (given in config order B,G,R: lib/utils/image.py:709-720),
+ * mask_rendered (B,1,H,W) = depth with values above mask_thr replaced by 1 (:478-488), bbox (B,4) {min_x,max_x,min_y,max_y} of
+ * depth > mask_thr for dim_box_mask (TEST.INIT_MASK box_rendered, :437-460).  Any output (and its input) may be NULL.  W % 4 == 0. */
+int dim_test_blobs_from_raw(const unsigned char* obs_bgr, const unsigned char* ren_bgr, const unsigned short* depth_rendered, int B, int H,
+                            int W, float depth_factor, const float* pixel_means_bgr3, float mask_thr, float* image_observed,
+                            float* image_rendered, float* mask_rendered, int* bbox, void* stream);
 
 /* ---------------------------------------------------------------- rasteriser
  * Mesh table in HBM: verts (sumV,3), uvs (sumV,2), faces (sumF,3 int32, indices local to the mesh),

@@ -98,8 +98,9 @@ __global__ void se3_compose_kernel(const float* __restrict__ pose_src, const flo
 }
 
 // (rot_delta quat (B,4), trans_delta (B,3)) = calc_RT_delta(pose_src, pose_tgt, rot_type="QUAT")
+// rot_mat (B,3,3), optional: the same delta as a rotation matrix (rot_type="MATRIX"); rot (quaternion) may then be null
 __global__ void se3_delta_kernel(const float* __restrict__ pose_src, const float* __restrict__ pose_tgt, float* __restrict__ rot,
-                                 float* __restrict__ trans, int B, int rot_coord, double m0, double m1, double m2, double s0,
+                                 float* __restrict__ rot_mat, float* __restrict__ trans, int B, int rot_coord, double m0, double m1, double m2, double s0,
                                  double s1, double s2) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -138,9 +139,13 @@ __global__ void se3_delta_kernel(const float* __restrict__ pose_src, const float
     dT[1] = (dT[1] - m1) / s1;
     dT[2] = (dT[2] - m2) / s2;
   }
-  double q[4];
-  mat2quat_d(Rd, q);
-  for (int i = 0; i < 4; ++i) rot[4 * b + i] = (float)q[i];
+  if (rot) {
+    double q[4];
+    mat2quat_d(Rd, q);
+    for (int i = 0; i < 4; ++i) rot[4 * b + i] = (float)q[i];
+  }
+  if (rot_mat)
+    for (int i = 0; i < 9; ++i) rot_mat[9 * b + i] = (float)Rd[i];
   for (int i = 0; i < 3; ++i) trans[3 * b + i] = (float)dT[i];
 }
 
@@ -367,10 +372,21 @@ int dim_se3_delta(const float* pose_src, const float* pose_tgt, float* rot_quat,
   if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(pose_src && pose_tgt && rot_quat && trans && T_means3 && T_stds3, "null pointer");
   DIM_REQUIRE(parse_rot(rot_coord) >= 0, "unknown rot_coord %d", rot_coord);
-  hipLaunchKernelGGL(se3_delta_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, pose_tgt, rot_quat, trans, B,
-                     rot_coord, (double)T_means3[0], (double)T_means3[1], (double)T_means3[2], (double)T_stds3[0],
+  hipLaunchKernelGGL(se3_delta_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, pose_tgt, rot_quat, nullptr, trans,
+                     B, rot_coord, (double)T_means3[0], (double)T_means3[1], (double)T_means3[2], (double)T_stds3[0],
                      (double)T_stds3[1], (double)T_stds3[2]);
   return check_launch("se3_delta");
+}
+
+int dim_se3_delta_matrix(const float* pose_src, const float* pose_tgt, float* rot_mat, float* trans, int B, int rot_coord,
+                         const float* T_means3, const float* T_stds3, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(pose_src && pose_tgt && rot_mat && trans && T_means3 && T_stds3, "null pointer");
+  DIM_REQUIRE(parse_rot(rot_coord) >= 0, "unknown rot_coord %d", rot_coord);
+  hipLaunchKernelGGL(se3_delta_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, pose_tgt, nullptr, rot_mat, trans,
+                     B, rot_coord, (double)T_means3[0], (double)T_means3[1], (double)T_means3[2], (double)T_stds3[0],
+                     (double)T_stds3[1], (double)T_stds3[2]);
+  return check_launch("se3_delta_matrix");
 }
 
 int dim_pose_to_KT(const float* pose_src, const float* pose_tgt, const float* K9, float* KT, int B, void* stream) {

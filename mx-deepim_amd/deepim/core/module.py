@@ -302,7 +302,7 @@ class MutableModule(object):
         self._bucket_ready("fc6_weight")
         ops.bias_grad(dz6, 256, g["fc6_bias"], workspace=self.bias_ws)
         # d(ReLU10) += dz6 * W6  (fc6 dgrad as a 1x1 convolution to 81920 "channels" = the NHWC feature map)
-        ops.conv2d_fwd_ex(dz6, 0, 256, self.dgrad_packed["fc6"], None, d10.view(B, 1, 1, 81920), 0, 81920, 1, 1, 1, 0, accumulate=True)
+        ops.conv2d_fwd_ex(dz6, 0, 256, self.dgrad_packed["fc6"], None, d10.view(B, 1, 1, 81920), 0, 81920, 1, 1, 1, 0, accumulate=True)  # M = B rows: tile 3
         # ---------------- encoder, top down
         prev = {ENCODER[i][0]: (ENCODER[i - 1][0] if i else None) for i in range(len(ENCODER))}
         cin = {}
@@ -339,7 +339,10 @@ class MutableModule(object):
                 elif name in self.wino5_dgrad:
                     ops.conv2d_dgrad_winograd5x5s2(dy, cout, self.wino5_dgrad[name], self.dacts[prev[name]], cin[name], workspace=self.wino_ws)
                 else:
-                    ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False)
+                    # bf16: operand-traffic bound, so the widest tile the channel count allows (dX channels are the GEMM's N)
+                    dg_tile = 4 if (self.bf16 and ops.pad64(cin[name]) % 128 == 0) else 3
+                    ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False,
+                                     tile=dg_tile)
         self._bucket_ready(None)
         return g
 
@@ -401,7 +404,8 @@ class MutableModule(object):
         ops.conv2d_unpack_weight(self.gpack, g[name + "_weight"], CoutPad=x_cpad)
         ops.bias_grad(dz, cout, g[name + "_bias"], dz_coff=dz_coff, workspace=self.bias_ws)
         # data gradient: the same convolution applied to dz
-        ops.conv2d_fwd_ex(dz, dz_coff, cout, self.dgrad_packed[name], None, dx, 0, x_cpad, 4, 4, 2, 1, Ho=h, Wo=wd, accumulate=False)
+        ops.conv2d_fwd_ex(dz, dz_coff, cout, self.dgrad_packed[name], None, dx, 0, x_cpad, 4, 4, 2, 1, Ho=h, Wo=wd, accumulate=False,
+                          tile=4 if (self.bf16 and x_cpad % 128 == 0) else 3)
 
     def forward_backward(self, batch):
         out = self.forward(batch)

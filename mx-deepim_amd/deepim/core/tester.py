@@ -94,6 +94,17 @@ class Refiner(object):
             li = np.stack([[np.random.uniform(0.9, 1.1, size=(3,)) for _ in range(self.test_iter - 1)] for _ in range(self.B)])
             self.light_int.copy_(torch.from_numpy(li.transpose(1, 0, 2).astype(np.float32)))
 
+    def load_staged(self, loader, staged):
+        """take the next batch straight from a deepim.core.loader.TestDataLoader staging set: the raw pixels it uploaded are turned
+        into the resident blobs by dim_test_blobs_from_raw / dim_box_mask on the current stream -- no host blobs, no extra copies"""
+        loader.build_blobs(staged, out={"image_observed": self.batch["image_observed"], "image_rendered": self.init["image_rendered"],
+                                        "mask_rendered": self.init["mask_rendered"], "mask_observed": self.init["mask_observed"]})
+        ops.copy(self.pose_init, staged.d_pose)
+        ops.copy(self.batch["class_index"], staged.d_cls)
+        if self.lit and self.test_iter > 1:
+            li = np.stack([[np.random.uniform(0.9, 1.1, size=(3,)) for _ in range(self.test_iter - 1)] for _ in range(self.B)])
+            self.light_int.copy_(torch.from_numpy(li.transpose(1, 0, 2).astype(np.float32)))
+
     def _loop(self):
         """tester.py:476-598 for a whole batch; everything enqueued on the current stream, no host sync."""
         cfg, net, b = self.cfg, self.net, self.batch

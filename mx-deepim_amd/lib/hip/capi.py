@@ -28,10 +28,12 @@ SIGNATURES = {
     "dim_zoom_trans": (I, [P, P, P, I, I, P]),
     "dim_se3_compose": (I, [P, P, P, P, I, I, P, P, P]),
     "dim_se3_delta": (I, [P, P, P, P, I, I, P, P, P]),
+    "dim_se3_delta_matrix": (I, [P, P, P, P, I, I, P, P, P]),
     "dim_pose_to_KT": (I, [P, P, P, P, I, P]),
     "dim_transform3d_fwd": (I, [P, P, P, P, P, I, I, I, P, P, P]),
     "dim_transform3d_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P, P]),
     "dim_depth_to_flow": (I, [P, P, P, P, I, I, I, P, P, P]),
+    "dim_test_blobs_from_raw": (I, [P, P, P, I, I, I, F, P, F, P, P, P, P, P]),
     "dim_raster_workspace_bytes": (L, [I, I, I, I]),
     "dim_raster_render": (I, [P, P, P, P, I, I, I, P, P, P, P, P, I, I, I, F, F, I, P, F, P, P, P, P, P, P, P, P]),
     "dim_raster_render_lit": (I, [P, P, P, P, P, I, I, I, P, P, P, P, P, I, I, I, F, F, I, P, P, F, P, F, P, P, P, P, P, P, P, P]),

@@ -106,6 +106,18 @@ def se3_delta(pose_src, pose_tgt, rot_coord, T_means, T_stds):
     return rot, trans
 
 
+def se3_delta_matrix(pose_src, pose_tgt, rot_coord, T_means, T_stds):
+    """-> (rotation residual (B,3,3), translation residual (B,3)): calc_RT_delta(..., rot_type="MATRIX")"""
+    B = pose_src.shape[0]
+    rot = _new((B, 3, 3), pose_src)
+    trans = _new((B, 3), pose_src)
+    k1, mp = host_f32(T_means, 3)
+    k2, sp = host_f32(T_stds, 3)
+    check(lib().dim_se3_delta_matrix(dptr(pose_src, f32), dptr(pose_tgt, f32), dptr(rot, f32), dptr(trans, f32), B,
+                                     capi.rot_coord_id(rot_coord), mp, sp, current_stream()))
+    return rot, trans
+
+
 def transform3d_fwd(points, rot, trans, pose_src, rot_coord, T_means, T_stds, out=None):
     B = points.shape[0]
     npts = points.numel() // (B * 3) if B else 0
@@ -146,6 +158,16 @@ def box_mask(bbox, mask, bbox_of_mask=None):
     check(lib().dim_box_mask(dptr(bbox, i32), dptr(mask, f32), B, H, W, dptr(bbox_of_mask, i32) if bbox_of_mask is not None else None,
                              current_stream()))
     return mask
+
+
+def test_blobs_from_raw(obs_bgr, ren_bgr, depth_ren, depth_factor, pixel_means_bgr, image_observed, image_rendered, mask_rendered, bbox,
+                        mask_thr=0.2):
+    """uint8 BGR images (B,H,W,3) + uint16 rendered depth (B,H,W) -> the float blobs of a test batch, on the device (csrc/data.hip)"""
+    B, H, W = depth_ren.shape
+    keep, mp = host_f32(pixel_means_bgr, 3)
+    check(lib().dim_test_blobs_from_raw(dptr(obs_bgr, torch.uint8), dptr(ren_bgr, torch.uint8), dptr(depth_ren, torch.uint16), B, H, W,
+                                        float(depth_factor), mp, float(mask_thr), dptr(image_observed, f32), dptr(image_rendered, f32),
+                                        dptr(mask_rendered, f32), dptr(bbox, i32), current_stream()))
 
 
 def conv2d_pack_weight(w_oihw):

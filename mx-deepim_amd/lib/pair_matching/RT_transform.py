@@ -35,8 +35,16 @@ def RT_transform(pose_src, r, t, T_means, T_stds, rot_coord="MODEL", device="cud
 
 
 def calc_RT_delta(pose_src, pose_tgt, T_means, T_stds, rot_coord="MODEL", rot_type="MATRIX", device="cuda:0"):
-    if rot_type.lower() != "quat":
-        raise Exception("HIP path implements rot_type 'QUAT' (the only one the training labels use); got {}".format(rot_type))
-    q, t = calc_RT_delta_batch(_dev(np.asarray(pose_src).reshape(1, 3, 4), device), _dev(np.asarray(pose_tgt).reshape(1, 3, 4), device),
-                               T_means, T_stds, rot_coord)
-    return q[0].cpu().numpy(), t[0].cpu().numpy()
+    """reference :16-48.  rot_type "quat" -> (w,x,y,z) with w >= 0, "matrix" -> the 3x3 residual rotation (the default there);
+    "euler" is not built (no shipped configuration uses it)."""
+    kind = rot_type.lower()
+    ps, pt = _dev(np.asarray(pose_src).reshape(1, 3, 4), device), _dev(np.asarray(pose_tgt).reshape(1, 3, 4), device)
+    if kind == "quat":
+        r, t = calc_RT_delta_batch(ps, pt, T_means, T_stds, rot_coord)
+    elif kind == "matrix":
+        r, t = ops.se3_delta_matrix(ps, pt, rot_coord, T_means, T_stds)
+    elif kind == "euler":
+        raise Exception("rot_type 'EULER' is not on the HIP path (QUAT and MATRIX are)")
+    else:
+        raise Exception("Unknown rot_type: {}".format(rot_type))
+    return r[0].cpu().numpy(), t[0].cpu().numpy()

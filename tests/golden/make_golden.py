@@ -7,7 +7,7 @@ only inputs and expected outputs are stored.
 Modules imported from /root/reference:
   lib/pair_matching/RT_transform.py  (numpy-2 alias shim for its module-level np.float uses, :246-247)
   lib/pair_matching/flow.py (calc_flow), lib/utils/pose_error.py (add, adi, arp_2d, re, te),
-  lib/utils/get_min_rect.py, lib/utils/projection.py (se3_mul, se3_inverse)
+  lib/utils/get_min_rect.py, lib/utils/projection.py (se3_mul, se3_inverse, backproject_camera), lib/utils/mask_dilate.py
 """
 import os
 import sys
@@ -23,7 +23,8 @@ from lib.pair_matching import RT_transform as RT  # noqa: E402
 from lib.pair_matching.flow import calc_flow  # noqa: E402
 from lib.utils.pose_error import add, adi, arp_2d, re, te  # noqa: E402
 from lib.utils.get_min_rect import get_min_rect  # noqa: E402
-from lib.utils.projection import se3_inverse, se3_mul  # noqa: E402
+from lib.utils.projection import backproject_camera, se3_inverse, se3_mul  # noqa: E402
+from lib.utils.mask_dilate import mask_dilate  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 K = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1]])
@@ -156,11 +157,49 @@ def min_rect_vectors():
     np.savez_compressed(os.path.join(HERE, "min_rect_golden.npz"), masks=np.array(masks), rects=np.array(rects))
 
 
+def data_layer_vectors():
+    """N4 (lib/utils/image.py helpers that import here): mask_dilate under a seeded numpy global RNG -- the seeds cover every value of
+    `direction` --, with both thickness bounds the callers use (10: image.py:346, :488); backproject_camera; calc_flow's X_valid."""
+    rng = np.random.default_rng(21)
+    masks = []
+    for i in range(3):
+        m = np.zeros((60, 80), dtype=np.float64)
+        y0, x0 = rng.integers(12, 25), rng.integers(12, 35)
+        m[y0:y0 + rng.integers(8, 25), x0:x0 + rng.integers(8, 30)] = 1.0
+        m[y0 + 3:y0 + 6, x0 + 2:x0 + 5] = 0.0  # a hole: the dilation rules look at != 0 / == 0 transitions
+        masks.append(m)
+    seeds, outs, which, thick = [], [], [], []
+    for seed in list(range(16)) + [17, 41]:   # first draws 0..9 all occur (seed 41 gives direction 0)
+        for k, m in enumerate(masks):
+            for mt in (10, 4):
+                np.random.seed(seed)
+                outs.append(mask_dilate(m, max_thickness=mt))
+                seeds.append(seed); which.append(k); thick.append(mt)
+    Ks = K.copy()
+    Ks[:2] *= 0.125
+    depth = (rng.uniform(0.4, 1.2, size=(60, 80)) * (rng.uniform(size=(60, 80)) > 0.3)).astype(np.float32)
+    X = backproject_camera(depth, Ks)
+    p0, p1 = rand_pose(rng), None
+    p0[:, 3] = [0.01, -0.02, 0.7]
+    p1 = p0.copy()
+    p1[:, 3] += [0.004, 0.002, 0.01]
+    d0, d1 = synth_depth(rng, p0, 60, 80, Ks), synth_depth(rng, p1, 60, 80, Ks)
+    f_std, v_std, X_valid = calc_flow(d0, p0, p1, Ks, d1, thresh=3e-3, standard_rep=True)
+    np.savez_compressed(os.path.join(HERE, "data_golden.npz"), masks=np.array(masks), dil_seed=np.array(seeds), dil_mask=np.array(which),
+                        dil_thick=np.array(thick), dil_out=np.array(outs), K=Ks, depth=depth, backproject=X.astype(np.float64),
+                        cf_depth_src=d0, cf_depth_tgt=d1, cf_pose_src=p0, cf_pose_tgt=p1, cf_flow_std=f_std.astype(np.float32),
+                        cf_visible=v_std.astype(np.float32), cf_X_valid=np.asarray(X_valid, dtype=np.float64))
+
+
 if __name__ == "__main__":
+    if "--data-only" in sys.argv:
+        data_layer_vectors()
+        sys.exit(0)
     se3_vectors()
     flow_vectors()
     pose_error_vectors()
     min_rect_vectors()
+    data_layer_vectors()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

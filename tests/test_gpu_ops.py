@@ -44,6 +44,18 @@ def test_se3_compose_and_delta_vs_reference_golden(ops, golden_dir, coord):
     np.testing.assert_allclose(rot.cpu().numpy(), g[coord + "_delta_q"], atol=2e-6)
     np.testing.assert_allclose(trans.cpu().numpy(), g[coord + "_delta_t"], atol=2e-6)
     assert (rot[:, 0] >= 0).all()
+    # rot_type "MATRIX" (the reference's default): the residual rotation itself, same translation residual
+    rmat, trans_m = ops.se3_delta_matrix(ps, pt, coord, z3, o3)
+    np.testing.assert_allclose(rmat.cpu().numpy(), g[coord + "_delta_R"], atol=2e-6)
+    np.testing.assert_array_equal(trans_m.cpu().numpy(), trans.cpu().numpy())
+    from lib.pair_matching.RT_transform import calc_RT_delta
+
+    r1, t1 = calc_RT_delta(g["pose_src"][3], g["pose_tgt"][3], z3, o3, coord, "MATRIX")
+    assert r1.shape == (3, 3)
+    np.testing.assert_allclose(r1, g[coord + "_delta_R"][3], atol=2e-6)
+    np.testing.assert_allclose(t1, g[coord + "_delta_t"][3], atol=2e-6)
+    with pytest.raises(Exception, match="EULER"):
+        calc_RT_delta(g["pose_src"][3], g["pose_tgt"][3], z3, o3, coord, "EULER")
 
 
 def test_se3_means_stds(ops, golden_dir):

@@ -2,12 +2,16 @@
 
 The reference trains in fp32 only (deepim/train.py:338-414), so there is no reference behaviour to match: the bar is DECLARED here.
 Every convolution / large deconvolution (forward, input gradient, weight gradient) rounds its two operands to bf16 (2^-9 relative
-each, nearest even) and accumulates in f32; 10 encoder layers deep that compounds to ~1e-2 on activations and gradients, plus the
-LeakyReLU' flips of pre-activations that sit within that noise of zero.
+each, nearest even) and accumulates in f32; 10 encoder layers deep that compounds to ~5e-3 on the activations.  Measured on MI355X:
+rot / trans within 3e-5, flow / mask heads 5e-3 .. 8e-3 L2-relative.  The GRADIENTS carry a second, larger term that is not arithmetic:
+LeakyReLU' is discontinuous at 0, and a unit whose pre-activation lies within the forward noise (~0.5 % of its scale) of zero takes
+slope 1 in one run and 0.1 in the other.  About 0.4 % of the units do, each changes its gradient by 90 % -> sqrt(0.004 * 0.81) ~ 6 % L2
+on every tensor below the first such layer (the fp32-vs-f64 comparison of tests/test_gpu_train.py sees the same effect at 1e-3 because
+its forward noise is 1e-6).  Either gradient is a valid sub-gradient of the same function at a point 2^-9 away.
 
-  outputs    rot_est_norm, trans_est            |bf16 - f32| <= 2e-2
-             flow_est_crop, mask_logit          L2-relative  <= 5e-2
-  gradients  every learnable tensor             L2-relative  <= 1e-1, median over the tensors <= 4e-2
+  outputs    rot_est_norm, trans_est            |bf16 - f32| <= 1e-3
+             flow_est_crop, mask_logit          L2-relative  <= 2e-2
+  gradients  every learnable tensor             L2-relative  <= 1.2e-1, median over the tensors <= 6e-2, cosine >= 0.99
   update     one SGD step from the bf16 gradients moves every tensor within 15 % (L2) of the fp32 step
 """
 import numpy as np
