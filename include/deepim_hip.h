@@ -72,6 +72,11 @@ int dim_zoom_net_input(const float* image_observed, const float* image_rendered,
                        const float* mask_rendered, const float* zoom_factor, float* X_nhwc8, int B, int H, int W,
                        const float* means3, float* z_image_observed, float* z_image_rendered, float* z_mask_observed,
                        float* z_mask_rendered, void* stream);
+/* the other input arities of get_convs (deepIM_flownet.py:33-66): mode 0 = masks (as dim_zoom_net_input), 1 = images only (INPUT_MASK
+ * off, ZoomImage path: channels 6, 7 of X are zero), 2 = depth_observed / depth_rendered in place of the masks (INPUT_DEPTH without
+ * masks: ZoomDepth's plain bilinear sample, / 255).  X stays (B,H,W,8) NHWC. */
+int dim_zoom_net_input_ex(const float* image_observed, const float* image_rendered, const float* extra_observed, const float* extra_rendered,
+                          const float* zoom_factor, float* X_nhwc8, int B, int H, int W, const float* means3, int mode, void* stream);
 
 /* ZoomTrans (zoom_trans.py:22-76): mode 0 copy, 1 (dx,dy)/wx, 2 (dx,dy)*wx */
 int dim_zoom_trans(const float* zoom_factor, const float* in, float* out, int B, int mode, void* stream);

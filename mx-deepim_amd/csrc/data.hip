@@ -20,7 +20,7 @@ __global__ void blobs_bbox_init_kernel(int* bbox, int n, int H, int W) {
 __global__ __launch_bounds__(256) void test_blobs_from_raw_kernel(const unsigned char* __restrict__ obs_bgr,
                                                                   const unsigned char* __restrict__ ren_bgr,
                                                                   const unsigned short* __restrict__ depth_ren, int H, int W,
-                                                                  float inv_depth_factor, float mb, float mg, float mr, float thr,
+                                                                  float depth_factor, float mb, float mg, float mr, float thr,
                                                                   float* __restrict__ image_observed, float* __restrict__ image_rendered,
                                                                   float* __restrict__ mask_rendered, int* __restrict__ bbox) {
   const int b = blockIdx.y;
@@ -48,10 +48,10 @@ __global__ __launch_bounds__(256) void test_blobs_from_raw_kernel(const unsigned
     }
     if (depth_ren) {
       const uint2 raw = *reinterpret_cast<const uint2*>(depth_ren + o);
-      d[0] = (float)(raw.x & 0xFFFFu) * inv_depth_factor;
-      d[1] = (float)(raw.x >> 16) * inv_depth_factor;
-      d[2] = (float)(raw.y & 0xFFFFu) * inv_depth_factor;
-      d[3] = (float)(raw.y >> 16) * inv_depth_factor;
+      d[0] = __fdiv_rn((float)(raw.x & 0xFFFFu), depth_factor);  // a true division, as `depth / DEPTH_FACTOR` on the host
+      d[1] = __fdiv_rn((float)(raw.x >> 16), depth_factor);  // a true division, as `depth / DEPTH_FACTOR` on the host
+      d[2] = __fdiv_rn((float)(raw.y & 0xFFFFu), depth_factor);  // a true division, as `depth / DEPTH_FACTOR` on the host
+      d[3] = __fdiv_rn((float)(raw.y >> 16), depth_factor);  // a true division, as `depth / DEPTH_FACTOR` on the host
       if (mask_rendered)
         *reinterpret_cast<float4*>(mask_rendered + o) = make_float4(d[0] > thr ? 1.f : d[0], d[1] > thr ? 1.f : d[1], d[2] > thr ? 1.f : d[2],
                                                                     d[3] > thr ? 1.f : d[3]);
@@ -99,7 +99,7 @@ int dim_test_blobs_from_raw(const unsigned char* obs_bgr, const unsigned char* r
   hipStream_t st = as_stream(stream);
   if (bbox) hipLaunchKernelGGL(blobs_bbox_init_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, bbox, B, H, W);
   hipLaunchKernelGGL(test_blobs_from_raw_kernel, dim3(ceil_div((long)H * W / 4, 256), B), dim3(256), 0, st, obs_bgr, ren_bgr, depth_rendered,
-                     H, W, 1.0f / depth_factor, pixel_means_bgr3[0], pixel_means_bgr3[1], pixel_means_bgr3[2], mask_thr, image_observed,
+                     H, W, depth_factor, pixel_means_bgr3[0], pixel_means_bgr3[1], pixel_means_bgr3[2], mask_thr, image_observed,
                      image_rendered, mask_rendered, bbox);
   return check_launch("test_blobs_from_raw");
 }

@@ -260,6 +260,10 @@ __global__ __launch_bounds__(256) void zoom_planes_kernel(const float* __restric
 //   X[b, y, x, 0:3] = zoom(image_observed)/255, [3:6] = zoom(image_rendered)/255,
 //   X[.., 6] = round(zoom(mask_observed)), X[.., 7] = round(zoom(bin02(mask_rendered)))   (NHWC, 8 ch)
 // plus optional NCHW copies of the four zoomed tensors for callers that want the op outputs.
+// MODE 0: the two masks (shipped graph); MODE 1: no masks (INPUT_MASK off: channels 6, 7 = 0, the first layer's weights for them are
+// zero too); MODE 2: no masks, depth_observed / depth_rendered in their place: plain bilinear samples (ZoomDepth, zoom_depth.py:24-50)
+// divided by 255 like the images (deepIM_flownet.py:33-51)
+template <int MODE>
 __global__ __launch_bounds__(256) void zoom_net_input_kernel(const float* __restrict__ img_obs, const float* __restrict__ img_ren,
                                                              const float* __restrict__ mask_obs, const float* __restrict__ mask_ren,
                                                              const float* __restrict__ zoom_factor, float* __restrict__ X,
@@ -282,10 +286,17 @@ __global__ __launch_bounds__(256) void zoom_net_input_kernel(const float* __rest
   v[3] = __fsub_rn(sample<PRE_NONE>(ir, t, m0), m0);
   v[4] = __fsub_rn(sample<PRE_NONE>(ir + plane, t, m1), m1);
   v[5] = __fsub_rn(sample<PRE_NONE>(ir + 2 * plane, t, m2), m2);
-  v[6] = mx_round(sample<PRE_NONE>(mask_obs + (long)b * plane, t, 0.f));
-  v[7] = mx_round(sample<PRE_BIN02>(mask_ren + (long)b * plane, t, 0.f));
+  if (MODE == 0) {
+    v[6] = mx_round(sample<PRE_NONE>(mask_obs + (long)b * plane, t, 0.f));
+    v[7] = mx_round(sample<PRE_BIN02>(mask_ren + (long)b * plane, t, 0.f));
+  } else if (MODE == 2) {
+    v[6] = __fdiv_rn(sample<PRE_NONE>(mask_obs + (long)b * plane, t, 0.f), 255.f);
+    v[7] = __fdiv_rn(sample<PRE_NONE>(mask_ren + (long)b * plane, t, 0.f), 255.f);
+  } else {
+    v[6] = v[7] = 0.f;
+  }
   const long o = (long)py * W + px;
-  if (z_img_obs) {
+  if (MODE == 0 && z_img_obs) {
     for (int c = 0; c < 3; ++c) {
       z_img_obs[((long)b * 3 + c) * plane + o] = v[c];
       z_img_ren[((long)b * 3 + c) * plane + o] = v[3 + c];
@@ -365,10 +376,30 @@ int dim_zoom_net_input(const float* image_observed, const float* image_rendered,
   DIM_REQUIRE(!any || all, "pass all four NCHW outputs or none");
   const int bx = (W % 256 != 0 && W % 128 == 0) ? 128 : 256;  // W = 640: 5 x 128 leaves no idle lanes (3 x 256 idles 17 %)
   dim3 grid(ceil_div(W, bx), H, B), block(bx);
-  hipLaunchKernelGGL(zoom_net_input_kernel, grid, block, 0, as_stream(stream), image_observed, image_rendered, mask_observed,
+  hipLaunchKernelGGL(zoom_net_input_kernel<0>, grid, block, 0, as_stream(stream), image_observed, image_rendered, mask_observed,
                      mask_rendered, zoom_factor, X_nhwc8, H, W, means3[0], means3[1], means3[2], z_image_observed,
                      z_image_rendered, z_mask_observed, z_mask_rendered);
   return check_launch("zoom_net_input");
+}
+
+int dim_zoom_net_input_ex(const float* image_observed, const float* image_rendered, const float* extra_observed, const float* extra_rendered,
+                          const float* zoom_factor, float* X_nhwc8, int B, int H, int W, const float* means3, int mode, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(image_observed && image_rendered && zoom_factor && X_nhwc8 && means3, "null pointer");
+  DIM_REQUIRE(mode == 0 || mode == 1 || mode == 2, "mode 0 (masks), 1 (images only) or 2 (depth planes)");
+  DIM_REQUIRE(mode == 1 || (extra_observed && extra_rendered), "modes 0 and 2 need the two extra planes");
+  const int bx = (W % 256 != 0 && W % 128 == 0) ? 128 : 256;
+  dim3 grid(ceil_div(W, bx), H, B), block(bx);
+  hipStream_t st = as_stream(stream);
+#define DIM_ZNI(M)                                                                                                                    \
+  hipLaunchKernelGGL(zoom_net_input_kernel<M>, grid, block, 0, st, image_observed, image_rendered, extra_observed, extra_rendered, \
+                     zoom_factor, X_nhwc8, H, W, means3[0], means3[1], means3[2], (float*)nullptr, (float*)nullptr, (float*)nullptr, \
+                     (float*)nullptr)
+  if (mode == 0) DIM_ZNI(0);
+  else if (mode == 1) DIM_ZNI(1);
+  else DIM_ZNI(2);
+#undef DIM_ZNI
+  return check_launch("zoom_net_input_ex");
 }
 
 }  // extern "C"

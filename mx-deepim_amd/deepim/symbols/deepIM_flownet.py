@@ -179,10 +179,21 @@ class FlowNetHip(object):
         self.B = batch_size
         self.device = torch.device(device)
         self.cin = input_channels(cfg)
-        if self.cin != 8:
-            raise NotImplementedError("HIP encoder is built for the shipped 8-channel input (INPUT_MASK & PRED_MASK, no depth)")
+        # first-layer input arities of get_convs (reference :33-66).  The device tensor X always has 8 NHWC channels:
+        #   mode 0  images + masks            (INPUT_MASK and PRED_MASK; the shipped graph)
+        #   mode 1  images only, 2 zero lanes (no masks in the Concat: Cin = 6; the weights of the two spare lanes are zero)
+        #   mode 2  images + two depth planes (INPUT_DEPTH without masks: Cin = 8)
+        with_masks = bool(cfg.network.INPUT_MASK and cfg.network.PRED_MASK)
+        if cfg.network.INPUT_DEPTH and with_masks:
+            raise NotImplementedError("INPUT_DEPTH together with the mask channels is a 10-channel first layer: the 8-lane first-layer "
+                                      "kernel does not cover it (no shipped configuration uses INPUT_DEPTH)")
+        self.input_mode = 0 if with_masks else (2 if cfg.network.INPUT_DEPTH else 1)
+        self.zoom_from_masks = bool(cfg.network.INPUT_MASK)   # ZoomMask vs ZoomImage for the zoom window (:783-819)
         d = self.device
         self.params = {k: torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float32).to(d) for k, v in arg_params.items()}
+        if self.cin == 6:  # zero weights for the two spare input lanes
+            w1 = self.params["flow_conv1_weight"]
+            self.params["flow_conv1_weight"] = torch.cat([w1, torch.zeros((w1.shape[0], 2) + tuple(w1.shape[2:]), device=d)], dim=1).contiguous()
         self.packed = {}
         for name, cout, k, s, p in ENCODER:
             self.packed[name] = self.pack_conv(self.params[name + "_weight"])
@@ -310,14 +321,25 @@ class FlowNetHip(object):
         """ZoomMask + ZoomImageWithFactor + Concat (reference :783-806, :53-60).  At test time
         mask_gt_observed IS mask_observed (:779).  bbox_ren may come pre-computed from the rasteriser, bbox_obs from dim_box_mask
         (the refinement loop knows the rectangle it has just written); src_pose / status override the blob / the status buffer."""
-        if bbox_obs is None:
-            bbox_obs = ops.mask_bbox(batch["mask_observed"], 0.3, out=self.bbox_obs)
-        if bbox_ren is None:
-            bbox_ren = ops.mask_bbox(batch["mask_rendered"], 0.2, out=self.bbox_ren)
+        if self.zoom_from_masks:
+            if bbox_obs is None:
+                bbox_obs = ops.mask_bbox(batch["mask_observed"], 0.3, out=self.bbox_obs)
+            if bbox_ren is None:
+                bbox_ren = ops.mask_bbox(batch["mask_rendered"], 0.2, out=self.bbox_ren)
+        else:
+            # ZoomImage (zoom_image.py:31-37): the validity "mask" of an image is sum_c(image + mean) > 0.01
+            bbox_obs = ops.mask_bbox(batch["image_observed"], 0.01, mode=1, means3=self.plane_means, out=self.bbox_obs)
+            bbox_ren = ops.mask_bbox(batch["image_rendered"], 0.01, mode=1, means3=self.plane_means, out=self.bbox_ren)
         ops.zoom_factor(bbox_obs, bbox_ren, batch["src_pose"] if src_pose is None else src_pose, self.K, self.H, self.W,
                         out=self.zoom_factor, status=self.status if status is None else status)
-        ops.zoom_net_input(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"],
-                           self.zoom_factor, self.plane_means, X=self.X, nchw_out=nchw_out)
+        if self.input_mode == 0:
+            ops.zoom_net_input(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"],
+                               self.zoom_factor, self.plane_means, X=self.X, nchw_out=nchw_out)
+        elif self.input_mode == 1:
+            ops.zoom_net_input_ex(batch["image_observed"], batch["image_rendered"], None, None, self.zoom_factor, self.plane_means, 1, X=self.X)
+        else:
+            ops.zoom_net_input_ex(batch["image_observed"], batch["image_rendered"], batch["depth_observed"], batch["depth_rendered"],
+                                  self.zoom_factor, self.plane_means, 2, X=self.X)
         return self.X
 
     def encoder(self, X=None, events=None):

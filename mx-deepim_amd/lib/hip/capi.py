@@ -25,6 +25,7 @@ SIGNATURES = {
     "dim_zoom_factor": (I, [P, P, P, P, I, I, I, P, P, P]),
     "dim_zoom_planes": (I, [P, P, P, I, I, I, I, I, I, I, P, I, P]),
     "dim_zoom_net_input": (I, [P, P, P, P, P, P, I, I, I, P, P, P, P, P, P]),
+    "dim_zoom_net_input_ex": (I, [P, P, P, P, P, P, I, I, I, P, I, P]),
     "dim_zoom_trans": (I, [P, P, P, I, I, P]),
     "dim_se3_compose": (I, [P, P, P, P, I, I, P, P, P]),
     "dim_se3_delta": (I, [P, P, P, P, I, I, P, P, P]),

@@ -78,6 +78,16 @@ def zoom_net_input(img_obs, img_ren, mask_obs, mask_ren, zf, plane_means3, X=Non
     return X
 
 
+def zoom_net_input_ex(img_obs, img_ren, extra_obs, extra_ren, zf, plane_means3, mode, X=None):
+    """the other input arities of the first layer: mode 1 = images only, mode 2 = depth planes in place of the masks (see the header)"""
+    B, _, H, W = img_obs.shape
+    X = X if X is not None else _new((B, H, W, 8), img_obs)
+    keep, mp = host_f32(plane_means3, 3)
+    check(lib().dim_zoom_net_input_ex(dptr(img_obs, f32), dptr(img_ren, f32), dptr(extra_obs, f32), dptr(extra_ren, f32), dptr(zf, f32),
+                                      dptr(X, f32), B, H, W, mp, int(mode), current_stream()))
+    return X
+
+
 def zoom_trans(zf, t, mode, out=None):
     B = t.shape[0]
     out = out if out is not None else torch.empty_like(t)

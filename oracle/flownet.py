@@ -141,27 +141,35 @@ def mask_head(params, cat3, dtype=torch.float32):
     return crop_like(up, (480, 640), (8, 8))
 
 
-def network_input(zoom_io, zoom_ir, zoom_mo=None, zoom_mr=None):
-    """Concat(img/255, img/255, masks) :53-66."""
+def network_input(zoom_io, zoom_ir, zoom_mo=None, zoom_mr=None, zoom_do=None, zoom_dr=None):
+    """Concat(img/255, img/255[, depth/255, depth/255][, masks]) :33-66."""
     parts = [np.asarray(zoom_io, np.float32) / np.float32(255.0), np.asarray(zoom_ir, np.float32) / np.float32(255.0)]
+    if zoom_do is not None:
+        parts += [np.asarray(zoom_do, np.float32) / np.float32(255.0), np.asarray(zoom_dr, np.float32) / np.float32(255.0)]
     if zoom_mo is not None:
         parts += [zoom_mo, zoom_mr]
     return np.concatenate(parts, axis=1).astype(np.float32)
 
 
 def forward_test(params, batch, K, pixel_means, fast_test=True, input_mask=True, pred_mask=True, pred_flow=True,
-                 normalize_flow=20.0, dtype=torch.float32):
+                 normalize_flow=20.0, dtype=torch.float32, input_depth=False):
     """get_test_symbol_share :764-980. batch: dict of numpy blobs (image_observed, image_rendered,
     src_pose, mask_observed, mask_rendered). Returns dict(se3, zoom_factor[, mask_observed_pred,
     zoom_mask_prob, flow_est_crop])."""
     H, W = 480, 640
+    # :783-838: the zoom window comes from the masks when INPUT_MASK, else from the images; get_convs (:33-66) concatenates the masks
+    # only when INPUT_MASK and PRED_MASK, and the zoomed depths (ZoomDepth) when INPUT_DEPTH
+    zmo = zmr = zdo = zdr = None
     if input_mask:
         zmo, _, zmr, zf = ozoom.zoom_mask(batch["mask_observed"], batch["mask_observed"], batch["mask_rendered"], batch["src_pose"], K, H, W)
         zio, zir = ozoom.zoom_image_with_factor(zf, batch["image_observed"], batch["image_rendered"], pixel_means, H, W)
-        data = network_input(zio, zir, zmo, zmr)
     else:
         zio, zir, zf = ozoom.zoom_image(batch["image_observed"], batch["image_rendered"], batch["src_pose"], K, pixel_means, H, W)
-        data = network_input(zio, zir)
+    if input_depth:
+        zdo, zdr = ozoom.zoom_depth(zf, batch["depth_observed"], batch["depth_rendered"], H, W)
+    if not (input_mask and pred_mask):
+        zmo = zmr = None
+    data = network_input(zio, zir, zmo, zmr, zdo, zdr)
     out = {"zoom_factor": zf, "data": data}
     with torch.no_grad():
         fc7, feats = encoder(params, torch.from_numpy(data), dtype, return_all=True)

@@ -30,16 +30,17 @@ def update_mask_observed_box_rendered(mask_rendered):
 
 
 def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord="CAMERA", test_iter=4, znear=0.25, zfar=6.0,
-                tex_bilinear=False, fast_test=True, return_outputs=False, lit=None):
+                tex_bilinear=False, fast_test=True, return_outputs=False, lit=None, **graph):
     """One (observed, rendered) pair, batch 1 like the reference.
     lit: None, or dict(normals=(V,3), ratio=0.7) for the ModelNet branch of `render` (tester.py:204-243): light index 2,
     one np.random.uniform(0.9, 1.1, 3) intensity per re-render drawn from numpy's global RNG like the reference.
+    graph: keyword arguments of flownet.forward_test selecting the graph variant (input_mask, pred_mask, input_depth).
     blobs: image_observed (1,3,H,W), image_rendered, mask_observed (1,1,H,W), mask_rendered, src_pose (1,3,4).
     mesh: (verts, uvs, faces, tex).  Returns list of poses (test_iter x (3,4) float64) and the per-iteration se3."""
     verts, uvs, faces, tex = mesh
     batch = {k: np.array(v, dtype=np.float32) for k, v in blobs.items()}
     pose_rendered = np.array(batch["src_pose"][0], dtype=np.float64)
-    out = flownet.forward_test(params, batch, K, pixel_means, fast_test=fast_test)
+    out = flownet.forward_test(params, batch, K, pixel_means, fast_test=fast_test, **graph)
     poses, se3s, outs = [], [], []
     for it in range(test_iter):
         se3 = np.squeeze(out["se3"]).astype("float32")
@@ -65,7 +66,7 @@ def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord=
             batch["mask_observed"] = update_mask_observed_box_rendered(mask_r)[np.newaxis, np.newaxis].astype(np.float32)
             batch["src_pose"] = pose_new[np.newaxis].astype(np.float32)  # nd.array -> float32
             pose_rendered = pose_new
-            out = flownet.forward_test(params, batch, K, pixel_means, fast_test=fast_test)
+            out = flownet.forward_test(params, batch, K, pixel_means, fast_test=fast_test, **graph)
     if return_outputs:  # tester.py:485-491 reads the mask / flow heads every iteration when not FAST_TEST
         return poses, se3s, outs
     return poses, se3s

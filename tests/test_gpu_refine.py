@@ -248,3 +248,56 @@ def test_pred_eval_collects_and_scores(setup, tmp_path):
     assert max(out["all_rot_err"][0][3]) < 0.1 and max(out["all_trans_err"][0][3]) < 1e-3
     rot_err, trans_err, poses_est, poses_gt = pickle.load(open(f, "rb"))
     assert len(poses_est) == 1 and len(poses_est[0]) == 4 and len(poses_est[0][0]) == 4 and poses_est[0][0][0].shape == (3, 4)
+
+
+def test_graph_variants_images_only_and_depth_input(hip_lib):
+    """The other first-layer arities of get_convs (deepIM_flownet.py:33-66, :809-838): INPUT_MASK off -> ZoomImage derives the zoom window
+    from the images and the network sees the 6 image channels; INPUT_DEPTH (without mask channels) adds the two zoomed depth planes.
+    Forward outputs and a 2-iteration refinement against the oracle; the 10-channel combination is refused, loudly."""
+    from deepim.core.tester import Predictor, Refiner
+    from deepim.symbols.deepIM_flownet import deepIM_flownet, input_channels
+    from lib.render_hip.render_py_multi import Render_Py
+
+    B = 2
+    scene = make_scene(B=B, seed=2333, subdiv=3)
+    bl = scene["blobs"]
+    z3, o3 = np.zeros(3), np.ones(3)
+    rng = np.random.RandomState(3)
+    depth = {"depth_observed": (rng.rand(B, 1, 480, 640) * 300).astype(np.float32), "depth_rendered": (rng.rand(B, 1, 480, 640) * 300).astype(np.float32)}
+    for input_mask, pred_mask, input_depth in ((False, False, False), (False, True, False), (False, False, True), (True, False, True)):
+        cfg = make_test_config(test_iter=2)
+        cfg.network.INPUT_MASK, cfg.network.PRED_MASK, cfg.network.INPUT_DEPTH = input_mask, pred_mask, input_depth
+        cin = input_channels(cfg)
+        assert cin == (8 if input_depth else 6)
+        sym = deepIM_flownet()
+        sym.get_symbol(cfg, is_train=False)
+        params = sym.init_weights(cfg, {}, {}, seed=4)
+        assert params["flow_conv1_weight"].shape == (64, cin, 7, 7)
+        params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
+        if cin > 6:
+            params["flow_conv1_weight"][:, 6:] = (rng.randn(64, cin - 6, 7, 7) * 0.05).astype(np.float32)   # the depth lanes must matter
+        pred = Predictor(cfg, params, B)
+        batch = {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in list(bl.items()) + list(depth.items())}
+        out = pred.predict(batch)[0]
+        kw = dict(input_mask=input_mask, pred_mask=pred_mask, input_depth=input_depth)
+        host = dict(bl, **depth)
+        ref = oflow.forward_test(params, host, scene["K"], cfg.network.PIXEL_MEANS, fast_test=True, **kw)
+        np.testing.assert_allclose(out["zoom_factor"].cpu().numpy(), ref["zoom_factor"], atol=1e-5)
+        np.testing.assert_allclose(pred.net.X[..., :cin].cpu().numpy(), ref["data"].transpose(0, 2, 3, 1), atol=2e-5)
+        assert cin == 8 or float(pred.net.X[..., 6:].abs().max()) == 0.0
+        np.testing.assert_allclose(out["se3_output"].cpu().numpy(), ref["se3"], atol=5e-5)
+        if not input_depth:   # the loop re-renders images (and masks): run it for the image-only variants
+            rm = Render_Py(None, cfg.dataset.class_name, scene["K"], meshes=scene["models"])
+            refiner = Refiner(cfg, pred, rm, B, capture_graph=True)
+            refiner.load(bl["image_observed"], bl["image_rendered"], bl["mask_observed"], bl["mask_rendered"], bl["src_pose"], bl["class_index"])
+            poses = refiner.refine().cpu().numpy()
+            for b in range(B):
+                blobs_b = {k: bl[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
+                o_poses, _ = orefine.refine_pair(params, scene["models"][int(bl["class_index"][b])], blobs_b, scene["K"], cfg.network.PIXEL_MEANS,
+                                                 z3, o3, "CAMERA", test_iter=2, **kw)
+                for it in range(2):
+                    np.testing.assert_allclose(poses[it, b], o_poses[it], atol=1e-3)
+    cfg = make_test_config(test_iter=1)
+    cfg.network.INPUT_DEPTH = True
+    with pytest.raises(NotImplementedError, match="10-channel"):
+        Predictor(cfg, sym.init_weights(cfg, {}, {}, seed=0), B)
