@@ -333,6 +333,38 @@ int dim_pose_head_fwd(const float* fc6, const float* fc7_w, const float* fc7_b, 
                       const float* trans_w, const float* trans_b, const float* zoom_factor, float* se3, float* fc7_out, int B,
                       void* stream);
 
+/* ---------------------------------------------------------------- resident refinement loop (hosts without torch)
+ * The inner loop of pred_eval (deepim/core/tester.py:476-598) for a batch of B 480x640 pairs that stays in HBM, FAST_TEST graph,
+ * UPDATE_MASK 'box_rendered': per iteration ZoomMask + ZoomImageWithFactor + Concat -> encoder -> fc6/fc7/rot/trans -> RT_transform
+ * -> render -> box mask.  dim_refiner_create packs the weights (MXNet-layout device arrays given by name: <layer>_weight / _bias of
+ * the ten encoder layers, fc6, fc7, rot, trans; the bias / fc7 / rot / trans arrays are read in place and must outlive the object),
+ * allocates every buffer and fixes the launch plan; dim_refiner_run only enqueues kernels on `stream` (no allocation, no sync: it
+ * may be captured into a hipGraph) and never writes its six input blobs.  Outputs: poses_iter (test_iter,B,3,4), se3_iter
+ * (test_iter,B,7), status_iter (test_iter,B) with the DIM_STATUS_* bits.  The mesh table pointers must outlive the object. */
+typedef struct dim_refiner dim_refiner;
+typedef struct {
+  int B, H, W, test_iter;
+  float K9[9];
+  float pixel_means_bgr[3]; /* config.network.PIXEL_MEANS, in its B,G,R order */
+  float T_means[3], T_stds[3];
+  int rot_coord; /* 0 MODEL, 1 CAMERA, 2 CAMERA_NEW, 3 NAIVE */
+  float znear, zfar;
+  int tex_bilinear;
+  const float* verts;
+  const float* uvs;
+  const int* faces;
+  const int* mesh_table;
+  int n_classes, vmax, fmax;
+  const unsigned char* textures;
+  const int* tex_table;
+} dim_refiner_desc;
+int dim_refiner_create(dim_refiner** out, const dim_refiner_desc* desc, const char* const* param_names, const float* const* param_ptrs,
+                       int n_params, void* stream);
+int dim_refiner_run(dim_refiner* r, const float* image_observed, const float* image_rendered, const float* mask_observed,
+                    const float* mask_rendered, const float* src_pose, const int* class_index, float* poses_iter, float* se3_iter,
+                    int* status_iter, void* stream);
+int dim_refiner_destroy(dim_refiner* r);
+
 #ifdef __cplusplus
 }
 #endif

