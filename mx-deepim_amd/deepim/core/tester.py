@@ -160,7 +160,7 @@ class Refiner(object):
         return self.poses_iter
 
 
-def pred_eval(config, refiner, batches, evaluator, result_file=None, logger=None):
+def pred_eval(config, refiner, batches, evaluator, result_file=None, logger=None, merge_ranks=True):
     """The outer loop of the reference's pred_eval (deepim/core/tester.py:418-676) on device-resident batches.
 
     batches: iterable of dicts with the blobs Refiner.load takes plus "pose_observed" (B,3,4) ground truth.
@@ -183,13 +183,33 @@ def pred_eval(config, refiner, batches, evaluator, result_file=None, logger=None
         poses = refiner.refine().cpu().numpy().astype(np.float64)     # ONE device->host copy per batch: (iter, B, 3, 4)
         cls = torch.as_tensor(batch["class_index"]).cpu().numpy().astype(int)
         gt = torch.as_tensor(batch["pose_observed"]).cpu().numpy().astype(np.float64)
+        src = torch.as_tensor(batch["src_pose"]).cpu().numpy().astype(np.float64)
         for b in range(poses.shape[1]):
+            # "NO POINT VALID IN INIT POSE" (:419-445): an undetected object comes with pose_rendered = -1 everywhere (sum -12); it is
+            # scored with its initial pose and 1000 deg / 1000 m at every iteration instead of being refined
+            undetected = np.sum(src[b]) == -12
             for it in range(n_it):
-                r_dist, t_dist = calc_rt_dist_m(poses[it, b], gt[b])
-                all_poses_est[cls[b]][it].append(poses[it, b])
+                est = src[b] if undetected else poses[it, b]
+                r_dist, t_dist = (1000, 1000) if undetected else calc_rt_dist_m(est, gt[b])
+                all_poses_est[cls[b]][it].append(est)
                 all_poses_gt[cls[b]][it].append(gt[b])
                 all_rot_err[cls[b]][it].append(r_dist)
                 all_trans_err[cls[b]][it].append(t_dist)
+    # several ranks refine disjoint shards (one process per GPU): the metrics are over ALL pairs, so the per-class lists are merged in
+    # rank order on every rank before scoring (the reference scores one list in one process)
+    import torch.distributed as dist
+
+    merged = False
+    if merge_ranks and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, (all_rot_err, all_trans_err, all_poses_est, all_poses_gt))
+        for k, mine in enumerate((all_rot_err, all_trans_err, all_poses_est, all_poses_gt)):
+            for c in range(n_cls):
+                for it in range(n_it):
+                    mine[c][it] = [x for part in parts for x in part[k][c][it]]
+        merged = True
+        if dist.get_rank() != 0:
+            result_file = None   # one result cache, written by rank 0
     if result_file:
         with open(result_file, "wb") as f:
             pickle.dump([np.array(all_rot_err, dtype=object), np.array(all_trans_err, dtype=object), all_poses_est, all_poses_gt], f,
@@ -198,4 +218,5 @@ def pred_eval(config, refiner, batches, evaluator, result_file=None, logger=None
     out["add"] = evaluator.evaluate_pose_add(config, all_poses_est, all_poses_gt, output_dir=None, logger=logger)
     out["arp_2d"] = evaluator.evaluate_pose_arp_2d(config, all_poses_est, all_poses_gt, output_dir=None, logger=logger)
     out["all_rot_err"], out["all_trans_err"] = all_rot_err, all_trans_err
+    out["merged_over_ranks"] = merged
     return out

@@ -50,6 +50,13 @@ def test_deepim(args):
         print("note: one process drives one GPU; using gpu {} (launch under torch.distributed.run for {})".format(dev_id, args.gpus))
     torch.cuda.set_device(dev_id)
     device = "cuda:{}".format(dev_id)
+    if world > 1:
+        # ranks refine disjoint shards with no data-path collective; the per-class pose lists are merged once at the end
+        # (pred_eval, all_gather_object) so that ADD / ARP-2D / pose accuracy are over the whole test set -- host objects: gloo
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     epoch = config.TEST.test_epoch
     image_set = config.dataset.test_image_set
@@ -74,10 +81,12 @@ def test_deepim(args):
     data = SyntheticPairs(config, args.num_pairs, B, device=device, rank=rank, world=world)
     predictor = Predictor(config, arg_params, B, device=device)
     refiner = Refiner(config, predictor, data.render_machine, B, capture_graph=True)
-    result_file = os.path.join(final_output_path, "{}_rank{}_results.pkl".format(image_set, rank))
+    result_file = os.path.join(final_output_path, "{}_results.pkl".format(image_set))
     out = pred_eval(config, refiner, data.test_batches(), data.evaluator(), result_file=result_file, logger=logger)
     print("refined {} pairs x {} iterations on {}; result cache: {}".format(data.num_pairs, config.TEST.test_iter, device, result_file))
     print(args.cfg, config.TEST.test_epoch)
+    if world > 1:
+        torch.distributed.destroy_process_group()
     return out
 
 

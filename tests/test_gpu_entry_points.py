@@ -63,3 +63,21 @@ def test_two_rank_training_replicas_stay_identical(hip_lib, tmp_path):
         assert m, r.stdout[-2000:]
         digests[overlap] = m.group(1)
     assert digests["1"] == digests["0"], digests
+
+
+def test_two_rank_test_run_scores_the_union_of_the_shards(hip_lib, tmp_path):
+    """deepim/test.py under torch.distributed.run, 2 ranks on one card: each rank refines its own 32 of the 64 pairs (no collective on
+    the data path), the per-class pose lists are merged once (all_gather_object) and every metric is over all 64 pairs; ONE result
+    cache is written."""
+    import pickle
+
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29523", os.path.join(PKG, "deepim", "test.py"), "--cfg", CFG, "--gpus", "0,0", "--num_pairs", "64"],
+                       cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    files = glob.glob(os.path.join(str(tmp_path), "output", "deepim_hip", "*", "synthetic_val_ape", "*_results.pkl"))
+    assert len(files) == 1, files
+    rot_err, trans_err, poses_est, poses_gt = pickle.load(open(files[0], "rb"))
+    assert len(poses_est[0][3]) == 64 and len(poses_gt[0][0]) == 64

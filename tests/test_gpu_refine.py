@@ -248,6 +248,15 @@ def test_pred_eval_collects_and_scores(setup, tmp_path):
     assert max(out["all_rot_err"][0][3]) < 0.1 and max(out["all_trans_err"][0][3]) < 1e-3
     rot_err, trans_err, poses_est, poses_gt = pickle.load(open(f, "rb"))
     assert len(poses_est) == 1 and len(poses_est[0]) == 4 and len(poses_est[0][0]) == 4 and poses_est[0][0][0].shape == (3, 4)
+    assert out["merged_over_ranks"] is False
+    # "NO POINT VALID IN INIT POSE" (tester.py:419-445): pose_rendered = -1 everywhere marks an undetected object; it keeps its initial
+    # pose and is scored 1000 deg / 1000 m at every iteration, the other pair of the batch is unaffected
+    lost = dict(batch)
+    lost["src_pose"] = np.array(bl["src_pose"], copy=True)
+    lost["src_pose"][1] = -1.0
+    out2 = pred_eval(cfg, ref, [lost], ev)
+    assert out2["all_rot_err"][0][3] == [out["all_rot_err"][0][3][0], 1000] and out2["all_trans_err"][0][0][1] == 1000
+    assert out2["add"]["per_class"][(cfg.dataset.class_name[0], 3)]["0.10"] == 50.0
 
 
 def test_graph_variants_images_only_and_depth_input(hip_lib):
