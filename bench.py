@@ -33,6 +33,7 @@ import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_32x32x2_f32)
 HBM_PEAK_GBS = 8000.0
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (the 5 PF headline figure includes 2:1 sparsity)
 
 
 def parse_args():
@@ -200,6 +201,26 @@ def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps):
         r["iteration_ms"] = el / steps * 1e3
         r["pair_iterations_per_s"] = B * world * steps / el
         r["finite"] = bool(torch.isfinite(mod.flat_w).all().item())
+        if dtype == "bf16":
+            # per-layer roofline of the bf16 forward convolutions (HIP events on the launch stream, 3 passes): against the dense bf16
+            # MFMA peak and against HBM with the layer's compulsory bytes (fp32 activations in + out, bf16 weights); the bound is the
+            # larger of the two lower limits -- the 8-channel first layer is HBM-bound in bf16 (130 FLOP/B against a ridge of 312)
+            evs = {}
+            for _ in range(3):
+                mod.net.encoder(events=evs)
+            torch.cuda.synchronize()
+            layers = {}
+            for name, lst in evs.items():
+                info = mod.net.layer_info.get(name)
+                if name == "fc6" or not info:
+                    continue
+                ms = sum(e[1].elapsed_time(e[2]) for e in lst) / 3.0
+                nbytes = info["min_bytes"] - 2 * info["N"] * info["K"]   # weights are read as bf16
+                t_mfma, t_hbm = info["flops"] / (BF16_MFMA_PEAK_TFLOPS * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
+                layers[name] = {"ms": round(ms, 4), "TFLOP/s": round(info["flops"] / ms / 1e9, 1), "compulsory_GB/s": round(nbytes / ms / 1e6, 1),
+                                "flop_per_byte": round(info["flops"] / nbytes, 1), "bound": "hbm" if t_hbm > t_mfma else "mfma",
+                                "frac_of_bound": round(max(t_mfma, t_hbm) * 1e3 / ms, 3)}
+            r["forward_conv_layers"] = layers
         res[dtype] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()}
         del mod
     cfg.TEST.FAST_TEST = fast

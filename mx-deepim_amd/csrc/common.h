@@ -89,15 +89,23 @@ struct WGemmArgs {
   int NTN;       // Cout / BN
   int per, rem;  // chunks per workgroup: per, +1 for the first rem workgroups
   unsigned v_bytes, u_bytes, m_bytes;
-  FastDiv d_nch, d_P, d_NTN;
+  FastDiv d_nch, d_P, d_NTN, d_MT;
   int G, BM, BN, tile;  // workgroups of the GEMM launch, its tile shape and id
+  int MT;               // row tiles
+  int plane_major;      // item order, see wcur_decode
 };
 int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile);
 // zeroed = the shared tiles have been zeroed already (by the transform kernel that ran before): no separate zero launch
 int wino_gemm_run(const WGemmArgs& plan, bool zeroed, hipStream_t st);
 
 #ifdef __HIPCC__
-// position in the flat chunk list: item = (mt * NTN + nt) * P + p, chunk ch of it
+// position in the flat chunk list.  Two item orders:
+//   plane_major = 0   item = (mt * NTN + nt) * P + p    (first version: a workgroup's consecutive items walk the 36 planes, i.e. 36
+//                     different weight sets of K x BN floats -- 19 MB for conv3 -- which no L2 holds: every item re-fetched its
+//                     weights from the Infinity Cache, 717 MB per conv3 launch, more than V and M together)
+//   plane_major = 1   item = (p * MT + mt) * NTN + nt   consecutive items are consecutive row tiles of ONE plane; together with the
+//                     XCD-contiguous workgroup numbering below, the ~32 workgroups that share an L2 work inside 4-5 planes at any
+//                     time (2-3 MB of weights), so a plane's weights leave the fabric once per XCD instead of once per item
 struct WCur {
   int ch, p, nt, mt;
 };
@@ -105,12 +113,26 @@ __device__ __forceinline__ WCur wcur_decode(int chunk, const WGemmArgs& a) {
   WCur c;
   const unsigned item = fastdiv((unsigned)chunk, a.d_nch);
   c.ch = chunk - (int)item * a.nch;
-  const unsigned t = fastdiv(item, a.d_P);
-  c.p = (int)(item - t * a.P);
-  const unsigned mt = fastdiv(t, a.d_NTN);
-  c.nt = (int)(t - mt * a.NTN);
-  c.mt = (int)mt;
+  if (a.plane_major) {
+    const unsigned t = fastdiv(item, a.d_NTN);
+    c.nt = (int)(item - t * a.NTN);
+    const unsigned p = fastdiv(t, a.d_MT);
+    c.mt = (int)(t - p * a.MT);
+    c.p = (int)p;
+  } else {
+    const unsigned t = fastdiv(item, a.d_P);
+    c.p = (int)(item - t * a.P);
+    const unsigned mt = fastdiv(t, a.d_NTN);
+    c.nt = (int)(t - mt * a.NTN);
+    c.mt = (int)mt;
+  }
   return c;
+}
+// workgroups are dealt round-robin to the 8 XCDs (blocks b and b + 8 share one L2): number them so that every XCD owns a CONTIGUOUS
+// run of chunk ranges (bijective for any G: the first G % 8 XCDs own one range more)
+__device__ __forceinline__ int wg_xcd_contiguous(int b, int G) {
+  const int x = b & 7, j = b >> 3, q = G >> 3, r = G & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
 }
 __device__ __forceinline__ int wg_first_chunk(int w, const WGemmArgs& a) { return w * a.per + min(w, a.rem); }
 // one 256-thread block zeroes the output tile of the item that the range boundary in front of workgroup w (1 <= w < G) falls into

@@ -19,6 +19,8 @@
 //   V [T][P][K]      row stride P*K floats
 //   U [P][K/32][Cout][32]   = the packed 1x1 weights of conv_fwd_kernel, plane-major: flat chunk index p*K/32 + c
 //   M [T][P][Cout]   row stride P*Cout floats
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dim {
@@ -28,7 +30,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ void wcur_advance(WCur& c, const WGemmArgs& a) {
   if (++c.ch == a.nch) {
     c.ch = 0;
-    if (++c.p == a.P) {
+    if (a.plane_major) {
+      if (++c.nt == a.NTN) {
+        c.nt = 0;
+        if (++c.mt == a.MT) {
+          c.mt = 0;
+          ++c.p;
+        }
+      }
+    } else if (++c.p == a.P) {
       c.p = 0;
       if (++c.nt == a.NTN) {
         c.nt = 0;
@@ -61,8 +71,9 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN
   const int frow = lane & 31;
   const int khalf = lane >> 5;
 
-  const int c_begin = wg_first_chunk(blockIdx.x, a);
-  const int c_end = wg_first_chunk(blockIdx.x + 1, a);
+  const int wg = a.plane_major ? wg_xcd_contiguous(blockIdx.x, a.G) : (int)blockIdx.x;
+  const int c_begin = wg_first_chunk(wg, a);
+  const int c_end = wg_first_chunk(wg + 1, a);
 
   const int RS = a.P * a.K;  // V row stride (floats)
   const int a_voff0 = (srow * RS + q * 4) * 4;
@@ -254,6 +265,10 @@ int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, in
   a.d_nch = make_fastdiv((unsigned)a.nch);
   a.d_P = make_fastdiv((unsigned)P);
   a.d_NTN = make_fastdiv((unsigned)a.NTN);
+  a.MT = (int)MT;
+  a.d_MT = make_fastdiv((unsigned)MT);
+  static const int order = getenv("DIM_WINO_PLANE_MAJOR") ? atoi(getenv("DIM_WINO_PLANE_MAJOR")) : 1;  // A/B switch (0 = first version)
+  a.plane_major = order;
   a.BM = BM;
   a.BN = BN;
   a.tile = tile;

@@ -375,7 +375,7 @@ def conv2d_fwd(x_nhwc, w_packed, bias, Cout, KH, KW, stride, pad, slope=0.1, spl
             e.record()
             return e
         e0 = ev()
-        if splits > 1:
+        if splits > 1 and w_packed.dtype != bf16:
             check(lib().dim_conv2d_fwd_partial(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(workspace, f32), N, H, W, Cin, Cout, KH, KW,
                                                stride, pad, splits, tile, current_stream()))
             e1 = ev()
@@ -384,8 +384,10 @@ def conv2d_fwd(x_nhwc, w_packed, bias, Cout, KH, KW, stride, pad, slope=0.1, spl
             e2 = ev()
             events += [("conv", e0, e1), ("reduce", e1, e2)]
         else:
-            check(lib().dim_conv2d_fwd(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), dptr(workspace, f32), N,
-                                       H, W, Cin, Cout, KH, KW, stride, pad, float(slope), splits, tile, current_stream()))
+            wp, is16 = _wp(w_packed)
+            check((lib().dim_conv2d_fwd_bf16 if is16 else lib().dim_conv2d_fwd)(dptr(x_nhwc, f32), wp, dptr(bias, f32), dptr(out, f32),
+                                                                                 dptr(workspace, f32), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                                                                 float(slope), splits, tile, current_stream()))
             n_launch = 1
             if splits == 0:
                 import ctypes
