@@ -319,7 +319,8 @@ def main():
                     kname = "dim::wino_gemm_kernel<{}>".format(TILE_SYM[info["wino_tile"]])
                     flops, nbytes = info["wino_flops"], info["wino_gemm_bytes"]
                 else:
-                    kname = "dim::conv_fwd_kernel<{}, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
+                    kname = "dim::conv1_halo_kernel<7, 7>" if info["tile"] == 6 else \
+                        "dim::conv_fwd_kernel<{}, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
                     flops, nbytes = info["flops"], info["min_bytes"]
             elif tag == "fc":  # fc6 weight stream (+ its partial-sum reduce inside the event pair)
                 kname, flops, nbytes = "dim::fc_stream_kernel", info["flops"], info["min_bytes"]

@@ -341,6 +341,119 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- first layer, LDS halo
+// flow_conv1 (8 channels, 7x7 / stride 2 / pad 3 -> 64 channels; deepIM_flownet.py:67-75) from an LDS-resident input patch.
+// In conv_fwd_kernel<.., CIN8> this layer was the furthest below its roof (0.60 ms = 103 TFLOP/s at B = 16): only 13 K chunks per
+// workgroup, so the pipeline fill (first gathered loads -> LDS -> barrier) and drain cost ~14 %, another 6 % went into the K padding
+// 392 -> 416, and the 49 taps re-gathered the input 3.7x from beyond L2.  Here a workgroup owns an 8 x 16 block of output pixels x
+// all 64 output channels: it loads the 21 x 37 x 8 input patch ONCE (zero outside the image = the padding), every wave then reads
+// its A fragments for all 49 taps from LDS at shifted addresses (ds_read_b128 with an immediate offset per tap) and runs 392 MFMAs
+// without another barrier or global activation load.  Four workgroups fit a CU (37 KB of LDS each), so one workgroup's patch load
+// and epilogue hide under the MFMAs of the others.  Weights: the packed [chunk][64][32] array of dim_conv2d_pack_weight as it is
+// (a chunk = 4 flat taps x 8 channels, so tap t's 8 channels of an output channel are 32 contiguous bytes), fetched per tap from L2
+// one tap ahead.  K is exactly 392.  Same products, same f32 accumulation chain per output as the direct kernel (k order differs).
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv1_halo_kernel(ConvArgs a) {
+  constexpr int TH = 8, TW = 16;                 // output pixels per workgroup: 4 waves x (2 rows x 16)
+  constexpr int S = 2;
+  constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;   // 21 x 37 input pixels
+  constexpr int PS = 12;                         // floats per patch pixel: 8 channels + 4 pad (48 B: 2-way instead of 4-way conflicts)
+  constexpr int NPIX = PH * PW;
+  __shared__ __attribute__((aligned(16))) float patch[NPIX * PS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_w = (a.Wo + TW - 1) / TW, tiles_h = (a.Ho + TH - 1) / TH;
+  int id = blockIdx.x;
+  const int twi = id % tiles_w;
+  id /= tiles_w;
+  const int thi = id % tiles_h;
+  const int n = id / tiles_h;
+  const int ho0 = thi * TH, wo0 = twi * TW;
+  const int hi0 = ho0 * S - a.pad_h, wi0 = wo0 * S - a.pad_w;
+
+  // ---- patch: 2 float4 per pixel; out-of-image pixels read zeros through the descriptor's range check
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  constexpr int ITEMS = (NPIX * 2 + 255) / 256;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int item = it * 256 + tid;
+    if (item < NPIX * 2) {
+      const int pix = item >> 1, half = item & 1;
+      const int py = pix / PW, px = pix - py * PW;
+      const int hi = hi0 + py, wi = wi0 + px;
+      const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const float4 v = buf_load16(rx, ok ? (((n * a.H + hi) * a.W + wi) * a.in_cstride + half * 4) * 4 : -1, 0);
+      *reinterpret_cast<float4*>(&patch[pix * PS + half * 4]) = v;
+    }
+  }
+  // ---- fragments.  The WEIGHTS are the MFMA's A operand (rows = output channels) and the pixels its B operand (columns), so a
+  // lane ends up with 4 consecutive output channels of ONE pixel per accumulator quad: the epilogue is 8 float4 stores per lane
+  // instead of 32 scalar ones
+  const int frow = lane & 31, khalf = lane >> 5;
+  const int p = wave * 32 + frow;               // output pixel = this lane's B column inside the block
+  const int ty = p / TW, tx = p - ty * TW;
+  const float* abase = &patch[((ty * S) * PW + tx * S) * PS + 4 * khalf];
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  // weight fragment of tap t, output-channel tile j: 16 bytes at ((t / 4) * 64 + 32 j + frow) * 32 + (t % 4) * 8 + 4 khalf floats
+  const int b_voff = (frow * 32 + 4 * khalf) * 4;
+  auto load_b = [&](int t, float4& b0, float4& b1) {
+    const int soff = ((t >> 2) * 64 * 32 + (t & 3) * 8) * 4;
+    b0 = buf_load16(rw, b_voff, soff);
+    b1 = buf_load16(rw, b_voff + 32 * 32 * 4, soff);
+  };
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  float4 b0, b1, nb0, nb1;
+  load_b(0, b0, b1);
+  __syncthreads();
+  float4 fa = *reinterpret_cast<const float4*>(abase);
+  for (int kh = 0; kh < KH; ++kh) {
+    const float* arow = abase + kh * PW * PS;
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw) {
+      const int t = kh * KW + kw;
+      // next tap's operands in flight while this tap multiplies (the one past the end re-reads tap 0: in range, unused)
+      const int tn = (t + 1 < KH * KW) ? t + 1 : 0;
+      load_b(tn, nb0, nb1);
+      const float* anext = (kw + 1 < KW) ? arow + (kw + 1) * PS : ((kh + 1 < KH) ? arow + PW * PS : abase);
+      const float4 nfa = *reinterpret_cast<const float4*>(anext);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.x, fa.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.x, fa.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.y, fa.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.y, fa.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.z, fa.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.z, fa.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0.w, fa.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1.w, fa.w, acc1, 0, 0, 0);
+      fa = nfa;
+      b0 = nb0;
+      b1 = nb1;
+    }
+  }
+  // ---- epilogue.  D layout: col = lane & 31 -> pixel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> output channel (+ 32 for acc1)
+  const int oy = ho0 + ty, ox = wo0 + tx;
+  if (oy < a.Ho && ox < a.Wo) {
+    float* o = a.y + a.out_coff + ((long)(n * a.Ho + oy) * a.Wo + ox) * a.out_cstride + 4 * khalf;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
+      if (a.has_bias) {
+        bv0 = *reinterpret_cast<const float4*>(a.bias + 8 * g + 4 * khalf);
+        bv1 = *reinterpret_cast<const float4*>(a.bias + 32 + 8 * g + 4 * khalf);
+      }
+      float4 v0 = make_float4(acc0[4 * g] + bv0.x, acc0[4 * g + 1] + bv0.y, acc0[4 * g + 2] + bv0.z, acc0[4 * g + 3] + bv0.w);
+      float4 v1 = make_float4(acc1[4 * g] + bv1.x, acc1[4 * g + 1] + bv1.y, acc1[4 * g + 2] + bv1.z, acc1[4 * g + 3] + bv1.w);
+      v0.x = v0.x > 0.f ? v0.x : v0.x * a.slope; v0.y = v0.y > 0.f ? v0.y : v0.y * a.slope;
+      v0.z = v0.z > 0.f ? v0.z : v0.z * a.slope; v0.w = v0.w > 0.f ? v0.w : v0.w * a.slope;
+      v1.x = v1.x > 0.f ? v1.x : v1.x * a.slope; v1.y = v1.y > 0.f ? v1.y : v1.y * a.slope;
+      v1.z = v1.z > 0.f ? v1.z : v1.z * a.slope; v1.w = v1.w > 0.f ? v1.w : v1.w * a.slope;
+      *reinterpret_cast<float4*>(o + 8 * g) = v0;
+      *reinterpret_cast<float4*>(o + 32 + 8 * g) = v1;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- bf16 MFMA
 // The same implicit GEMM on v_mfma_f32_32x32x16_bf16 (16x the f32 matrix rate, f32 accumulate): the training mode of BASELINE
 // configs[2].  Activations stay fp32 in HBM (every other kernel of the graph reads them); a thread rounds its float4 to four bf16
@@ -1012,6 +1125,16 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   hipStream_t st = as_stream(stream);
   if (tile == 0) {
     tile = (Cout % 128 == 0 && Cin != 8 && a.M >= 128) ? 4 : 3;  // same rule as lib/hip/ops.py conv_auto_plan
+  }
+  if (tile == 6) {
+    // the LDS-halo first-layer kernel (conv1_halo_kernel): 8 channels, 7x7 / stride 2, 64 output channels, dense output, no split-K
+    DIM_REQUIRE(Cin == 8 && KH == 7 && KW == 7 && stride == 2 && Cout == 64, "tile 6 is the 8-channel 7x7 / stride-2 / 64-filter first layer");
+    DIM_REQUIRE(splits == 1 && batch == 1 && a.dense_out && !a.accumulate && !a.bf16 && !partial_only,
+                "tile 6: dense single-launch f32 output only");
+    const int tiles = N * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+    DIM_REQUIRE(a.out_cstride % 4 == 0 && a.out_coff % 4 == 0, "tile 6 stores float4: output channel stride / offset must be multiples of 4");
+    hipLaunchKernelGGL((conv1_halo_kernel<7, 7>), dim3(tiles), dim3(256), 0, st, a);
+    return check_launch("conv1_halo");
   }
   DIM_REQUIRE((tile != 1 && tile != 4) || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
   DIM_REQUIRE(Cin != 8 || tile != 4, "tile 4 (128x128, 8 waves) is not built for the 8-channel layer");

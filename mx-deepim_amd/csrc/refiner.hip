@@ -158,6 +158,7 @@ int dim_refiner_create(dim_refiner** out, const dim_refiner_desc* desc, const ch
       P.kind = 0;
       const int nchunks = c == 8 ? (ly.k * ly.k + 3) / 4 : ly.k * ly.k * (c / 32);
       auto_plan(M, ly.cout, nchunks, c, &P.tile, &P.splits);
+      if (c == 8 && ly.k == 7 && ly.s == 2 && ly.cout == 64) { P.tile = 6; P.splits = 1; }  // LDS-halo first-layer kernel, as FlowNetHip
       TRY(dev_alloc(r, (void**)&P.w_packed, (size_t)dim_conv2d_packed_weight_floats(ly.cout, c, ly.k, ly.k) * 4));
       TRY(dim_conv2d_pack_weight(wsrc, P.w_packed, ly.cout, c, ly.k, ly.k, stream));
       if (P.splits != 1) max_ws = std::max(max_ws, dim_conv2d_workspace_floats(B, h, w, c, ly.cout, ly.k, ly.k, ly.s, ly.p, P.splits));

@@ -373,6 +373,9 @@ CONV_CASES = [
     (2, 60, 80, 8, 64, 7, 2, 3, 0, 1),
     (1, 37, 53, 8, 64, 7, 2, 3, 2, 1),
     (1, 37, 53, 8, 64, 7, 2, 3, 3, 1),
+    (2, 60, 80, 8, 64, 7, 2, 3, 6, 1),     # tile 6: the LDS-halo first-layer kernel (8 x 16 output blocks; 30 x 40 = no partial block ...
+    (1, 37, 53, 8, 64, 7, 2, 3, 6, 1),     # ... 19 x 27 outputs: partial blocks on both axes)
+    (3, 22, 18, 8, 64, 7, 2, 3, 6, 1),     # image smaller than one patch
     (2, 30, 40, 64, 128, 5, 2, 2, 1, 1),
     (1, 23, 31, 64, 128, 5, 2, 2, 3, 1),
     (2, 15, 20, 256, 256, 3, 1, 1, 0, 1),
