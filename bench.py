@@ -376,12 +376,18 @@ def main():
         "roofline": roofline,
     }
     if world == 1 and not args.no_fresh_batch and not args.no_graph:
-        out["fresh_batch"] = fresh_batch_bench(cfg, rm, refiner, B, dev, args.steps, args.warmup)
+        try:
+            out["fresh_batch"] = fresh_batch_bench(cfg, rm, refiner, B, dev, args.steps, args.warmup)
+        except Exception as e:
+            out["fresh_batch"] = {"error": "{}: {}".format(type(e).__name__, e)}
     if not args.no_train:
         del refiner, pred
         torch.cuda.empty_cache()
-        out["train"] = train_bench(cfg, models, rm, int(cfg.TRAIN.BATCH_PAIRS) if args.batch_pairs is None else B, dev, rank, world, dist,
-                                   args.train_steps)
+        try:
+            out["train"] = train_bench(cfg, models, rm, int(cfg.TRAIN.BATCH_PAIRS) if args.batch_pairs is None else B, dev, rank, world, dist,
+                                       args.train_steps)
+        except Exception as e:  # the non-headline object must never take the headline line down with it
+            out["train"] = {"error": "{}: {}".format(type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, params, models, batch, args.cpu_pairs)
     if rank == 0:
