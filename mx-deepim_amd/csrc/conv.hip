@@ -671,6 +671,165 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- bf16, LDS halo
+// The bf16 form of the large-map layers from an LDS-resident input patch (tile 7).  conv_bf16_kernel re-gathers its A tile from L2
+// for EVERY tap (10.7 GB of L2 -> LDS traffic per forward at B = 16) and has 4 MFMAs of work per barrier, which leaves every layer
+// at 0.11-0.24 of its bound once the matrix pipe is 16x faster.  Here a workgroup (4 waves, 64 pixels x 64 channels each) owns an
+// 8 x 16 block of output pixels x 128 output channels; per 32-channel slice it stages the ((8-1) S + K) x ((16-1) S + K) input
+// patch once (f32 -> bf16 on the way in, zeros outside the image = the padding) and then walks the K x K taps: the A fragments of a
+// tap are ds_read_b128 at an immediate offset into the patch, the B tile of a tap (128 channels x 32 k, 8 KB of the packed bf16
+// weights: one contiguous block) is staged through LDS two taps at a time, double buffered, so a barrier pair frames 16 MFMAs per
+// wave and the activations leave L2 once per slice instead of once per tap.  Dense output only (forward layers and the stride-1
+// input gradients); everything else stays on conv_bf16_kernel.
+template <int KH, int S>
+__global__ __launch_bounds__(256) void conv_bf16_halo_kernel(ConvArgs a) {
+  constexpr int KW = KH, TAPS = KH * KW;
+  constexpr int TH = 8, TW = 16, BN = 128;
+  constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, NPIX = PH * PW;
+  constexpr int PSE = 40;                        // bf16 elements per patch pixel / per weight row: 32 + 8 pad (80 B)
+  constexpr int STEPS = (TAPS + 1) / 2;          // taps are processed two per barrier pair (the last step of a slice holds one)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* patch = reinterpret_cast<__bf16*>(smem);             // [NPIX][PSE]
+  __bf16* sB = patch + ((NPIX * PSE + 7) / 8) * 8;             // [2 buffers][2 taps][BN][PSE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_w = (a.Wo + TW - 1) / TW, tiles_h = (a.Ho + TH - 1) / TH;
+  const int ntn = a.Cout / BN;
+  int id = blockIdx.x;
+  const int n0 = (id % ntn) * BN;                // output-channel tiles fastest: the workgroups sharing a patch are adjacent
+  id /= ntn;
+  const int twi = id % tiles_w;
+  id /= tiles_w;
+  const int thi = id % tiles_h;
+  const int n = id / tiles_h;
+  const int ho0 = thi * TH, wo0 = twi * TW;
+  const int hi0 = ho0 * S - a.pad_h, wi0 = wo0 * S - a.pad_w;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+
+  // ---- weights: tap t of slice cc is packed chunk cc * TAPS + t; this workgroup's 128 rows of it are 8 KB contiguous.
+  // thread -> 2 x 16 B of a tap (row = idx / 4, 16-byte segment = idx % 4)
+  const int wrow0 = tid >> 2, wseg = tid & 3;
+  const int w_voff0 = ((n0 + wrow0) * 32 + wseg * 8) * 2, w_voff1 = w_voff0 + 64 * 32 * 2;
+  const int w_lds0 = wrow0 * PSE + wseg * 8, w_lds1 = w_lds0 + 64 * PSE;
+  u32x4 wr[2][2];  // [tap of the step][half]
+  const int chunk_bytes = a.Cout * 32 * 2;
+  auto load_w = [&](int chunk_first, int ntaps, bool ok) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bool live = ok && t < ntaps;
+      const int soff = live ? (chunk_first + t) * chunk_bytes : 0;
+      wr[t][0] = __builtin_amdgcn_raw_buffer_load_b128(rw, live ? w_voff0 : -1, soff, 0);
+      wr[t][1] = __builtin_amdgcn_raw_buffer_load_b128(rw, live ? w_voff1 : -1, soff, 0);
+    }
+  };
+  auto store_w = [&](int buf) {
+    __bf16* d = sB + buf * 2 * BN * PSE;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      *reinterpret_cast<u32x4*>(d + t * BN * PSE + w_lds0) = wr[t][0];
+      *reinterpret_cast<u32x4*>(d + t * BN * PSE + w_lds1) = wr[t][1];
+    }
+  };
+
+  // ---- fragments
+  const int frow = lane & 31, khalf = lane >> 5;
+  const int ty_l = frow >> 4, tx = frow & 15;
+  const int a_el = (((4 * wm + ty_l) * S) * PW + tx * S) * PSE + 8 * khalf;   // + (2 i S PW) PSE for MFMA tile i, + tap, + 16 ks
+  const int b_el = (64 * wn + frow) * PSE + 8 * khalf;                        // + 32 j PSE, + 16 ks
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nslices = a.Cin / 32;
+  constexpr int PITEMS = (NPIX * 8 + 255) / 256;   // float4 per thread and patch slice
+  int wbuf = 0;
+  load_w(0, TAPS >= 2 ? 2 : 1, true);
+  for (int cc = 0; cc < nslices; ++cc) {
+    // ---- stage the patch of this channel slice (the previous slice's readers passed the barrier at the end of its last step)
+#pragma unroll
+    for (int it0 = 0; it0 < PITEMS; it0 += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int item = (it0 + u) * 256 + tid;
+        const int pix = item >> 3, q = item & 7;
+        const int py = pix / PW, px = pix - py * PW;
+        const int hi = hi0 + py, wi = wi0 + px;
+        const bool ok = it0 + u < PITEMS && item < NPIX * 8 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        v[u] = buf_load16(rx, ok ? (((n * a.H + hi) * a.W + wi) * a.in_cstride + cc * 32 + q * 4) * 4 : -1, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int item = (it0 + u) * 256 + tid;
+        if (it0 + u < PITEMS && item < NPIX * 8) *reinterpret_cast<bf16x4*>(patch + (item >> 3) * PSE + (item & 7) * 4) = to_bf16x4(v[u]);
+      }
+    }
+    store_w(wbuf);          // the first step's weights (loaded during the previous slice / before the loop)
+    __syncthreads();
+    for (int st = 0; st < STEPS; ++st) {
+      const int ntaps = (2 * st + 2 <= TAPS) ? 2 : 1;
+      // next step's weights in flight under this step's MFMAs (next slice's first step after the last one)
+      {
+        const int nst = st + 1 < STEPS ? st + 1 : 0;
+        const int ncc = st + 1 < STEPS ? cc : cc + 1;
+        load_w(ncc * TAPS + 2 * nst, (2 * nst + 2 <= TAPS) ? 2 : 1, ncc < nslices);
+      }
+      const __bf16* cB = sB + wbuf * 2 * BN * PSE + b_el;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t < ntaps) {
+          const int tap = 2 * st + t;
+          const int kh = tap / KW, kw = tap - kh * KW;
+          const __bf16* pa = patch + a_el + (kh * PW + kw) * PSE;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(pa + (2 * i * S * PW) * PSE + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(cB + t * BN * PSE + 32 * j * PSE + 16 * ks);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      if (st + 1 < STEPS) store_w(wbuf ^ 1);   // (the next slice's first step is stored after its patch, above)
+      __syncthreads();
+      if (st + 1 < STEPS) wbuf ^= 1;
+    }
+    wbuf ^= 1;
+  }
+
+  // ---- epilogue.  D layout: col = lane & 31 -> output channel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> pixel of the tile
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int co = n0 + 64 * wn + 32 * j + frow;
+    const float bv = a.has_bias ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pp = (r & 3) + 8 * (r >> 2) + 4 * khalf;           // 0..31 inside MFMA tile i
+        const int oy = ho0 + 4 * wm + 2 * i + (pp >> 4), ox = wo0 + (pp & 15);
+        if (oy < a.Ho && ox < a.Wo) {
+          float* o = a.y + a.out_coff + ((long)(n * a.Ho + oy) * a.Wo + ox) * a.out_cstride + co;
+          float v = acc[i][j][r] + bv;
+          v = v > 0.f ? v : v * a.slope;
+          if (a.accumulate) v += *o;
+          *o = v;
+        }
+      }
+  }
+}
+
 // element-wise f32 -> bf16 (round to nearest even): the packed weight arrays of the bf16 kernels, the flat gradient bucket
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -1125,6 +1284,32 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   hipStream_t st = as_stream(stream);
   if (tile == 0) {
     tile = (Cout % 128 == 0 && Cin != 8 && a.M >= 128) ? 4 : 3;  // same rule as lib/hip/ops.py conv_auto_plan
+  }
+  if (tile == 7) {
+    // the bf16 LDS-halo kernel (conv_bf16_halo_kernel): square 3x3 or 5x5 taps, stride 1 or 2, Cin % 32 == 0, Cout % 128 == 0, dense
+    DIM_REQUIRE(a.bf16 && KH == KW && (KH == 3 || KH == 5) && (stride == 1 || stride == 2) && Cin % 32 == 0 && Cout % 128 == 0,
+                "tile 7: bf16, 3x3 or 5x5, stride 1 or 2, Cin %% 32 == 0, Cout %% 128 == 0");
+    DIM_REQUIRE(!(KH == 5 && stride == 1), "tile 7: 5x5 is built for stride 2");
+    DIM_REQUIRE(splits == 1 && batch == 1 && a.dense_out && !partial_only, "tile 7: dense single-launch output only");
+    const int blocks = N * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16) * (Cout / 128);
+    const int ph = 7 * stride + KH, pw = 15 * stride + KW;
+    const size_t lds = (size_t)((ph * pw * 40 + 7) / 8 * 8) * 2 + (size_t)2 * 2 * 128 * 40 * 2;
+#define DIM_HALO16(K, S)                                                                                                              \
+  {                                                                                                                                   \
+    static bool attr_set = false;                                                                                                     \
+    if (!attr_set) {                                                                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_kernel<K, S>),                                 \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+      if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));             \
+      attr_set = true;                                                                                                                \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((conv_bf16_halo_kernel<K, S>), dim3(blocks), dim3(256), lds, st, a);                                           \
+  }
+    if (KH == 3 && stride == 1) DIM_HALO16(3, 1)
+    else if (KH == 3) DIM_HALO16(3, 2)
+    else DIM_HALO16(5, 2)
+#undef DIM_HALO16
+    return check_launch("conv_bf16_halo");
   }
   if (tile == 6) {
     // the LDS-halo first-layer kernel (conv1_halo_kernel): 8 channels, 7x7 / stride 2, 64 output channels, dense output, no split-K

@@ -341,6 +341,8 @@ class MutableModule(object):
                 else:
                     # bf16: operand-traffic bound, so the widest tile the channel count allows (dX channels are the GEMM's N)
                     dg_tile = 4 if (self.bf16 and ops.pad64(cin[name]) % 128 == 0) else 3
+                    if (dg_tile == 4 and s == 1 and k == 3 and dy.shape[1] * dy.shape[2] >= 1200 and os.environ.get("DIM_BF16_HALO", "1") != "0"):
+                        dg_tile = 7   # stride-1 input gradient of a large map: LDS-halo kernel
                     ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False,
                                      tile=dg_tile)
         self._bucket_ready(None)

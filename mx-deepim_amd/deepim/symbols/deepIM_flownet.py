@@ -221,6 +221,14 @@ class FlowNetHip(object):
                 h, w = ops.conv_out_hw(h, w, k, k, s, p)
                 tiles = -(-batch_size * h * w // 128) * (cout // 128) if cout % 128 == 0 else 0
                 self.conv_plan[name] = (4 if (cout % 128 == 0 and c != 8) else 3, 1 if (tiles == 0 or tiles >= 256) else min(4, -(-512 // tiles)))
+                # 3x3 / stride-1 layers on large maps: the LDS-halo kernel (conv.hip conv_bf16_halo_kernel, tile 7).  Measured at B = 16
+                # against the gathered-tap kernel: conv3_1 0.150 vs 0.161 ms, conv4_1 0.175 vs 0.177; the stride-2 layers lose (conv2
+                # 0.366 vs 0.256, conv3 0.286 vs 0.247, conv4 0.143 vs 0.102: their 45-53 KB patches + 41 KB of weight buffers leave
+                # one 4-wave workgroup per CU), so they stay where they were.  DIM_BF16_HALO=0: gathered-tap kernel everywhere; =2: every
+                # eligible layer on tile 7 (the A/B above)
+                halo = os.environ.get("DIM_BF16_HALO", "1")
+                if c % 32 == 0 and cout % 128 == 0 and h * w >= 1200 and ((halo == "1" and k == 3 and s == 1) or (halo == "2" and k in (3, 5))):
+                    self.conv_plan[name] = (7, 1)
                 c = cout
         if conv_plan:
             self.conv_plan.update(conv_plan)

@@ -57,6 +57,13 @@ FWD_CASES = [
     (2, 15, 20, 512, 512, 3, 1, 1, 3, 3),
     (2, 8, 10, 512, 1024, 3, 2, 1, 4, 4),
     (1, 9, 11, 32, 64, 3, 1, 0, 2, 1),
+    # tile 7: the LDS-halo kernel (8 x 16 output blocks x 128 channels; partial blocks, several channel slices, both strides)
+    (2, 30, 40, 64, 128, 5, 2, 2, 7, 1),
+    (1, 23, 31, 64, 128, 5, 2, 2, 7, 1),
+    (2, 15, 20, 256, 256, 3, 1, 1, 7, 1),
+    (2, 15, 20, 256, 512, 3, 2, 1, 7, 1),
+    (1, 37, 53, 32, 128, 3, 1, 1, 7, 1),
+    (3, 9, 11, 96, 128, 3, 2, 1, 7, 1),
 ]
 
 
@@ -83,6 +90,7 @@ BWD_CASES = [
     (2, 9, 11, 128, 64, 3, 2, 1, 1),
     (1, 17, 23, 64, 128, 5, 2, 2, 1),
     (2, 8, 10, 256, 512, 3, 1, 1, 1),
+    (1, 21, 35, 128, 256, 3, 1, 1, 2),
     (3, 13, 9, 32, 64, 3, 1, 1, 2),    # one chunk column group only partly filled (9 chunks, 4 per workgroup)
 ]
 
@@ -105,6 +113,11 @@ def test_dgrad_wgrad_bf16(ops, case):
     got = dx[..., :Cin].permute(0, 3, 1, 2).cpu().double().numpy()
     assert np.abs(got - xr.grad.numpy()).max() <= 1e-4 * xr.grad.abs().max().item() + 1e-5
     assert l2rel(got, xf.grad.numpy()) <= L2_BAR
+    if s == 1 and ops.pad64(Cin) % 128 == 0:   # stride-1 input gradients may take the LDS-halo kernel too
+        dx7 = torch.empty((N, H, W, ops.pad64(Cin)), device=DEV)
+        ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dx7, Cin, k, k, s, p, accumulate=False, tile=7)
+        got7 = dx7[..., :Cin].permute(0, 3, 1, 2).cpu().double().numpy()
+        assert np.abs(got7 - xr.grad.numpy()).max() <= 1e-4 * xr.grad.abs().max().item() + 1e-5
     dwp = torch.zeros_like(ops.conv2d_pack_weight(w.float().to(DEV)))
     ops.conv2d_wgrad(nhwc(x.float()), Cin, nhwc(dy.float()), Cout, k, k, s, p, dwp, splits=splits, bf16_mfma=True)
     ref = ops.conv2d_pack_weight(wr.grad.float().to(DEV))
