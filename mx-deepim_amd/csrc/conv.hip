@@ -438,9 +438,10 @@ __global__ __launch_bounds__(256) void conv1_halo_kernel(ConvArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
-      if (a.has_bias) {
-        bv0 = *reinterpret_cast<const float4*>(a.bias + 8 * g + 4 * khalf);
-        bv1 = *reinterpret_cast<const float4*>(a.bias + 32 + 8 * g + 4 * khalf);
+      if (a.has_bias) {  // scalar loads: the bias may be a 4-byte-aligned slice of a flat parameter vector
+        const float* b0p = a.bias + 8 * g + 4 * khalf;
+        bv0 = make_float4(b0p[0], b0p[1], b0p[2], b0p[3]);
+        bv1 = make_float4(b0p[32], b0p[33], b0p[34], b0p[35]);
       }
       float4 v0 = make_float4(acc0[4 * g] + bv0.x, acc0[4 * g + 1] + bv0.y, acc0[4 * g + 2] + bv0.z, acc0[4 * g + 3] + bv0.w);
       float4 v1 = make_float4(acc1[4 * g] + bv1.x, acc1[4 * g + 1] + bv1.y, acc1[4 * g + 2] + bv1.z, acc1[4 * g + 3] + bv1.w);
@@ -1317,7 +1318,8 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
     DIM_REQUIRE(splits == 1 && batch == 1 && a.dense_out && !a.accumulate && !a.bf16 && !partial_only,
                 "tile 6: dense single-launch f32 output only");
     const int tiles = N * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
-    DIM_REQUIRE(a.out_cstride % 4 == 0 && a.out_coff % 4 == 0, "tile 6 stores float4: output channel stride / offset must be multiples of 4");
+    DIM_REQUIRE(a.out_cstride % 4 == 0 && a.out_coff % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
+                "tile 6 stores float4: output channel stride / offset must be multiples of 4 and y 16-byte aligned");
     hipLaunchKernelGGL((conv1_halo_kernel<7, 7>), dim3(tiles), dim3(256), 0, st, a);
     return check_launch("conv1_halo");
   }

@@ -96,6 +96,11 @@ int dim_test_blobs_from_raw(const unsigned char* obs_bgr, const unsigned char* r
   DIM_REQUIRE(pixel_means_bgr3, "null pointer");
   DIM_REQUIRE(W % 4 == 0 && H > 0 && depth_factor > 0.f, "W must be a multiple of 4, depth_factor positive");
   DIM_REQUIRE(!(mask_rendered || bbox) || depth_rendered, "mask_rendered / bbox need depth_rendered");
+  DIM_REQUIRE(((reinterpret_cast<uintptr_t>(obs_bgr) | reinterpret_cast<uintptr_t>(ren_bgr)) & 3) == 0 &&
+                  (reinterpret_cast<uintptr_t>(depth_rendered) & 7) == 0 &&
+                  ((reinterpret_cast<uintptr_t>(image_observed) | reinterpret_cast<uintptr_t>(image_rendered) |
+                    reinterpret_cast<uintptr_t>(mask_rendered)) & 15) == 0,
+              "pointer alignment: raw images 4 bytes, raw depth 8 bytes, float planes 16 bytes");
   hipStream_t st = as_stream(stream);
   if (bbox) hipLaunchKernelGGL(blobs_bbox_init_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, bbox, B, H, W);
   hipLaunchKernelGGL(test_blobs_from_raw_kernel, dim3(ceil_div((long)H * W / 4, 256), B), dim3(256), 0, st, obs_bgr, ren_bgr, depth_rendered,

@@ -541,7 +541,10 @@ static int raster_render_impl(const float* verts, const float* normals, const fl
   hipLaunchKernelGGL(raster_init_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, bbox, B, H, W, hdr);
   float p0 = plane_means3 ? plane_means3[0] : 0.f, p1 = plane_means3 ? plane_means3[1] : 0.f, p2 = plane_means3 ? plane_means3[2] : 0.f;
   LitArgs lit = {verts, normals, poses, light_pos, light_int, ratio};
-  if (W % 4 == 0) {
+  auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // the two-pass resolve moves float4 / 2 x u64: every plane pointer (and the workspace) must be 16-byte aligned; anything else
+  // takes the one-thread-per-pixel kernel
+  if (W % 4 == 0 && aligned16(workspace) && aligned16(image) && aligned16(depth) && aligned16(mask) && aligned16(bgr)) {
     // pass 1 streams the z-buffer once and finishes depth / mask / bbox / background; pass 2 colours the listed pixels on full waves
     hipLaunchKernelGGL(raster_resolve_stream_kernel, dim3(ceil_div((long)H * W / 4, 256), B), dim3(256), 0, st, zbuf, H, W, p0, p1, p2,
                        mask_thr, image, depth, mask, bgr, bbox, hdr, list);
