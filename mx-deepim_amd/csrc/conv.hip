@@ -17,6 +17,7 @@
 // and dim_splitk_reduce finishes (deterministic, no atomics).
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -43,6 +44,7 @@ struct ConvArgs {
   int dense_out, OH, OW, osy, osx, ooy, oox;
   int accumulate;  // out += v (final pass only)
   unsigned x_bytes, w_bytes;  // extents of x / w for the buffer descriptors (loads past them return 0)
+  unsigned y_bytes;           // extent of one output problem (kernels that store through a descriptor: tile 9)
   int xcd_chunk;   // > 0: workgroup id -> tile remap that keeps consecutive tiles on one XCD (see conv_fwd_kernel)
   FastDiv div_kw;  // 8-channel layer: flat tap index -> (kh, kw)
   int boy, box;    // batched launch with scattered output: problem b lands at (ooy + (b >> 1) boy, oox + (b & 1) box) (deconv phases)
@@ -52,6 +54,81 @@ struct ConvArgs {
   long slab_stride;  // elements between the slabs of consecutive splits
   int bf16;          // weights are packed bf16, products on v_mfma_f32_32x32x16_bf16 (conv_bf16_kernel)
 };
+
+// Epilogue of the gathered-tap kernels (f32 and bf16): bias + LeakyReLU (+ accumulate) and the store of a wave's TM x TN accumulator
+// tiles.  D layout: col = lane & 31 -> output channel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> GEMM row of the tile.
+// Every store goes through a buffer descriptor and a row outside the output gets byte offset 0xFFFFFFFF, which the range check drops:
+// no branches.  With a per-row `if` hipcc opens each block with `s_waitcnt vmcnt(0)` (the bias load is still "pending" across the
+// block boundary), and on gfx950 vmcnt also counts the stores -- the wave's 32 .. 128 stores then leave one round trip (~0.2 us) at a
+// time.  Round 1 gave the f32 full-tile path its own branch-free loop for that reason; the partial tiles, the scattered output of the
+// deconvolution / strided-gradient phases, the accumulate path and the whole bf16 twin still paid it (6 us per workgroup of a bf16
+// layer whose main loop is 7 us).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_store_tiles(const ConvArgs& a, const f32x16 (&acc)[TM][TN], float* yb, int mrow, int ncol, int split) {
+  const bool final = gridDim.z == 1;
+  const int ldc = final ? a.out_cstride : a.Cout;
+  float* base = final ? yb : yb + (long)split * a.slab_stride;
+  const unsigned extent = final ? a.y_bytes : (unsigned)((long)(a.M - a.slab_row0) * a.Cout * 4);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(base, 0, extent, 0x00020000);
+  float bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bv[j] = (final && a.has_bias) ? a.bias[ncol + 32 * j] : 0.f;
+  const float slope = final ? a.slope : 1.0f;
+  int voff[TM][16];   // byte offset of the row's channel ncol (tile j: + 128 j bytes), -1 = not stored
+  if (!final || a.dense_out) {
+    const int col_b = ((final ? a.out_coff : 0) + ncol) * 4, row0 = final ? 0 : a.slab_row0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow + 32 * i + (r & 3) + 8 * (r >> 2);
+        voff[i][r] = m < a.M ? (m - row0) * (ldc * 4) + col_b : -1;
+      }
+  } else {
+    // scattered output (deconvolution phase + Crop, strided-gradient phase): row m = (n, ho, wo) lands at (n, ho*osy+ooy, wo*osx+oox)
+    // if that is inside OH x OW
+    const int oyb = a.ooy + (int)(blockIdx.y >> 1) * a.boy, oxb = a.oox + (int)(blockIdx.y & 1) * a.box;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow + 32 * i + (r & 3) + 8 * (r >> 2);
+        const int mm = m < a.M ? m : 0;
+        const int wo = mm % a.Wo, t = mm / a.Wo;
+        const int ho = t % a.Ho, n = t / a.Ho;
+        const int oy = ho * a.osy + oyb, ox = wo * a.osx + oxb;
+        const bool ok = m < a.M && (unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW;
+        voff[i][r] = ok ? (((n * a.OH + oy) * a.OW + ox) * ldc + a.out_coff + ncol) * 4 : -1;
+      }
+  }
+  if (final && a.accumulate) {   // wave-uniform: out += result
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, voff[i][r], 128 * j, 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv[j];
+          v = (v > 0.f ? v : v * slope) + old[r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff[i][r], 128 * j, 0);
+        }
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv[j];
+          v = v > 0.f ? v : v * slope;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff[i][r], 128 * j, 0);
+        }
+  }
+}
 
 template <int BM, int BN, int WM, int WN, bool CIN8>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
@@ -269,76 +346,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvArgs a) {
 #undef DIM_STORE_A
 #undef DIM_STORE_CHUNK
 
-  // ---- epilogue.  D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  // Full tiles take a branch-free path: with a per-store `if (m < M)` hipcc put `s_waitcnt vmcnt(0)` in front of every
-  // predicated store (the bias load keeps the counter "unknown" across the branches), serialising 16 store round trips
-  // per wave.
-  const bool final = gridDim.z == 1;
-  const int ldc = final ? a.out_cstride : a.Cout;
-  const int ncol = n0 + wn * (BN / WN) + frow;
-  float bv[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) bv[j] = (final && a.has_bias) ? a.bias[ncol + 32 * j] : 0.f;
-  const float slope = final ? a.slope : 1.0f;
-  const bool acc_out = final && a.accumulate;
-  const int mrow = m0 + wm * (BM / WM) + 4 * khalf;
-  if (!final || a.dense_out) {
-    float* out = (final ? yb + a.out_coff + (long)mrow * ldc : yb + (long)split * a.slab_stride + (long)(mrow - a.slab_row0) * ldc) + ncol;
-    if (m0 + BM <= a.M) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[i][j][r] + bv[j];
-            v = v > 0.f ? v : v * slope;
-            float* o = out + (long)(32 * i + (r & 3) + 8 * (r >> 2)) * ldc + 32 * j;
-            if (acc_out) v += *o;
-            *o = v;
-          }
-    } else {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dm = 32 * i + (r & 3) + 8 * (r >> 2);
-            if (mrow + dm < a.M) {
-              float v = acc[i][j][r] + bv[j];
-              v = v > 0.f ? v : v * slope;
-              if (acc_out) v += out[(long)dm * ldc + 32 * j];
-              out[(long)dm * ldc + 32 * j] = v;
-            }
-          }
-    }
-  } else {
-    // scattered output (deconvolution phase + Crop): row m = (n, ho, wo) lands at (n, ho*osy+ooy, wo*osx+oox) if inside OH x OW
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mrow + 32 * i + (r & 3) + 8 * (r >> 2);
-        if (m < a.M) {
-          int wo = m % a.Wo;
-          int t = m / a.Wo;
-          int ho = t % a.Ho;
-          int n = t / a.Ho;
-          int oy = ho * a.osy + a.ooy + (int)(blockIdx.y >> 1) * a.boy, ox = wo * a.osx + a.oox + (int)(blockIdx.y & 1) * a.box;
-          if ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW) {
-            float* o = yb + a.out_coff + ((long)(n * a.OH + oy) * a.OW + ox) * ldc + ncol;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              float v = acc[i][j][r] + bv[j];
-              v = v > 0.f ? v : v * slope;
-              if (acc_out) v += o[32 * j];
-              o[32 * j] = v;
-            }
-          }
-        }
-      }
-  }
+  // ---- epilogue (conv_store_tiles above: branch-free buffer stores)
+  conv_store_tiles<TM, TN>(a, acc, yb, m0 + wm * (BM / WM) + 4 * khalf, n0 + wn * (BN / WN) + frow, split);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- first layer, LDS halo
@@ -619,57 +628,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(ConvArgs a) {
     if (kc + 1 < kc_end) chunk_body(std::integral_constant<int, 1>{}, kc + 1);
   }
 
-  // ---- epilogue: as conv_fwd_kernel (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-  const bool final = gridDim.z == 1;
-  const int ldc = final ? a.out_cstride : a.Cout;
-  const int ncol = n0 + wn * (BN / WN) + frow;
-  float bv[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) bv[j] = (final && a.has_bias) ? a.bias[ncol + 32 * j] : 0.f;
-  const float slope = final ? a.slope : 1.0f;
-  const bool acc_out = final && a.accumulate;
-  const int mrow = m0 + wm * (BM / WM) + 4 * khalf;
-  if (!final || a.dense_out) {
-    float* out = (final ? yb + a.out_coff + (long)mrow * ldc : yb + (long)split * a.slab_stride + (long)(mrow - a.slab_row0) * ldc) + ncol;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dm = 32 * i + (r & 3) + 8 * (r >> 2);
-          if (mrow + dm < a.M) {
-            float v = acc[i][j][r] + bv[j];
-            v = v > 0.f ? v : v * slope;
-            if (acc_out) v += out[(long)dm * ldc + 32 * j];
-            out[(long)dm * ldc + 32 * j] = v;
-          }
-        }
-  } else {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mrow + 32 * i + (r & 3) + 8 * (r >> 2);
-        if (m < a.M) {
-          int wo = m % a.Wo;
-          int t = m / a.Wo;
-          int ho = t % a.Ho;
-          int n = t / a.Ho;
-          int oy = ho * a.osy + a.ooy + (int)(blockIdx.y >> 1) * a.boy, ox = wo * a.osx + a.oox + (int)(blockIdx.y & 1) * a.box;
-          if ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW) {
-            float* o = yb + a.out_coff + ((long)(n * a.OH + oy) * a.OW + ox) * ldc + ncol;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              float v = acc[i][j][r] + bv[j];
-              v = v > 0.f ? v : v * slope;
-              if (acc_out) v += o[32 * j];
-              o[32 * j] = v;
-            }
-          }
-        }
-      }
-  }
+  // ---- epilogue (conv_store_tiles above: branch-free buffer stores)
+  conv_store_tiles<TM, TN>(a, acc, yb, m0 + wm * (BM / WM) + 4 * khalf, n0 + wn * (BN / WN) + frow, split);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- bf16, LDS halo
@@ -809,25 +769,288 @@ __global__ __launch_bounds__(256) void conv_bf16_halo_kernel(ConvArgs a) {
     wbuf ^= 1;
   }
 
-  // ---- epilogue.  D layout: col = lane & 31 -> output channel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> pixel of the tile
+  // ---- epilogue.  D layout: col = lane & 31 -> output channel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> pixel of the tile.
+  // Branch-free buffer stores (see conv_store_tiles): a pixel outside the map gets offset 0xFFFFFFFF and is dropped.
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+  int voff[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pp = (r & 3) + 8 * (r >> 2) + 4 * khalf;           // 0..31 inside MFMA tile i
+      const int oy = ho0 + 4 * wm + 2 * i + (pp >> 4), ox = wo0 + (pp & 15);
+      voff[i][r] = (oy < a.Ho && ox < a.Wo) ? (((n * a.Ho + oy) * a.Wo + ox) * a.out_cstride + a.out_coff + n0 + 64 * wn + frow) * 4 : -1;
+    }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int co = n0 + 64 * wn + 32 * j + frow;
-    const float bv = a.has_bias ? a.bias[co] : 0.f;
+    const float bv = a.has_bias ? a.bias[n0 + 64 * wn + 32 * j + frow] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        old[r] = a.accumulate ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, voff[i][r], 128 * j, 0)) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int pp = (r & 3) + 8 * (r >> 2) + 4 * khalf;           // 0..31 inside MFMA tile i
-        const int oy = ho0 + 4 * wm + 2 * i + (pp >> 4), ox = wo0 + (pp & 15);
-        if (oy < a.Ho && ox < a.Wo) {
-          float* o = a.y + a.out_coff + ((long)(n * a.Ho + oy) * a.Wo + ox) * a.out_cstride + co;
-          float v = acc[i][j][r] + bv;
-          v = v > 0.f ? v : v * a.slope;
-          if (a.accumulate) v += *o;
-          *o = v;
+        float v = acc[i][j][r] + bv;
+        v = (v > 0.f ? v : v * a.slope) + old[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff[i][r], 128 * j, 0);
+      }
+    }
+  }
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---------------------------------------------------------------------------------------------------------------- bf16, stride-1 patch
+// Tile 9: every stride-1 bf16 convolution with a small rectangular tap set (KH, KW <= 3) on a large map -- the 3x3 forward layers,
+// their input gradients, and the stride-1 phase convolutions a stride-2 input gradient or a 4x4 / stride-2 deconvolution splits into
+// (2x2, 2x3, 3x2, 3x3 taps, scattered output).  PMC on the kernels above (bf16 training iteration): waves parked on s_waitcnt /
+// barriers 60 % of their life, matrix pipe busy 12-26 % -- conv_bf16_kernel moves 12.7 TB/s out of L2 (the gather repeats per
+// tap), conv_bf16_halo_kernel awaits its weight tiles and its patch with one step of flight time.  Here
+//  * a workgroup (4 waves, 2 x 2) owns a 16 x 16 block of output pixels x 128 output channels, a wave 128 pixels x 64 channels
+//    (8 accumulator tiles): 16 MFMAs per tap and k-slice against 8 LDS fragment reads and 4 weight-fragment loads;
+//  * the (16+KH-1) x (16+KW-1) input patch of a 32-channel slice lives in LDS (f32 -> bf16 on the way in, zeros outside the image
+//    = the padding), double buffered: the next slice's patch is fetched in batches at the first taps of the current slice, each
+//    batch converted and stored one tap after the next one was issued -- two taps of flight time, ONE barrier per slice;
+//  * the weights never touch LDS: a lane's B fragment is 16 contiguous bytes of the packed bf16 array (chunk = slice * taps + tap),
+//    loaded NSETS-1 taps ahead into a rotating register set;
+//  * patch rows are 1536 B apart (a multiple of 256 B) and pixels 80 B: a ds_read_b128 lane group ({0-3,12-15,20-27}: two pixel
+//    rows of an MFMA tile) then covers all 64 banks exactly once.
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
+  constexpr int NT = KH * KW;
+  constexpr int TH = 16, TW = 16, BN = 128;
+  constexpr int PH = TH + KH - 1, PW = TW + KW - 1;
+  constexpr int PXB = 80, PITCH = 1536, PBUF = PH * PITCH;
+  constexpr int NITEM = PH * PW * 8;                 // float4 pieces of one patch slice
+  constexpr int PITEMS = (NITEM + 255) / 256;        // per thread
+  constexpr int NSETS = NT % 3 == 0 ? 3 : (NT % 4 == 0 ? 4 : 2);
+  constexpr int PF = NSETS - 1;                      // weight prefetch distance in taps
+  constexpr int IPT = (PITEMS + (NT > 1 ? NT - 2 : 0)) / (NT > 1 ? NT - 1 : 1);   // patch pieces fetched per tap (taps 0 .. NT-2)
+  static_assert(NT >= 2 && NT % NSETS == 0 && PW * PXB <= PITCH && IPT * (NT - 1) >= PITEMS, "tap plan");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* patch = reinterpret_cast<char*>(smem);       // [2][PH][PITCH] bytes + 256 B dump slot
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_w = (a.Wo + TW - 1) / TW, tiles_h = (a.Ho + TH - 1) / TH;
+  const int ntn = a.Cout / BN;
+  int id = blockIdx.x;
+  const int n0 = (id % ntn) * BN;   // channel tiles fastest: the workgroups sharing a patch are neighbours in launch order
+  id /= ntn;
+  const int twi = id % tiles_w;
+  id /= tiles_w;
+  const int thi = id % tiles_h;
+  const int n = id / tiles_h;
+  const int ho0 = thi * TH, wo0 = twi * TW;
+  const int hi0 = ho0 - a.pad_h, wi0 = wo0 - a.pad_w;
+  const float* xb = a.x + (long)blockIdx.y * a.bx;
+  const char* wb = reinterpret_cast<const char*>(a.w) + (long)blockIdx.y * a.bw * 2;
+  float* yb = a.y + (long)blockIdx.y * a.by;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wb), 0, a.w_bytes, 0x00020000);
+  const int nslices = a.Cin / 32;
+  const int chunk_bytes = a.Cout * 64;
+
+  // ---- patch pieces of this thread: global byte offset of slice 0 (-1: outside the image / past the patch), LDS byte offset
+  int p_goff[PITEMS], p_loff[PITEMS];
+#pragma unroll
+  for (int u = 0; u < PITEMS; ++u) {
+    const int item = u * 256 + tid;
+    const int pix = item >> 3, q = item & 7;
+    const int py = pix / PW, px = pix - py * PW;
+    const int hi = hi0 + py, wi = wi0 + px;
+    const bool ok = item < NITEM && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+    p_goff[u] = ok ? (((n * a.H + hi) * a.W + wi) * a.in_cstride + q * 4) * 4 : -1;
+    p_loff[u] = item < NITEM ? py * PITCH + px * PXB + q * 8 : -1;
+  }
+
+  // ---- fragments
+  const int frow = lane & 31, khalf = lane >> 5;
+  const int a_off = (8 * wm + (frow >> 4)) * PITCH + (frow & 15) * PXB + 16 * khalf;   // + 2 i PITCH, + kh PITCH + kw PXB, + 32 ks
+  const int b_voff = ((n0 + 64 * wn + frow) * 32 + 8 * khalf) * 2;                      // + 32 j rows, + 16 ks elements
+  bf16x8 fb[NSETS][2][2];   // [set][k-step][channel tile]
+  auto load_b = [&](auto SET, int chunk) {
+    constexpr int set = decltype(SET)::value;
+    const int soff = chunk * chunk_bytes;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff + (32 * j * 32 + 16 * ks) * 2, soff, 0);
+        fb[set][ks][j] = *reinterpret_cast<bf16x8*>(&v);
+      }
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: patch of slice 0 (exposed once), weight sets of taps 0 .. PF-1
+  {
+    float4 v[PITEMS];
+#pragma unroll
+    for (int u = 0; u < PITEMS; ++u) v[u] = buf_load16(rx, p_goff[u], 0);
+#pragma unroll
+    for (int u = 0; u < PITEMS; ++u)
+      if (p_loff[u] >= 0) *reinterpret_cast<bf16x4*>(patch + p_loff[u]) = to_bf16x4(v[u]);
+  }
+  const int last_chunk = a.nchunks - 1;
+  if constexpr (PF >= 1) load_b(std::integral_constant<int, 0>{}, 0);
+  if constexpr (PF >= 2) load_b(std::integral_constant<int, 1>{}, min(1, last_chunk));
+  if constexpr (PF >= 3) load_b(std::integral_constant<int, 2>{}, min(2, last_chunk));
+  __syncthreads();
+
+  int buf = 0;
+  float4 st[2][IPT];   // two batches of patch pieces in flight
+  bf16x8 fa[2][2][4];  // [tap parity][k-step][pixel tile]
+  auto load_a = [&](auto SET, const char* pc, auto TAP) {
+    constexpr int set = decltype(SET)::value, tap = decltype(TAP)::value;
+    constexpr int kh = tap / KW, kw = tap - kh * KW;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[set][ks][i] = *reinterpret_cast<const bf16x8*>(pc + (kh + 2 * i) * PITCH + kw * PXB + 32 * ks);
+  };
+  for (int cc = 0; cc < nslices; ++cc) {
+    const char* pcur = patch + buf * PBUF + a_off;
+    load_a(std::integral_constant<int, 0>{}, pcur, std::integral_constant<int, 0>{});   // tap 0: after the barrier that published this patch
+    char* pnext = patch + (buf ^ 1) * PBUF;
+    const int next_soff = (cc + 1) * 128;           // byte offset of the next slice's channels
+    const bool have_next = cc + 1 < nslices;
+    const int g0 = cc * NT;
+    static_for<NT>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      // One scheduling region per tap.  Program order: patch pieces of batch t (next slice) and the weights of tap t + PF, the A
+      // fragments of tap t + 1, the 16 MFMAs of tap t, rounding + LDS stores of batch t - 1.  With one wave per SIMD nothing else
+      // fills the matrix pipe while the wave issues loads / LDS traffic / VALU, so the sched_group_barrier sequence below deals
+      // them out one small group behind each MFMA (an MFMA holds the issue port 8 of its 32 cycles); without it hipcc either sinks
+      // the loads to their first use (prefetch distance gone, one load even inside a branch followed by vmcnt(0)) or, fenced into
+      // blocks, leaves the pipe idle during every non-MFMA block (measured: 43 % MFMA-busy inside a wave's life).
+      constexpr int NLD = (t < NT - 1 ? (IPT < PITEMS - t * IPT ? IPT : (PITEMS - t * IPT > 0 ? PITEMS - t * IPT : 0)) : 0) + 4;
+      constexpr int NST = t >= 1 ? (IPT < PITEMS - (t - 1) * IPT ? IPT : (PITEMS - (t - 1) * IPT > 0 ? PITEMS - (t - 1) * IPT : 0)) : 0;
+      if (t < NT - 1) {
+#pragma unroll
+        for (int e = 0; e < IPT; ++e) {
+          const int u = t * IPT + e;
+          if (u < PITEMS) st[t & 1][e] = buf_load16(rx, (have_next && p_goff[u] >= 0) ? p_goff[u] + next_soff : -1, 0);
         }
       }
+      load_b(std::integral_constant<int, (t + PF) % NSETS>{}, min(g0 + t + PF, last_chunk));
+      if constexpr (t + 1 < NT) load_a(std::integral_constant<int, (t + 1) & 1>{}, pcur, std::integral_constant<int, t + 1>{});
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][ks][i], fb[t % NSETS][ks][j], acc[i][j], 0, 0, 0);
+      if (t >= 1) {
+#pragma unroll
+        for (int e = 0; e < IPT; ++e) {
+          const int u = (t - 1) * IPT + e;
+          if (u < PITEMS) {
+            char* dst = p_loff[u] >= 0 ? pnext + p_loff[u] : patch + 2 * PBUF + (tid & 31) * 8;
+            *reinterpret_cast<bf16x4*>(dst) = to_bf16x4(st[(t - 1) & 1][e]);
+          }
+        }
+      }
+      static_for<16>([&](auto Mi) {
+        constexpr int m = decltype(Mi)::value;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // one MFMA
+        if constexpr (m < NLD) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                     // address arithmetic of ...
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // ... one global load
+        }
+        if constexpr (m < 8 && t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one A-fragment read
+        if constexpr (m >= 16 - NST) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                     // round one piece ...
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                     // ... and store it
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // LDS-only barrier: the weight loads of the next taps stay in flight across it (__syncthreads would drain them)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    buf ^= 1;
+  }
+
+  // ---- epilogue.  D layout: col = lane & 31 -> output channel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> pixel of the MFMA tile.
+  // Branch-free: a pixel outside the output is a buffer store at offset 0xFFFFFFFF, which the range check drops.  (Stores inside
+  // per-element `if` blocks cost 26 us per workgroup here: hipcc opens every block with s_waitcnt vmcnt(0) -- the bias load is
+  // still "pending" at the block boundary -- and on gfx950 vmcnt also counts the stores, so the 128 stores went out one round
+  // trip at a time.)
+  const int by = blockIdx.y;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yb, 0, a.y_bytes, 0x00020000);
+  const int oy_base = a.ooy + (by >> 1) * a.boy, ox_base = a.oox + (by & 1) * a.box;
+  // this lane's 64 pixel slots: row 8 wm + 2 i + (r >> 3), column 4 khalf + (r & 3) + 8 ((r >> 2) & 1) of the 16 x 16 block; the byte
+  // offset is affine in both (channel co of tile j = + 128 j bytes), and a block that lies inside the output needs no per-pixel test
+  const int hob = ho0 + 8 * wm, wob = wo0 + 4 * khalf;
+  const int row_b = a.osy * a.OW * a.out_cstride * 4, col_b = a.osx * a.out_cstride * 4;
+  const int base_b = (((n * a.OH + hob * a.osy + oy_base) * a.OW + wob * a.osx + ox_base) * a.out_cstride + a.out_coff + n0 + 64 * wn + frow) * 4;
+  const bool inside = ho0 + TH <= a.Ho && wo0 + TW <= a.Wo && ho0 * a.osy + oy_base >= 0 && (ho0 + TH - 1) * a.osy + oy_base < a.OH &&
+                      wo0 * a.osx + ox_base >= 0 && (wo0 + TW - 1) * a.osx + ox_base < a.OW;   // workgroup-uniform
+  int voff[4][16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = 2 * i + (r >> 3), dc = (r & 3) + 8 * ((r >> 2) & 1);
+      voff[i][r] = base_b + dr * row_b + dc * col_b;
+    }
+  if (!inside) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ho = hob + 2 * i + (r >> 3), wo = wob + (r & 3) + 8 * ((r >> 2) & 1);
+        const int oy = ho * a.osy + oy_base, ox = wo * a.osx + ox_base;
+        const bool ok = ho < a.Ho && wo < a.Wo && (unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW;
+        voff[i][r] = ok ? voff[i][r] : -1;
+      }
+  }
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bv[j] = a.has_bias ? a.bias[n0 + 64 * wn + 32 * j + frow] : 0.f;
+  if (a.accumulate) {   // wave-uniform: out += result (gradients that meet in one buffer)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, voff[i][r], 128 * j, 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv[j];
+          v = (v > 0.f ? v : v * a.slope) + old[r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff[i][r], 128 * j, 0);
+        }
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv[j];
+          v = v > 0.f ? v : v * a.slope;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff[i][r], 128 * j, 0);
+        }
   }
 }
 
@@ -1109,6 +1332,19 @@ static int launch_conv(const ConvArgs& a, int splits, hipStream_t st, int batch 
   return check_launch("conv_fwd");
 }
 
+// bf16-only workgroup tiles (no f32 instantiation): 8 = 128 rows x 256 channels on 8 waves of 64 x 64
+template <int BM, int BN, int WM, int WN>
+static int launch_conv_bf16(const ConvArgs& a, int splits, hipStream_t st, int batch, int tile_begin, int tile_count) {
+  const size_t lds = (size_t)2 * BM * (32 + 8) * 2;
+  const int tiles = ceil_div(a.M, BM) * (a.Cout / BN);
+  ConvArgs b = a;
+  b.xcd_chunk = 0;
+  b.tile_off = tile_begin;
+  dim3 grid(tile_count < 0 ? tiles : tile_count, batch, splits);
+  hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), lds, st, b);
+  return check_launch("conv_bf16");
+}
+
 }  // namespace dim
 
 using namespace dim;
@@ -1238,6 +1474,7 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   DIM_REQUIRE(stride >= 1 && pad >= 0 && KH >= 1 && KW >= 1, "bad geometry");
   DIM_REQUIRE(Cin != 8 || KW <= 8, "Cin==8 path needs KW<=8");
   ConvArgs a;
+  a.y_bytes = 0;
   a.x = x; a.w = w_packed; a.bias = bias;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride;
   a.pad_h = pad;
@@ -1273,6 +1510,10 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   DIM_REQUIRE(splits == 1 || !ex || (a.dense_out && a.out_cstride == Cout && a.out_coff == 0),
               "split-K writes a dense [M][Cout] result: not available with a strided / scattered output");
   a.y = splits > 1 ? workspace : y;
+  // every kernel stores through a buffer descriptor with 32-bit byte offsets (branch-free epilogues)
+  DIM_REQUIRE((long)N * a.OH * a.OW * a.out_cstride * 4 < (1L << 31), "output too large for 32-bit byte offsets (%ld bytes)",
+              (long)N * a.OH * a.OW * a.out_cstride * 4);
+  a.y_bytes = (unsigned)((long)N * a.OH * a.OW * a.out_cstride * 4);
   a.tile_off = 0;
   a.slab_row0 = 0;
   a.slab_stride = (long)N * a.Ho * a.Wo * Cout;
@@ -1312,6 +1553,38 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
 #undef DIM_HALO16
     return check_launch("conv_bf16_halo");
   }
+  if (tile == 9) {
+    // the bf16 stride-1 patch kernel (conv_bf16_patch_kernel): 2 .. 9 taps with KH, KW <= 3, Cin % 32 == 0, Cout % 128 == 0; dense or
+    // scattered output, batched launch (deconvolution phases) allowed, no split-K
+    DIM_REQUIRE(a.bf16 && stride == 1 && KH >= 1 && KH <= 3 && KW >= 1 && KW <= 3 && KH * KW >= 2 && Cin % 32 == 0 && Cout % 128 == 0,
+                "tile 9: bf16, stride 1, 2..9 taps (KH, KW <= 3), Cin %% 32 == 0, Cout %% 128 == 0");
+    DIM_REQUIRE(splits == 1 && !partial_only, "tile 9: no split-K");
+    const int blocks = N * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16) * (Cout / 128);
+    const size_t lds = (size_t)2 * (16 + KH - 1) * 1536 + 256;   // two patch buffers + the dump slot
+#define DIM_PATCH16(KHc, KWc)                                                                                                         \
+  {                                                                                                                                   \
+    static bool attr_set = false;                                                                                                     \
+    if (!attr_set) {                                                                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_patch_kernel<KHc, KWc>),                            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+      if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));             \
+      attr_set = true;                                                                                                                \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((conv_bf16_patch_kernel<KHc, KWc>), dim3(blocks, batch), dim3(256), lds, st, a);                               \
+  }
+    switch (KH * 4 + KW) {
+      case 1 * 4 + 2: DIM_PATCH16(1, 2) break;
+      case 2 * 4 + 1: DIM_PATCH16(2, 1) break;
+      case 1 * 4 + 3: DIM_PATCH16(1, 3) break;
+      case 3 * 4 + 1: DIM_PATCH16(3, 1) break;
+      case 2 * 4 + 2: DIM_PATCH16(2, 2) break;
+      case 2 * 4 + 3: DIM_PATCH16(2, 3) break;
+      case 3 * 4 + 2: DIM_PATCH16(3, 2) break;
+      default: DIM_PATCH16(3, 3) break;
+    }
+#undef DIM_PATCH16
+    return check_launch("conv_bf16_patch");
+  }
   if (tile == 6) {
     // the LDS-halo first-layer kernel (conv1_halo_kernel): 8 channels, 7x7 / stride 2, 64 output channels, dense output, no split-K
     DIM_REQUIRE(Cin == 8 && KH == 7 && KW == 7 && stride == 2 && Cout == 64, "tile 6 is the 8-channel 7x7 / stride-2 / 64-filter first layer");
@@ -1324,6 +1597,7 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
     return check_launch("conv1_halo");
   }
   DIM_REQUIRE((tile != 1 && tile != 4) || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");
+  DIM_REQUIRE(tile != 8 || (a.bf16 && Cout % 256 == 0 && Cin != 8 && !auto_split), "tile 8 (128x256): bf16, Cout %% 256 == 0, explicit splits");
   DIM_REQUIRE(Cin != 8 || tile != 4, "tile 4 (128x128, 8 waves) is not built for the 8-channel layer");
   DIM_REQUIRE(Cin != 8 || batch == 1, "batched launch is not built for the 8-channel layer");
   auto launch = [&](const ConvArgs& args, int nsplit, int t0, int tn) -> int {
@@ -1332,6 +1606,7 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
       if (tile == 2) return launch_conv<128, 64, 2, 2, true>(args, nsplit, st, 1, t0, tn);
       return launch_conv<64, 64, 2, 2, true>(args, nsplit, st, 1, t0, tn);
     }
+    if (tile == 8) return launch_conv_bf16<128, 256, 2, 4>(args, nsplit, st, batch, t0, tn);
     if (tile == 4) return launch_conv<128, 128, 2, 4, false>(args, nsplit, st, batch, t0, tn);
     if (tile == 1) return launch_conv<128, 128, 2, 2, false>(args, nsplit, st, batch, t0, tn);
     if (tile == 2) return launch_conv<128, 64, 2, 2, false>(args, nsplit, st, batch, t0, tn);
@@ -1518,9 +1793,13 @@ static int conv2d_dgrad_impl(const float* dy, const float* w_dgrad_packed, float
         ex.accumulate = accumulate;
         ex.bf16 = bf16;
         if (total > 0) {
+          // tile 9 (bf16 patch kernel) takes the phases with 2 .. 9 taps; a single-tap phase is a 1x1 convolution: gathered-tap kernel
+          int ptile = tile;
+          if (tile == 9 && !(bf16 && ah.ntaps <= 3 && aw.ntaps <= 3 && ah.ntaps * aw.ntaps >= 2 && CinPad % 128 == 0))
+            ptile = CinPad % 128 == 0 ? 4 : 3;
           int rc = conv2d_fwd_impl(dy, bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(w_dgrad_packed) + 2 * off)
                                             : w_dgrad_packed + off, nullptr, dx, nullptr, N, Ho, Wo, Cout, CinPad, ah.ntaps, aw.ntaps, 1,
-                                   -ah.emin, 1.0f, 1, tile, 0, stream, &ex);
+                                   -ah.emin, 1.0f, 1, ptile, 0, stream, &ex);
           if (rc != DIM_OK) return rc;
         } else if (!accumulate) {
           return set_err(DIM_ERR_ARG, "phase (%d,%d) has no taps: dX rows of that phase would stay unwritten", py, px);

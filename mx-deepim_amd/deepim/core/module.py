@@ -21,7 +21,7 @@ import torch
 
 from lib.hip import ops
 from lib.utils.dist_utils import allreduce_sum_
-from deepim.symbols.deepIM_flownet import ENCODER, FlowNetHip, deepIM_flownet
+from deepim.symbols.deepIM_flownet import bf16_tile, BF16_PATCH, ENCODER, FlowNetHip, deepIM_flownet
 
 FROZEN = ("upsampling_weight", "mask_upsampling_weight")  # attr lr_mult 0.0 (deepIM_flownet.py:334, :520)
 
@@ -340,9 +340,11 @@ class MutableModule(object):
                     ops.conv2d_dgrad_winograd5x5s2(dy, cout, self.wino5_dgrad[name], self.dacts[prev[name]], cin[name], workspace=self.wino_ws)
                 else:
                     # bf16: operand-traffic bound, so the widest tile the channel count allows (dX channels are the GEMM's N)
-                    dg_tile = 4 if (self.bf16 and ops.pad64(cin[name]) % 128 == 0) else 3
-                    if (dg_tile == 4 and s == 1 and k == 3 and dy.shape[1] * dy.shape[2] >= 1200 and os.environ.get("DIM_BF16_HALO", "1") != "0"):
+                    dg_tile = bf16_tile(ops.pad64(cin[name])) if self.bf16 else 3
+                    if (dg_tile != 3 and s == 1 and k == 3 and dy.shape[1] * dy.shape[2] >= 1200 and os.environ.get("DIM_BF16_HALO", "1") != "0"):
                         dg_tile = 7   # stride-1 input gradient of a large map: LDS-halo kernel
+                    if self.bf16 and BF16_PATCH and ops.pad64(cin[name]) % 128 == 0 and k in (3, 5) and dy.shape[1] * dy.shape[2] >= 1200:
+                        dg_tile = 9   # stride-1 patch kernel: the gradient itself (stride 1) or its four phase convolutions (stride 2)
                     ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False,
                                      tile=dg_tile)
         self._bucket_ready(None)
@@ -407,7 +409,7 @@ class MutableModule(object):
         ops.bias_grad(dz, cout, g[name + "_bias"], dz_coff=dz_coff, workspace=self.bias_ws)
         # data gradient: the same convolution applied to dz
         ops.conv2d_fwd_ex(dz, dz_coff, cout, self.dgrad_packed[name], None, dx, 0, x_cpad, 4, 4, 2, 1, Ho=h, Wo=wd, accumulate=False,
-                          tile=4 if (self.bf16 and x_cpad % 128 == 0) else 3)
+                          tile=bf16_tile(x_cpad) if self.bf16 else 3)
 
     def forward_backward(self, batch):
         out = self.forward(batch)

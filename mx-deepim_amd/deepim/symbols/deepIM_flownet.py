@@ -35,6 +35,17 @@ ENCODER = [
 # Winograd output tile edge per 3x3 / stride-1 layer (4 where not listed; measured at B = 16: F(4x4) wins on all four, also on the
 # 8x10 map of conv6_1 despite 20 % tile padding: 0.108 vs 0.128 ms)
 WINO_M_DEFAULT = {}
+# workgroup tile of the wide-Cout bf16 layers: 4 = 128 x 128 on 8 waves (64 x 32 each), 1 = 128 x 128 on 4 waves (64 x 64 each)
+BF16_BIG_TILE = int(os.environ.get("DIM_BF16_BIG_TILE", "4"))
+# the stride-1 patch kernel (tile 9) for the 3x3 / stride-1 layers, their input gradients and the phases of the stride-2 input gradients
+BF16_PATCH = os.environ.get("DIM_BF16_PATCH", "1") != "0"
+
+
+def bf16_tile(cout):
+    """workgroup tile of a bf16 layer with `cout` GEMM columns: 8 = 128 x 256 (only when DIM_BF16_BIG_TILE=8), 4 / 1 = 128 x 128, 3 = 64 x 64"""
+    if BF16_BIG_TILE == 8:
+        return 8 if cout % 256 == 0 else (4 if cout % 128 == 0 else 3)
+    return BF16_BIG_TILE if cout % 128 == 0 else 3
 
 
 def input_channels(cfg):
@@ -220,7 +231,7 @@ class FlowNetHip(object):
             for name, cout, k, s, p in ENCODER:
                 h, w = ops.conv_out_hw(h, w, k, k, s, p)
                 tiles = -(-batch_size * h * w // 128) * (cout // 128) if cout % 128 == 0 else 0
-                self.conv_plan[name] = (4 if (cout % 128 == 0 and c != 8) else 3, 1 if (tiles == 0 or tiles >= 256) else min(4, -(-512 // tiles)))
+                self.conv_plan[name] = (bf16_tile(cout) if c != 8 else 3, 1 if (tiles == 0 or tiles >= 256) else min(4, -(-512 // tiles)))
                 # 3x3 / stride-1 layers on large maps: the LDS-halo kernel (conv.hip conv_bf16_halo_kernel, tile 7).  Measured at B = 16
                 # against the gathered-tap kernel: conv3_1 0.150 vs 0.161 ms, conv4_1 0.175 vs 0.177; the stride-2 layers lose (conv2
                 # 0.366 vs 0.256, conv3 0.286 vs 0.247, conv4 0.143 vs 0.102: their 45-53 KB patches + 41 KB of weight buffers leave
@@ -229,6 +240,8 @@ class FlowNetHip(object):
                 halo = os.environ.get("DIM_BF16_HALO", "1")
                 if c % 32 == 0 and cout % 128 == 0 and h * w >= 1200 and ((halo == "1" and k == 3 and s == 1) or (halo == "2" and k in (3, 5))):
                     self.conv_plan[name] = (7, 1)
+                if BF16_PATCH and c % 32 == 0 and cout % 128 == 0 and h * w >= 1200 and k == 3 and s == 1:
+                    self.conv_plan[name] = (9, 1)   # stride-1 patch kernel (conv.hip conv_bf16_patch_kernel)
                 c = cout
         if conv_plan:
             self.conv_plan.update(conv_plan)
@@ -428,13 +441,14 @@ class FlowNetHip(object):
         r10, r8, r6 = self.acts["conv6_1"], self.acts["conv5_1"], self.acts["conv4_1"]
         ops.conv_small_cout_fwd(r10, 1024, self.packed["Convolution1"], p["Convolution1_bias"], 2, out=self.flow6)
         self.concat2[..., :512].copy_(r8)  # strided: an elementwise kernel, not a memcpy node
-        ops.deconv4x4s2_fwd(r10, 1024, self.packed["deconv5"], p["deconv5_bias"], self.concat2, 512, crop=1, slope=0.1, out_coff=512)
+        ops.deconv4x4s2_fwd(r10, 1024, self.packed["deconv5"], p["deconv5_bias"], self.concat2, 512, crop=1, slope=0.1, out_coff=512,
+                            tile=bf16_tile(512) if self.bf16 else 3)
         ops.deconv4x4s2_tiny_fwd(self.flow6, 2, p["upsample_flow6to5_weight"], p["upsample_flow6to5_bias"], self.concat2, 2, crop=1,
                                  out_coff=1024)
         ops.conv_small_cout_fwd(self.concat2, 1026, self.packed["Convolution2"], p["Convolution2_bias"], 2, out=self.flow5)
         self.concat3[..., :512].copy_(r6)
         ops.deconv4x4s2_fwd(self.concat2, 1026, self.packed["deconv4"], p["deconv4_bias"], self.concat3, 256, crop=1, slope=0.1,
-                            out_coff=512)
+                            out_coff=512, tile=bf16_tile(256) if self.bf16 else 3)
         ops.deconv4x4s2_tiny_fwd(self.flow5, 2, p["upsample_flow5to4_weight"], p["upsample_flow5to4_bias"], self.concat3, 2, crop=1,
                                  out_coff=768)
         return self.concat3

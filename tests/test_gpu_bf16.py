@@ -64,6 +64,12 @@ FWD_CASES = [
     (2, 15, 20, 256, 512, 3, 2, 1, 7, 1),
     (1, 37, 53, 32, 128, 3, 1, 1, 7, 1),
     (3, 9, 11, 96, 128, 3, 2, 1, 7, 1),
+    # tile 9: the stride-1 patch kernel (16 x 16 output blocks x 128 channels; partial blocks, 1 .. 8 channel slices, no padding)
+    (2, 15, 20, 256, 256, 3, 1, 1, 9, 1),
+    (1, 37, 53, 32, 128, 3, 1, 1, 9, 1),
+    (2, 33, 17, 64, 128, 3, 1, 1, 9, 1),
+    (1, 18, 35, 96, 256, 3, 1, 0, 9, 1),
+    (1, 16, 16, 32, 128, 3, 1, 1, 9, 1),
 ]
 
 
@@ -84,6 +90,8 @@ def test_conv_fwd_bf16(ops, case):
 
 BWD_CASES = [
     # N, H, W, Cin, Cout, k, s, p, wgrad splits
+    (1, 30, 40, 128, 128, 5, 2, 2, 3),   # stride-2 input gradient = 3x3 / 3x2 / 2x3 / 2x2 phase convolutions (tile 9 below)
+    (2, 21, 17, 128, 64, 3, 2, 1, 1),    # 2x2 / 2x1 / 1x2 / 1x1 phases
     (2, 15, 20, 64, 64, 3, 1, 1, 1),
     (2, 15, 20, 64, 128, 3, 2, 1, 2),
     (1, 30, 40, 64, 128, 5, 2, 2, 3),
@@ -118,6 +126,14 @@ def test_dgrad_wgrad_bf16(ops, case):
         ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dx7, Cin, k, k, s, p, accumulate=False, tile=7)
         got7 = dx7[..., :Cin].permute(0, 3, 1, 2).cpu().double().numpy()
         assert np.abs(got7 - xr.grad.numpy()).max() <= 1e-4 * xr.grad.abs().max().item() + 1e-5
+    if ops.pad64(Cin) % 128 == 0:   # ... and the stride-1 patch kernel, which also takes the phases of a stride-2 gradient
+        dx9 = torch.full((N, H, W, ops.pad64(Cin)), 3.0, device=DEV)
+        ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dx9, Cin, k, k, s, p, accumulate=False, tile=9)
+        got9 = dx9[..., :Cin].permute(0, 3, 1, 2).cpu().double().numpy()
+        assert np.abs(got9 - xr.grad.numpy()).max() <= 1e-4 * xr.grad.abs().max().item() + 1e-5
+        ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dx9, Cin, k, k, s, p, accumulate=True, tile=9)   # out += result
+        got9 = dx9[..., :Cin].permute(0, 3, 1, 2).cpu().double().numpy()
+        assert np.abs(got9 - 2 * xr.grad.numpy()).max() <= 2e-4 * xr.grad.abs().max().item() + 2e-5
     dwp = torch.zeros_like(ops.conv2d_pack_weight(w.float().to(DEV)))
     ops.conv2d_wgrad(nhwc(x.float()), Cin, nhwc(dy.float()), Cout, k, k, s, p, dwp, splits=splits, bf16_mfma=True)
     ref = ops.conv2d_pack_weight(wr.grad.float().to(DEV))
@@ -168,6 +184,13 @@ def test_deconv4x4s2_bf16_forward_and_backward(ops, shape):
     got = y[..., 8:8 + Cout].permute(0, 3, 1, 2).cpu().double()
     assert (got - ref.detach()).abs().max().item() <= 1e-4 * ref.abs().max().item() + 2e-5
     assert (y[..., :8] == -7).all() and (y[..., 8 + Cout:] == -7).all()
+    if Cout % 128 == 0:   # the four 2x2 phase convolutions as one batched launch of the stride-1 patch kernel
+        y9 = torch.full((N, OH, OW, Cout + 40), -7.0, device=DEV)
+        ops.deconv4x4s2_fwd(xin, Cin, ops.to_bf16(ops.deconv4x4s2_pack_weight(w.float().to(DEV))), b.float().to(DEV), y9, Cout, crop=1,
+                            slope=0.1, out_coff=8, tile=9)
+        got9 = y9[..., 8:8 + Cout].permute(0, 3, 1, 2).cpu().double()
+        assert (got9 - ref.detach()).abs().max().item() <= 1e-4 * ref.abs().max().item() + 2e-5
+        assert (y9[..., :8] == -7).all() and (y9[..., 8 + Cout:] == -7).all()
     # backward through the convolution view (decoder): dgrad = stride-2 conv of dz with the weight read as (O = Cin, I = Cout)
     dz = torch.randn(pre.shape, generator=g, dtype=torch.float64)
     pre.backward(r16(dz))
