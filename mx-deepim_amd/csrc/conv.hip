@@ -825,10 +825,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 //    loaded NSETS-1 taps ahead into a rotating register set;
 //  * patch rows are 1536 B apart (a multiple of 256 B) and pixels 80 B: a ds_read_b128 lane group ({0-3,12-15,20-27}: two pixel
 //    rows of an MFMA tile) then covers all 64 banks exactly once.
-template <int KH, int KW>
+template <int KH, int KW, int BN>
 __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
   constexpr int NT = KH * KW;
-  constexpr int TH = 16, TW = 16, BN = 128;
+  constexpr int TH = 16, TW = 16;
+  constexpr int TN = BN / 64;                         // 32-channel tiles per wave: BN = 128 (2 x 64 per wave column) or 64 (2 x 32)
+  static_assert(BN == 128 || BN == 64, "channel tile");
   constexpr int PH = TH + KH - 1, PW = TW + KW - 1;
   constexpr int PXB = 80, PITCH = 1536, PBUF = PH * PITCH;
   constexpr int NITEM = PH * PW * 8;                 // float4 pieces of one patch slice
@@ -874,27 +876,27 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
     p_loff[u] = item < NITEM ? py * PITCH + px * PXB + q * 8 : -1;
   }
 
-  // ---- fragments
+  // ---- fragments (wave (wm, wn): pixel rows 8 wm .. 8 wm + 7, channels (BN / 2) wn .. + BN / 2)
   const int frow = lane & 31, khalf = lane >> 5;
   const int a_off = (8 * wm + (frow >> 4)) * PITCH + (frow & 15) * PXB + 16 * khalf;   // + 2 i PITCH, + kh PITCH + kw PXB, + 32 ks
-  const int b_voff = ((n0 + 64 * wn + frow) * 32 + 8 * khalf) * 2;                      // + 32 j rows, + 16 ks elements
-  bf16x8 fb[NSETS][2][2];   // [set][k-step][channel tile]
+  const int b_voff = ((n0 + (BN / 2) * wn + frow) * 32 + 8 * khalf) * 2;                      // + 32 j rows, + 16 ks elements
+  bf16x8 fb[NSETS][2][TN];  // [set][k-step][channel tile]
   auto load_b = [&](auto SET, int chunk) {
     constexpr int set = decltype(SET)::value;
     const int soff = chunk * chunk_bytes;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < TN; ++j) {
         u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff + (32 * j * 32 + 16 * ks) * 2, soff, 0);
         fb[set][ks][j] = *reinterpret_cast<bf16x8*>(&v);
       }
   };
-  f32x16 acc[4][2];
+  f32x16 acc[4][TN];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
       // them out one small group behind each MFMA (an MFMA holds the issue port 8 of its 32 cycles); without it hipcc either sinks
       // the loads to their first use (prefetch distance gone, one load even inside a branch followed by vmcnt(0)) or, fenced into
       // blocks, leaves the pipe idle during every non-MFMA block (measured: 43 % MFMA-busy inside a wave's life).
-      constexpr int NLD = (t < NT - 1 ? (IPT < PITEMS - t * IPT ? IPT : (PITEMS - t * IPT > 0 ? PITEMS - t * IPT : 0)) : 0) + 4;
+      constexpr int NLD = (t < NT - 1 ? (IPT < PITEMS - t * IPT ? IPT : (PITEMS - t * IPT > 0 ? PITEMS - t * IPT : 0)) : 0) + 2 * TN;
       constexpr int NST = t >= 1 ? (IPT < PITEMS - (t - 1) * IPT ? IPT : (PITEMS - (t - 1) * IPT > 0 ? PITEMS - (t - 1) * IPT : 0)) : 0;
       if (t < NT - 1) {
 #pragma unroll
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][ks][i], fb[t % NSETS][ks][j], acc[i][j], 0, 0, 0);
       if (t >= 1) {
 #pragma unroll
@@ -968,7 +970,8 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
           }
         }
       }
-      static_for<16>([&](auto Mi) {
+      constexpr int NM = 8 * TN;   // MFMAs of the tap
+      static_for<NM>([&](auto Mi) {
         constexpr int m = decltype(Mi)::value;
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // one MFMA
         if constexpr (m < NLD) {
@@ -976,7 +979,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // ... one global load
         }
         if constexpr (m < 8 && t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one A-fragment read
-        if constexpr (m >= 16 - NST) {
+        if constexpr (m >= NM - NST) {
           __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                     // round one piece ...
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                     // ... and store it
         }
@@ -1000,7 +1003,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
   // offset is affine in both (channel co of tile j = + 128 j bytes), and a block that lies inside the output needs no per-pixel test
   const int hob = ho0 + 8 * wm, wob = wo0 + 4 * khalf;
   const int row_b = a.osy * a.OW * a.out_cstride * 4, col_b = a.osx * a.out_cstride * 4;
-  const int base_b = (((n * a.OH + hob * a.osy + oy_base) * a.OW + wob * a.osx + ox_base) * a.out_cstride + a.out_coff + n0 + 64 * wn + frow) * 4;
+  const int base_b = (((n * a.OH + hob * a.osy + oy_base) * a.OW + wob * a.osx + ox_base) * a.out_cstride + a.out_coff + n0 + (BN / 2) * wn + frow) * 4;
   const bool inside = ho0 + TH <= a.Ho && wo0 + TW <= a.Wo && ho0 * a.osy + oy_base >= 0 && (ho0 + TH - 1) * a.osy + oy_base < a.OH &&
                       wo0 * a.osx + ox_base >= 0 && (wo0 + TW - 1) * a.osx + ox_base < a.OW;   // workgroup-uniform
   int voff[4][16];
@@ -1022,12 +1025,12 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
         voff[i][r] = ok ? voff[i][r] : -1;
       }
   }
-  float bv[2];
+  float bv[TN];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) bv[j] = a.has_bias ? a.bias[n0 + 64 * wn + 32 * j + frow] : 0.f;
+  for (int j = 0; j < TN; ++j) bv[j] = a.has_bias ? a.bias[n0 + (BN / 2) * wn + 32 * j + frow] : 0.f;
   if (a.accumulate) {   // wave-uniform: out += result (gradients that meet in one buffer)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float old[16];
@@ -1042,7 +1045,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
       }
   } else {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1556,21 +1559,26 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   if (tile == 9) {
     // the bf16 stride-1 patch kernel (conv_bf16_patch_kernel): 2 .. 9 taps with KH, KW <= 3, Cin % 32 == 0, Cout % 128 == 0; dense or
     // scattered output, batched launch (deconvolution phases) allowed, no split-K
-    DIM_REQUIRE(a.bf16 && stride == 1 && KH >= 1 && KH <= 3 && KW >= 1 && KW <= 3 && KH * KW >= 2 && Cin % 32 == 0 && Cout % 128 == 0,
-                "tile 9: bf16, stride 1, 2..9 taps (KH, KW <= 3), Cin %% 32 == 0, Cout %% 128 == 0");
+    DIM_REQUIRE(a.bf16 && stride == 1 && KH >= 1 && KH <= 3 && KW >= 1 && KW <= 3 && KH * KW >= 2 && Cin % 32 == 0 && Cout % 64 == 0,
+                "tile 9: bf16, stride 1, 2..9 taps (KH, KW <= 3), Cin %% 32 == 0, Cout %% 64 == 0");
     DIM_REQUIRE(splits == 1 && !partial_only, "tile 9: no split-K");
-    const int blocks = N * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16) * (Cout / 128);
+    const int bn = Cout % 128 == 0 ? 128 : 64;   // 64: the 64-channel layers (input gradient of flow_conv2)
+    const int blocks = N * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16) * (Cout / bn);
     const size_t lds = (size_t)2 * (16 + KH - 1) * 1536 + 256;   // two patch buffers + the dump slot
-#define DIM_PATCH16(KHc, KWc)                                                                                                         \
+#define DIM_PATCH16_BN(KHc, KWc, BNc)                                                                                                 \
   {                                                                                                                                   \
     static bool attr_set = false;                                                                                                     \
     if (!attr_set) {                                                                                                                  \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_patch_kernel<KHc, KWc>),                            \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_patch_kernel<KHc, KWc, BNc>),                       \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
       if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));             \
       attr_set = true;                                                                                                                \
     }                                                                                                                                 \
-    hipLaunchKernelGGL((conv_bf16_patch_kernel<KHc, KWc>), dim3(blocks, batch), dim3(256), lds, st, a);                               \
+    hipLaunchKernelGGL((conv_bf16_patch_kernel<KHc, KWc, BNc>), dim3(blocks, batch), dim3(256), lds, st, a);                          \
+  }
+#define DIM_PATCH16(KHc, KWc)                                                                                                         \
+  {                                                                                                                                   \
+    if (bn == 128) DIM_PATCH16_BN(KHc, KWc, 128) else DIM_PATCH16_BN(KHc, KWc, 64)                                                    \
   }
     switch (KH * 4 + KW) {
       case 1 * 4 + 2: DIM_PATCH16(1, 2) break;
@@ -1582,6 +1590,7 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
       case 3 * 4 + 2: DIM_PATCH16(3, 2) break;
       default: DIM_PATCH16(3, 3) break;
     }
+#undef DIM_PATCH16_BN
 #undef DIM_PATCH16
     return check_launch("conv_bf16_patch");
   }
@@ -1795,7 +1804,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w_dgrad_packed, float
         if (total > 0) {
           // tile 9 (bf16 patch kernel) takes the phases with 2 .. 9 taps; a single-tap phase is a 1x1 convolution: gathered-tap kernel
           int ptile = tile;
-          if (tile == 9 && !(bf16 && ah.ntaps <= 3 && aw.ntaps <= 3 && ah.ntaps * aw.ntaps >= 2 && CinPad % 128 == 0))
+          if (tile == 9 && !(bf16 && ah.ntaps <= 3 && aw.ntaps <= 3 && ah.ntaps * aw.ntaps >= 2))
             ptile = CinPad % 128 == 0 ? 4 : 3;
           int rc = conv2d_fwd_impl(dy, bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(w_dgrad_packed) + 2 * off)
                                             : w_dgrad_packed + off, nullptr, dx, nullptr, N, Ho, Wo, Cout, CinPad, ah.ntaps, aw.ntaps, 1,

@@ -343,7 +343,7 @@ class MutableModule(object):
                     dg_tile = bf16_tile(ops.pad64(cin[name])) if self.bf16 else 3
                     if (dg_tile != 3 and s == 1 and k == 3 and dy.shape[1] * dy.shape[2] >= 1200 and os.environ.get("DIM_BF16_HALO", "1") != "0"):
                         dg_tile = 7   # stride-1 input gradient of a large map: LDS-halo kernel
-                    if self.bf16 and BF16_PATCH and ops.pad64(cin[name]) % 128 == 0 and k in (3, 5) and dy.shape[1] * dy.shape[2] >= 1200:
+                    if self.bf16 and BF16_PATCH and k in (3, 5) and dy.shape[1] * dy.shape[2] >= 1200:
                         dg_tile = 9   # stride-1 patch kernel: the gradient itself (stride 1) or its four phase convolutions (stride 2)
                     ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False,
                                      tile=dg_tile)

@@ -70,6 +70,8 @@ FWD_CASES = [
     (2, 33, 17, 64, 128, 3, 1, 1, 9, 1),
     (1, 18, 35, 96, 256, 3, 1, 0, 9, 1),
     (1, 16, 16, 32, 128, 3, 1, 1, 9, 1),
+    (2, 20, 33, 64, 64, 3, 1, 1, 9, 1),    # 64-channel tile
+    (1, 17, 16, 32, 192, 3, 1, 1, 9, 1),   # 192 = 3 x 64
 ]
 
 
@@ -126,7 +128,7 @@ def test_dgrad_wgrad_bf16(ops, case):
         ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dx7, Cin, k, k, s, p, accumulate=False, tile=7)
         got7 = dx7[..., :Cin].permute(0, 3, 1, 2).cpu().double().numpy()
         assert np.abs(got7 - xr.grad.numpy()).max() <= 1e-4 * xr.grad.abs().max().item() + 1e-5
-    if ops.pad64(Cin) % 128 == 0:   # ... and the stride-1 patch kernel, which also takes the phases of a stride-2 gradient
+    if True:   # ... and the stride-1 patch kernel (128- or 64-channel tiles), which also takes the phases of a stride-2 gradient
         dx9 = torch.full((N, H, W, ops.pad64(Cin)), 3.0, device=DEV)
         ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dx9, Cin, k, k, s, p, accumulate=False, tile=9)
         got9 = dx9[..., :Cin].permute(0, 3, 1, 2).cpu().double().numpy()
