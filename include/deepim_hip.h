@@ -291,6 +291,11 @@ int dim_bias_grad(const float* dz, float* db, float* workspace, int M, int C, in
 /* LeakyReLU backward in place on a channel range: dy *= (y > 0 ? 1 : slope) */
 int dim_lrelu_bwd(const float* y, int y_cstride, int y_coff, float* dy, int dy_cstride, int dy_coff, long M, int C, float slope,
                   void* stream);
+/* both of the above in one pass over the gradient map: dy *= (y > 0 ? 1 : slope) in place, db[c] (+)= sum_m dy[m][dy_coff + c]
+ * (the pair MXNet's LeakyReLU backward + Convolution backward-bias make; deepIM_flownet.py:67-208) */
+long dim_lrelu_bwd_bias_grad_workspace_floats(int M, int C);
+int dim_lrelu_bwd_bias_grad(const float* y, int y_cstride, int y_coff, float* dy, int dy_cstride, int dy_coff, float* db, float* workspace,
+                            int M, int C, float slope, int accumulate, void* stream);
 /* ---------------------------------------------------------------- training-only pieces (csrc/train.hip)
  * layout converters: packed conv / fc weights (or gradients) back to the MXNet layouts; fc6 dgrad weights */
 int dim_conv2d_unpack_weight(const float* w_packed, float* w_oihw, int Cout, int CoutPad, int Cin, int KH, int KW, float scale,

@@ -375,19 +375,75 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
 }
 
+// LeakyReLU' and the bias gradient in ONE pass over the gradient map: dz = dy * (y > 0 ? 1 : slope) in place, partial column sums of
+// dz as in colsum_partial_kernel (same grid, same partial layout, same final fold).  The two separate kernels read dz twice.
+__global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const float* __restrict__ y, int y_cstride, int y_coff, float* __restrict__ dy,
+                                                               int dy_cstride, int dy_coff, int M, int C, float slope, int rows_per_block,
+                                                               float* __restrict__ partial) {
+  const int cg = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cg * 4;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (c < C) {
+    const float* yb = y + y_coff + c;
+    float* gb = dy + dy_coff + c;
+    auto one = [&](int m, float4& s) {
+      const float4 yv = *reinterpret_cast<const float4*>(yb + (long)m * y_cstride);
+      float4* g = reinterpret_cast<float4*>(gb + (long)m * dy_cstride);
+      float4 gv = *g;
+      gv.x *= yv.x > 0.f ? 1.f : slope;
+      gv.y *= yv.y > 0.f ? 1.f : slope;
+      gv.z *= yv.z > 0.f ? 1.f : slope;
+      gv.w *= yv.w > 0.f ? 1.f : slope;
+      *g = gv;
+      s.x += gv.x; s.y += gv.y; s.z += gv.z; s.w += gv.w;
+    };
+    int m = r0 + rsub;
+    for (; m + 16 < r1; m += 32) {
+      one(m, s0);
+      one(m + 16, s1);
+    }
+    for (; m < r1; m += 16) one(m, s0);
+  }
+  __shared__ float4 red[16][16];
+  red[rsub][cg] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    const float* r = reinterpret_cast<const float*>(&red[0][0]) + threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += r[k * 64];
+    if (col < C) partial[(long)blockIdx.y * C + col] = t;
+  }
+}
+
 // workgroup = 64 columns x 4 partial-row groups; LDS fold
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ db,
-                                                           int accumulate) {
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ db,
+                                                            int accumulate) {
+  // 64 columns x 16 row groups, four independent partial sums per thread: the fold of up to 1024 partial rows is a chain of dependent
+  // L2 round trips otherwise (4 groups x 1 sum: 25-40 us per call at 1024 rows)
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (c < C)
-    for (int k = rg; k < nsplit; k += 4) s += partial[(long)k * C + c];
-  __shared__ float red[4][64];
-  red[rg][cl] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    int k = rg;
+    for (; k + 48 < nsplit; k += 64) {
+      s0 += partial[(long)k * C + c];
+      s1 += partial[(long)(k + 16) * C + c];
+      s2 += partial[(long)(k + 32) * C + c];
+      s3 += partial[(long)(k + 48) * C + c];
+    }
+    for (; k < nsplit; k += 16) s0 += partial[(long)k * C + c];
+  }
+  __shared__ float red[16][64];
+  red[rg][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rg == 0 && c < C) {
-    float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][cl];
     db[c] = accumulate ? db[c] + t : t;
   }
 }
@@ -572,8 +628,30 @@ int dim_bias_grad(const float* dz, float* db, float* workspace, int M, int C, in
   int nsplit = ceil_div(M, rpb);
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C, 64), nsplit), dim3(256), 0, st, dz, M, C, dz_cstride, dz_coff, rpb, workspace);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, workspace, nsplit, C, db, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, st, workspace, nsplit, C, db, accumulate);
   return check_launch("bias_grad");
+}
+
+int dim_lrelu_bwd_bias_grad(const float* y, int y_cstride, int y_coff, float* dy, int dy_cstride, int dy_coff, float* db, float* workspace,
+                            int M, int C, float slope, int accumulate, void* stream) {
+  if (M == 0) return DIM_OK;
+  DIM_REQUIRE(y && dy && db && workspace, "null pointer");
+  DIM_REQUIRE(C % 4 == 0 && y_cstride % 4 == 0 && dy_cstride % 4 == 0 && y_coff % 4 == 0 && dy_coff % 4 == 0, "multiples of 4 required");
+  // more, shorter row blocks than dim_bias_grad: this pass also WRITES the map, so it wants every CU busy (<= 512 partial rows)
+  int rpb = ceil_div(M, 512);
+  if (rpb < 64) rpb = 64;
+  const int nsplit = ceil_div(M, rpb);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(lrelu_bwd_colsum_kernel, dim3(ceil_div(C, 64), nsplit), dim3(256), 0, st, y, y_cstride, y_coff, dy, dy_cstride,
+                     dy_coff, M, C, slope, rpb, workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, st, workspace, nsplit, C, db, accumulate);
+  return check_launch("lrelu_bwd_bias_grad");
+}
+
+long dim_lrelu_bwd_bias_grad_workspace_floats(int M, int C) {
+  int rpb = ceil_div(M, 512);
+  if (rpb < 64) rpb = 64;
+  return (long)ceil_div(M, rpb) * C;
 }
 
 int dim_lrelu_bwd(const float* y, int y_cstride, int y_coff, float* dy, int dy_cstride, int dy_coff, long M, int C, float slope,

@@ -155,7 +155,11 @@ class MutableModule(object):
                      ops.lib().dim_conv_small_cout_bwd_workspace_floats(B, 8, 10, 1024, 2, 3, 3))
         self.ws = torch.empty(max_ws, dtype=torch.float32, device=d)
         self.gpack = torch.empty(max_pack, dtype=torch.float32, device=d)
-        self.bias_ws = torch.empty(ops.lib().dim_bias_grad_workspace_floats(B * 240 * 320, 64) + 1024 * 64, dtype=torch.float32, device=d)
+        need_b, h, w = ops.lib().dim_bias_grad_workspace_floats(B * 240 * 320, 64) + 1024 * 64, 480, 640
+        for name, cout, k, s, p in ENCODER:   # partial column sums of the fused LeakyReLU' + bias-gradient pass
+            h, w = ops.conv_out_hw(h, w, k, k, s, p)
+            need_b = max(need_b, ops.lib().dim_lrelu_bwd_bias_grad_workspace_floats(B * h * w, cout))
+        self.bias_ws = torch.empty(need_b, dtype=torch.float32, device=d)
         # dgrad-layout weights (refreshed by repack())
         self.dgrad_packed = {}
         self.wino_dgrad = {}
@@ -316,7 +320,7 @@ class MutableModule(object):
                 dy.add_(self.dconcat2[..., :512])   # skip connection into Concat2
             if name == "conv4_1":
                 dy.add_(self.dconcat3[..., :512])   # skip connection into Concat3
-            ops.lrelu_bwd(net.acts[name], dy, cout)
+            ops.lrelu_bwd_bias_grad(net.acts[name], dy, cout, g[name + "_bias"], workspace=self.bias_ws)   # dz in place + bias gradient
             x = net.acts[prev[name]] if prev[name] else net.X
             if name in self.wino_wgrad:
                 S, sp = self.wino_wgrad[name]
@@ -325,7 +329,6 @@ class MutableModule(object):
                 ops.conv2d_wgrad(x, cin[name], dy, cout, k, k, s, p, self.gpack, splits=self.wgrad_splits[name], workspace=self.ws,
                                  bf16_mfma=self.bf16)
                 ops.conv2d_unpack_weight(self.gpack, g[name + "_weight"])
-            ops.bias_grad(dy, cout, g[name + "_bias"], workspace=self.bias_ws)
             self._bucket_ready(name + "_weight")
             if prev[name]:
                 if name in self.wino_dgrad:

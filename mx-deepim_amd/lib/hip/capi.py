@@ -104,6 +104,8 @@ SIGNATURES = {
     "dim_bias_grad_workspace_floats": (L, [I, I]),
     "dim_bias_grad": (I, [P, P, P, I, I, I, I, I, P]),
     "dim_lrelu_bwd": (I, [P, I, I, P, I, I, L, I, F, P]),
+    "dim_lrelu_bwd_bias_grad_workspace_floats": (L, [I, I]),
+    "dim_lrelu_bwd_bias_grad": (I, [P, I, I, P, I, I, P, P, I, I, F, I, P]),
     "dim_fc_pack_weight": (I, [P, P, I, I, I, I, P]),
     "dim_pose_head_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, P]),
 }

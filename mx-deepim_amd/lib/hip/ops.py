@@ -519,6 +519,17 @@ def lrelu_bwd(y_nhwc, dy_nhwc, C, slope=0.1, y_coff=0, dy_coff=0):
     return dy_nhwc
 
 
+def lrelu_bwd_bias_grad(y_nhwc, dy_nhwc, C, db, slope=0.1, y_coff=0, dy_coff=0, workspace=None, accumulate=False):
+    """dy[..., dy_coff:dy_coff+C] *= LeakyReLU'(y[..., y_coff:y_coff+C]) in place and db (+)= its column sums, one pass (dim_lrelu_bwd_bias_grad)"""
+    M = dy_nhwc.numel() // dy_nhwc.shape[-1]
+    need = lib().dim_lrelu_bwd_bias_grad_workspace_floats(M, C)
+    if workspace is None or workspace.numel() < need:
+        workspace = _new((need,), dy_nhwc)
+    check(lib().dim_lrelu_bwd_bias_grad(dptr(y_nhwc, f32), y_nhwc.shape[-1], y_coff, dptr(dy_nhwc, f32), dy_nhwc.shape[-1], dy_coff, dptr(db, f32),
+                                        dptr(workspace, f32), M, C, float(slope), int(accumulate), current_stream()))
+    return dy_nhwc
+
+
 # ---------------------------------------------------------------- training-only pieces (csrc/train.hip)
 def _p(t, off=0):
     """device pointer of a contiguous CUDA f32 tensor, advanced by `off` floats (channel offset inside an NHWC row)"""

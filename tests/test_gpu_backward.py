@@ -99,6 +99,24 @@ def test_lrelu_bwd(ops):
     np.testing.assert_allclose(dy.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 7, 96, 128, 64, 16, 32), (3, 33, 41, 64, 64, 64, 0, 0), (1, 120, 160, 136, 200, 132, 4, 8)])
+def test_lrelu_bwd_bias_grad_fused(ops, shape):
+    """one pass = lrelu_bwd followed by bias_grad (row counts below, at and far above one row block; channel ranges of wider buffers)"""
+    N, H, W, Cy, Cdy, C, yo, dyo = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    y = torch.randn((N, H, W, Cy), generator=g).to(DEV)
+    dy = torch.randn((N, H, W, Cdy), generator=g).to(DEV)
+    ref = dy.clone()
+    ref[..., dyo:dyo + C] *= torch.where(y[..., yo:yo + C] > 0, 1.0, 0.1)
+    db_ref = ref[..., dyo:dyo + C].double().sum(dim=(0, 1, 2))
+    db = torch.full((C,), 7.0, device=DEV)
+    ops.lrelu_bwd_bias_grad(y, dy, C, db, slope=0.1, y_coff=yo, dy_coff=dyo)
+    np.testing.assert_allclose(dy.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(db.cpu().numpy(), db_ref.cpu().numpy(), rtol=2e-5, atol=2e-4)
+    ops.lrelu_bwd_bias_grad(y, ref.clone(), C, db, slope=1.0, y_coff=yo, dy_coff=dyo, accumulate=True)   # slope 1: dz unchanged, db += sums
+    np.testing.assert_allclose(db.cpu().numpy(), 2 * db_ref.cpu().numpy(), rtol=2e-5, atol=4e-4)
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 8, 10, 128, 15, 20), (1, 70, 15, 20, 64, 30, 40)])
 def test_deconv4x4s2_backward_via_conv_view(ops, shape):
     """Deconvolution(k4,s2)+Crop(1,1) backward as used by the decoder: dgrad = stride-2 convolution of dz with the deconv weight
