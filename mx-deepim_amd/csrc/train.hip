@@ -254,44 +254,51 @@ __global__ __launch_bounds__(256) void conv_small_cout_dgrad_kernel(const float*
 //   the KH*KW*Cout accumulators of the thread; the dY values of the q - tap neighbours are wave-uniform scalars.
 // stage 1: grid (pixel chunks, ceil(Cin/256)); partial[chunk][co][tap][ci] (deterministic, no atomics);  stage 2 sums the chunks.
 template <int COUT, int TAPS>
-__global__ __launch_bounds__(256) void conv_small_cout_wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                            float* __restrict__ partial, float* __restrict__ partial_b,
-                                                                            int N, int H, int W, int Cin, int in_cstride, int KH, int KW,
-                                                                            int pad, int chunk_px) {
+__global__ __launch_bounds__(64) void conv_small_cout_wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                           float* __restrict__ partial, float* __restrict__ partial_b,
+                                                                           int N, int H, int W, int Cin, int CinP, int in_cstride, int KH, int KW,
+                                                                           int pad, int chunk_px) {
+  // one wave = 256 input channels, a lane = 4 adjacent channels (one 16-byte load per pixel and tap; the first version loaded one
+  // dword per lane and was bound by the number of wave-loads: 2.8 M of them for the 770-channel head at 16 x 30 x 40)
   const int chunk = blockIdx.x;
-  const int ci = blockIdx.y * 256 + threadIdx.x;
+  const int ci = (blockIdx.y * 64 + threadIdx.x) * 4;
   const long P = (long)N * H * W;
   const long p0 = (long)chunk * chunk_px, p1 = min(P, p0 + chunk_px);
-  float acc[TAPS][COUT];
+  float4 acc[TAPS][COUT];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[t][c] = 0.f;
-  // dW[tap] pairs output pixel p with input pixel q = p + (tap - pad): walk the INPUT pixels q that any p of the chunk touches
-  // would double-count across chunks, so walk output pixels p and read X at the 9 shifted rows -- but only the rows of this
-  // thread's ci, and with the dY scalars hoisted: X[p + shift] is re-read 9x from L1/L2 within the chunk, never from HBM.
-  for (long p = p0; p < p1; ++p) {
-    const int xx = (int)(p % W);
-    const int y = (int)((p / W) % H);
-    float g[COUT];
+    for (int c = 0; c < COUT; ++c) acc[t][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // dW[tap] pairs output pixel p with input pixel p + (tap - pad): walk the output pixels of the chunk and read X at the 9 shifted
+  // rows (re-read from L1 / L2 within the chunk, never from HBM); the dY values and the border tests are wave-uniform
+  if (ci < CinP) {
+    for (long p = p0; p < p1; ++p) {
+      const int xx = (int)(p % W);
+      const int y = (int)((p / W) % H);
+      float g[COUT];
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) g[c] = dy[p * COUT + c];
+      for (int c = 0; c < COUT; ++c) g[c] = dy[p * COUT + c];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int kh = t / KW, kw = t - kh * KW;
-      const int iy = y - pad + kh, ix = xx - pad + kw;
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && ci < Cin) {
-        const float xv = x[(p + (long)(kh - pad) * W + (kw - pad)) * in_cstride + ci];
+      for (int t = 0; t < TAPS; ++t) {
+        const int kh = t / KW, kw = t - kh * KW;
+        const int iy = y - pad + kh, ix = xx - pad + kw;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+          const float4 xv = *reinterpret_cast<const float4*>(x + (p + (long)(kh - pad) * W + (kw - pad)) * in_cstride + ci);
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[t][c] = fmaf(g[c], xv, acc[t][c]);
+          for (int c = 0; c < COUT; ++c) {
+            acc[t][c].x = fmaf(g[c], xv.x, acc[t][c].x);
+            acc[t][c].y = fmaf(g[c], xv.y, acc[t][c].y);
+            acc[t][c].z = fmaf(g[c], xv.z, acc[t][c].z);
+            acc[t][c].w = fmaf(g[c], xv.w, acc[t][c].w);
+          }
+        }
       }
     }
-  }
-  if (ci < Cin) {
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-      for (int c = 0; c < COUT; ++c) partial[(((long)chunk * COUT + c) * TAPS + t) * Cin + ci] = acc[t][c];
+      for (int c = 0; c < COUT; ++c)
+        *reinterpret_cast<float4*>(partial + (((long)chunk * COUT + c) * TAPS + t) * CinP + ci) = acc[t][c];
   }
   if (blockIdx.y == 0 && threadIdx.x < COUT) {
     float sb = 0.f;
@@ -303,14 +310,16 @@ __global__ __launch_bounds__(256) void conv_small_cout_wgrad_partial_kernel(cons
 // workgroup = 64 outputs x 4 chunk groups (the chunk count is in the hundreds: a serial loop per output took 100 us)
 __global__ __launch_bounds__(256) void conv_small_cout_wgrad_final_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b,
                                                                           float* __restrict__ dw, float* __restrict__ db, int nchunk, int Cin,
-                                                                          int Cout, int KH, int KW) {
+                                                                          int CinP, int Cout, int KH, int KW) {
   const int ol = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const long idx = (long)blockIdx.x * 64 + ol;
-  const long per = (long)Cout * KH * KW * Cin;
+  const long per = (long)Cout * KH * KW * Cin, perP = (long)Cout * KH * KW * CinP;   // partial rows are CinP (multiple of 4) long
   __shared__ float red[4][64];
   float s = 0.f;
-  if (idx < per)
-    for (int c = grp; c < nchunk; c += 4) s += partial[(long)c * per + idx];
+  if (idx < per) {
+    const long pidx = (idx / Cin) * CinP + idx % Cin;
+    for (int c = grp; c < nchunk; c += 4) s += partial[(long)c * perP + pidx];
+  }
   red[grp][ol] = s;
   __syncthreads();
   if (grp == 0 && idx < per) {
@@ -501,12 +510,12 @@ int dim_upsample16_bwd(const float* dout_nchw, const float* w_c1_32_32, float* d
   return check_launch("upsample16_bwd");
 }
 
-static const int kSmallCoutChunkPx = 32;  // output pixels per workgroup of the wgrad partial pass (600 x 4 workgroups at 16x30x40)
+static const int kSmallCoutChunkPx = 64;  // output pixels per wave of the wgrad partial pass (300 x 4 waves at 16x30x40)
 
 long dim_conv_small_cout_bwd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW) {
   long nchunk = ceil_div((long)N * H * W, kSmallCoutChunkPx);
   long cin_pad = (Cin + 3) / 4 * 4;
-  return nchunk * ((long)Cout * KH * KW * Cin + Cout) + 4 + (long)KH * KW * Cout * cin_pad;  // chunk partials + transposed weight
+  return nchunk * ((long)Cout * KH * KW * cin_pad + Cout) + 4 + (long)KH * KW * Cout * cin_pad;  // chunk partials + transposed weight
 }
 
 int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw, float* dx, float* dw_oihw, float* db, float* workspace,
@@ -519,8 +528,11 @@ int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw
   const int nchunk = ceil_div((long)N * H * W, kSmallCoutChunkPx);
   const int CinPad = (Cin + 3) / 4 * 4;
   float* partial = workspace;
-  float* partial_b = workspace + (long)nchunk * Cout * KH * KW * Cin;
-  float* wt = workspace + (((long)nchunk * Cout * KH * KW * Cin + (long)nchunk * Cout + 3) / 4) * 4;  // 16-byte aligned
+  float* partial_b = workspace + (long)nchunk * Cout * KH * KW * CinPad;
+  float* wt = workspace + (((long)nchunk * Cout * KH * KW * CinPad + (long)nchunk * Cout + 3) / 4) * 4;  // 16-byte aligned
+  DIM_REQUIRE(in_cstride % 4 == 0 && in_cstride >= CinPad && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+              "small-Cout backward reads x 16 bytes at a time: in_cstride %% 4 == 0, >= Cin rounded up to 4, x and workspace 16-byte aligned");
   if (dx) {
     DIM_REQUIRE(dx_cstride % 4 == 0, "dx_cstride must be a multiple of 4");
     long wtot = (long)KH * KW * Cout * CinPad;
@@ -529,16 +541,16 @@ int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw
     hipLaunchKernelGGL(conv_small_cout_dgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, dy, wt, dx, N, H, W, Cin, CinPad,
                        dx_cstride, Cout, KH, KW, pad, accumulate_dx);
   }
-  dim3 grid(nchunk, ceil_div(Cin, 256));
+  dim3 grid(nchunk, ceil_div(CinPad, 256));
   if (Cout == 2)
-    hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<2, 9>), grid, dim3(256), 0, st, x, dy, partial, partial_b, N, H, W, Cin,
+    hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<2, 9>), grid, dim3(64), 0, st, x, dy, partial, partial_b, N, H, W, Cin, CinPad,
                        in_cstride, KH, KW, pad, kSmallCoutChunkPx);
   else
-    hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<1, 9>), grid, dim3(256), 0, st, x, dy, partial, partial_b, N, H, W, Cin,
+    hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<1, 9>), grid, dim3(64), 0, st, x, dy, partial, partial_b, N, H, W, Cin, CinPad,
                        in_cstride, KH, KW, pad, kSmallCoutChunkPx);
   long per = (long)Cout * KH * KW * Cin;
   hipLaunchKernelGGL(conv_small_cout_wgrad_final_kernel, dim3(ceil_div(per, 64)), dim3(256), 0, st, partial, partial_b, dw_oihw, db,
-                     nchunk, Cin, Cout, KH, KW);
+                     nchunk, Cin, CinPad, Cout, KH, KW);
   return check_launch("conv_small_cout_bwd");
 }
 

@@ -99,6 +99,30 @@ def test_lrelu_bwd(ops):
     np.testing.assert_allclose(dy.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 9, 11, 770, 800, 2), (1, 15, 20, 1026, 1056, 2), (3, 8, 10, 64, 64, 1), (2, 30, 40, 6, 8, 2),
+                                   (1, 13, 17, 258, 260, 1)])
+def test_conv_small_cout_backward(ops, shape):
+    """3x3 / pad 1 heads with 1 or 2 output channels (Convolution1-3, mask_conv3): dX, dW, db vs torch autograd in float64; channel counts
+    that are not multiples of 4 inside wider zero-padded rows (the concat buffers), pixel counts around the 64-pixel chunk"""
+    N, H, W, Cin, cs, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn((N, Cin, H, W), generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g, dtype=torch.float64) / np.sqrt(9 * Cin)).requires_grad_()
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, b, padding=1)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xb = torch.zeros((N, H, W, cs), device=DEV)
+    xb[..., :Cin] = nhwc(x.detach().float())
+    dx = torch.full((N, H, W, cs), 0.5, device=DEV)
+    dw = torch.empty((Cout, Cin, 3, 3), device=DEV)
+    db = torch.empty((Cout,), device=DEV)
+    ops.conv_small_cout_bwd(xb, Cin, nhwc(dy.float()), w.detach().float().to(DEV), dx, dw, db, accumulate_dx=True)
+    np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=1e-4, atol=2e-5 * w.grad.abs().max().item())
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dx[..., :Cin].permute(0, 3, 1, 2).cpu().numpy() - 0.5, x.grad.numpy(), rtol=1e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 7, 96, 128, 64, 16, 32), (3, 33, 41, 64, 64, 64, 0, 0), (1, 120, 160, 136, 200, 132, 4, 8)])
 def test_lrelu_bwd_bias_grad_fused(ops, shape):
     """one pass = lrelu_bwd followed by bias_grad (row counts below, at and far above one row block; channel ranges of wider buffers)"""
