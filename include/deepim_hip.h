@@ -154,7 +154,9 @@ int dim_box_mask(const int* bbox, float* mask, int B, int H, int W, int* bbox_of
  * weights: pack once from the reference layout (Cout,Cin,KH,KW).  Cin must be 8 or a multiple of 32,
  * Cout a multiple of 64.  y = LeakyReLU_slope(conv(x) + bias); slope 1.0 = linear.
  * splits > 1 = split-K through `workspace` (dim_conv2d_workspace_floats), deterministic reduce.
- * tile: 0 auto | 1 128x128 | 2 128x64 | 3 64x64 (pixels x channels per workgroup). */
+ * tile: 0 auto | 1 128x128 (4 waves) | 2 128x64 | 3 64x64 | 4 128x128 (8 waves) (GEMM rows x output channels per workgroup of the
+ *       gathered-tap kernel) | 6 the LDS-halo first-layer kernel (Cin 8, 7x7 / stride 2, Cout 64, dense f32 output).
+ * Outputs are stored through a buffer descriptor with 32-bit byte offsets: N*OH*OW*out_cstride*4 must stay below 2^31. */
 long dim_conv2d_packed_weight_floats(int Cout, int Cin, int KH, int KW);
 int dim_conv2d_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
 long dim_conv2d_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int splits);
@@ -267,7 +269,11 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
  * SAME packed array the f32 entry point takes (dim_conv2d_pack_weight, dim_conv2d_dgrad_pack_weight, dim_deconv4x4s2_pack_weight,
  * dim_conv2d_pack_weight_padded), so every packer is shared.  Arguments otherwise as the f32 functions (dim_conv2d_fwd_bf16:
  * splits >= 1, no "auto" mode).  dim_conv2d_wgrad_bf16 returns an fp32 gradient in the packed layout, like dim_conv2d_wgrad.
- * Declared tolerance vs the fp32 path: 2^-8 relative per product, i.e. ~4e-3 L2-relative on a layer output / gradient tensor. */
+ * Declared tolerance vs the fp32 path: 2^-8 relative per product, i.e. ~4e-3 L2-relative on a layer output / gradient tensor.
+ * bf16-only tiles: 7 = LDS-halo kernel (8 x 16 pixels x 128 channels; 3x3 / 5x5, stride 1 / 2, dense output); 8 = 128 x 256 gathered taps;
+ * 9 = stride-1 patch kernel (16 x 16 pixels x 128 or 64 channels, KH, KW <= 3 with 2 .. 9 taps, Cin % 32 == 0, Cout % 64 == 0, dense or
+ * scattered output, batched phases); dim_conv2d_dgrad_bf16 with tile 9 applies it to every phase of a strided gradient that has >= 2
+ * taps and runs the single-tap phase on the gathered-tap kernel. */
 int dim_f32_to_bf16(const float* src, void* dst_bf16, long n, void* stream);
 int dim_bf16_to_f32(const void* src_bf16, float* dst, long n, void* stream);
 int dim_conv2d_fwd_bf16(const float* x, const void* w_packed_bf16, const float* bias, float* y, float* workspace, int N, int H, int W,
