@@ -825,20 +825,24 @@ __device__ __forceinline__ void static_for(F&& f) {
 //    loaded NSETS-1 taps ahead into a rotating register set;
 //  * patch rows are 1536 B apart (a multiple of 256 B) and pixels 80 B: a ds_read_b128 lane group ({0-3,12-15,20-27}: two pixel
 //    rows of an MFMA tile) then covers all 64 banks exactly once.
-template <int KH, int KW, int BN>
+template <int KH, int KW, int BN, int S>
 __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
   constexpr int NT = KH * KW;
-  constexpr int TH = 16, TW = 16;
+  // S = 1: 16 x 16 output pixels per workgroup; S = 2 (the stride-2 forward layers): 8 x 16, and the patch keeps the even and the odd
+  // input columns of a row in two halves (1536 B apart), so that the 16 pixels of a fragment row -- every second input column --
+  // are 80 B apart again and the bank argument below holds for both strides
+  constexpr int TH = S == 1 ? 16 : 8, TW = 16;
+  constexpr int TMW = TH / 4;                         // 32-pixel MFMA tiles (2 rows x 16) per wave: the wave's TH / 2 rows
   constexpr int TN = BN / 64;                         // 32-channel tiles per wave: BN = 128 (2 x 64 per wave column) or 64 (2 x 32)
-  static_assert(BN == 128 || BN == 64, "channel tile");
-  constexpr int PH = TH + KH - 1, PW = TW + KW - 1;
-  constexpr int PXB = 80, PITCH = 1536, PBUF = PH * PITCH;
+  static_assert((BN == 128 || BN == 64) && (S == 1 || S == 2), "channel tile / stride");
+  constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;   // input rows / columns under the block
+  constexpr int PXB = 80, HALF = 1536, PITCH = S * HALF, PBUF = PH * PITCH;
   constexpr int NITEM = PH * PW * 8;                 // float4 pieces of one patch slice
   constexpr int PITEMS = (NITEM + 255) / 256;        // per thread
-  constexpr int NSETS = NT % 3 == 0 ? 3 : (NT % 4 == 0 ? 4 : 2);
+  constexpr int NSETS = NT % 3 == 0 ? 3 : (NT % 4 == 0 ? 4 : (NT % 5 == 0 ? 5 : 2));
   constexpr int PF = NSETS - 1;                      // weight prefetch distance in taps
   constexpr int IPT = (PITEMS + (NT > 1 ? NT - 2 : 0)) / (NT > 1 ? NT - 1 : 1);   // patch pieces fetched per tap (taps 0 .. NT-2)
-  static_assert(NT >= 2 && NT % NSETS == 0 && PW * PXB <= PITCH && IPT * (NT - 1) >= PITEMS, "tap plan");
+  static_assert(NT >= 2 && NT % NSETS == 0 && ((PW + S - 1) / S) * PXB <= HALF && IPT * (NT - 1) >= PITEMS, "tap plan");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* patch = reinterpret_cast<char*>(smem);       // [2][PH][PITCH] bytes + 256 B dump slot
 
@@ -854,7 +858,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
   const int thi = id % tiles_h;
   const int n = id / tiles_h;
   const int ho0 = thi * TH, wo0 = twi * TW;
-  const int hi0 = ho0 - a.pad_h, wi0 = wo0 - a.pad_w;
+  const int hi0 = ho0 * S - a.pad_h, wi0 = wo0 * S - a.pad_w;
   const float* xb = a.x + (long)blockIdx.y * a.bx;
   const char* wb = reinterpret_cast<const char*>(a.w) + (long)blockIdx.y * a.bw * 2;
   float* yb = a.y + (long)blockIdx.y * a.by;
@@ -873,12 +877,12 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
     const int hi = hi0 + py, wi = wi0 + px;
     const bool ok = item < NITEM && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
     p_goff[u] = ok ? (((n * a.H + hi) * a.W + wi) * a.in_cstride + q * 4) * 4 : -1;
-    p_loff[u] = item < NITEM ? py * PITCH + px * PXB + q * 8 : -1;
+    p_loff[u] = item < NITEM ? py * PITCH + (S == 2 ? (px & 1) * HALF + (px >> 1) * PXB : px * PXB) + q * 8 : -1;
   }
 
-  // ---- fragments (wave (wm, wn): pixel rows 8 wm .. 8 wm + 7, channels (BN / 2) wn .. + BN / 2)
+  // ---- fragments (wave (wm, wn): output rows (TH / 2) wm .. + TH / 2, channels (BN / 2) wn .. + BN / 2)
   const int frow = lane & 31, khalf = lane >> 5;
-  const int a_off = (8 * wm + (frow >> 4)) * PITCH + (frow & 15) * PXB + 16 * khalf;   // + 2 i PITCH, + kh PITCH + kw PXB, + 32 ks
+  const int a_off = ((TH / 2) * wm + (frow >> 4)) * S * PITCH + (frow & 15) * PXB + 16 * khalf;   // + 2 i S PITCH, + tap offset, + 32 ks
   const int b_voff = ((n0 + (BN / 2) * wn + frow) * 32 + 8 * khalf) * 2;                      // + 32 j rows, + 16 ks elements
   bf16x8 fb[NSETS][2][TN];  // [set][k-step][channel tile]
   auto load_b = [&](auto SET, int chunk) {
@@ -892,9 +896,9 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
         fb[set][ks][j] = *reinterpret_cast<bf16x8*>(&v);
       }
   };
-  f32x16 acc[4][TN];
+  f32x16 acc[TMW][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TMW; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -913,19 +917,21 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
   if constexpr (PF >= 1) load_b(std::integral_constant<int, 0>{}, 0);
   if constexpr (PF >= 2) load_b(std::integral_constant<int, 1>{}, min(1, last_chunk));
   if constexpr (PF >= 3) load_b(std::integral_constant<int, 2>{}, min(2, last_chunk));
+  if constexpr (PF >= 4) load_b(std::integral_constant<int, 3>{}, min(3, last_chunk));
   __syncthreads();
 
   int buf = 0;
   float4 st[2][IPT];   // two batches of patch pieces in flight
-  bf16x8 fa[2][2][4];  // [tap parity][k-step][pixel tile]
+  bf16x8 fa[2][2][TMW];  // [tap parity][k-step][pixel tile]
   auto load_a = [&](auto SET, const char* pc, auto TAP) {
     constexpr int set = decltype(SET)::value, tap = decltype(TAP)::value;
     constexpr int kh = tap / KW, kw = tap - kh * KW;
+    constexpr int tap_off = kh * PITCH + (S == 2 ? (kw & 1) * HALF + (kw >> 1) * PXB : kw * PXB);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        fa[set][ks][i] = *reinterpret_cast<const bf16x8*>(pc + (kh + 2 * i) * PITCH + kw * PXB + 32 * ks);
+      for (int i = 0; i < TMW; ++i)
+        fa[set][ks][i] = *reinterpret_cast<const bf16x8*>(pc + tap_off + 2 * i * S * PITCH + 32 * ks);
   };
   for (int cc = 0; cc < nslices; ++cc) {
     const char* pcur = patch + buf * PBUF + a_off;
@@ -956,7 +962,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TMW; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][ks][i], fb[t % NSETS][ks][j], acc[i][j], 0, 0, 0);
@@ -970,7 +976,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
           }
         }
       }
-      constexpr int NM = 8 * TN;   // MFMAs of the tap
+      constexpr int NM = 2 * TMW * TN;   // MFMAs of the tap
       static_for<NM>([&](auto Mi) {
         constexpr int m = decltype(Mi)::value;
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // one MFMA
@@ -978,7 +984,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                     // address arithmetic of ...
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // ... one global load
         }
-        if constexpr (m < 8 && t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one A-fragment read
+        if constexpr (m < 2 * TMW && t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one A-fragment read
         if constexpr (m >= NM - NST) {
           __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                     // round one piece ...
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                     // ... and store it
@@ -1001,14 +1007,14 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
   const int oy_base = a.ooy + (by >> 1) * a.boy, ox_base = a.oox + (by & 1) * a.box;
   // this lane's 64 pixel slots: row 8 wm + 2 i + (r >> 3), column 4 khalf + (r & 3) + 8 ((r >> 2) & 1) of the 16 x 16 block; the byte
   // offset is affine in both (channel co of tile j = + 128 j bytes), and a block that lies inside the output needs no per-pixel test
-  const int hob = ho0 + 8 * wm, wob = wo0 + 4 * khalf;
+  const int hob = ho0 + (TH / 2) * wm, wob = wo0 + 4 * khalf;
   const int row_b = a.osy * a.OW * a.out_cstride * 4, col_b = a.osx * a.out_cstride * 4;
   const int base_b = (((n * a.OH + hob * a.osy + oy_base) * a.OW + wob * a.osx + ox_base) * a.out_cstride + a.out_coff + n0 + (BN / 2) * wn + frow) * 4;
   const bool inside = ho0 + TH <= a.Ho && wo0 + TW <= a.Wo && ho0 * a.osy + oy_base >= 0 && (ho0 + TH - 1) * a.osy + oy_base < a.OH &&
                       wo0 * a.osx + ox_base >= 0 && (wo0 + TW - 1) * a.osx + ox_base < a.OW;   // workgroup-uniform
-  int voff[4][16];
+  int voff[TMW][16];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TMW; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int dr = 2 * i + (r >> 3), dc = (r & 3) + 8 * ((r >> 2) & 1);
@@ -1016,7 +1022,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
     }
   if (!inside) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ho = hob + 2 * i + (r >> 3), wo = wob + (r & 3) + 8 * ((r >> 2) & 1);
@@ -1032,7 +1038,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < TMW; ++i) {
         float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, voff[i][r], 128 * j, 0));
@@ -1047,7 +1053,7 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TMW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = acc[i][j][r] + bv[j];
@@ -1557,38 +1563,47 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
     return check_launch("conv_bf16_halo");
   }
   if (tile == 9) {
-    // the bf16 stride-1 patch kernel (conv_bf16_patch_kernel): 2 .. 9 taps with KH, KW <= 3, Cin % 32 == 0, Cout % 128 == 0; dense or
-    // scattered output, batched launch (deconvolution phases) allowed, no split-K
-    DIM_REQUIRE(a.bf16 && stride == 1 && KH >= 1 && KH <= 3 && KW >= 1 && KW <= 3 && KH * KW >= 2 && Cin % 32 == 0 && Cout % 64 == 0,
-                "tile 9: bf16, stride 1, 2..9 taps (KH, KW <= 3), Cin %% 32 == 0, Cout %% 64 == 0");
-    DIM_REQUIRE(splits == 1 && !partial_only, "tile 9: no split-K");
+    // the bf16 patch kernel (conv_bf16_patch_kernel).  Stride 1: 2 .. 9 taps with KH, KW <= 3, 16 x 16 output pixels x 128 or 64
+    // channels per workgroup; stride 2: 3x3 or 5x5, 8 x 16 pixels x 128 channels.  Cin % 32 == 0; dense or scattered output, batched
+    // launch (deconvolution phases) allowed, no split-K
+    DIM_REQUIRE(a.bf16 && Cin % 32 == 0 && splits == 1 && !partial_only, "tile 9: bf16, Cin %% 32 == 0, no split-K");
+    if (stride == 1)
+      DIM_REQUIRE(KH >= 1 && KH <= 3 && KW >= 1 && KW <= 3 && KH * KW >= 2 && Cout % 64 == 0,
+                  "tile 9, stride 1: 2..9 taps (KH, KW <= 3), Cout %% 64 == 0");
+    else
+      DIM_REQUIRE(stride == 2 && KH == KW && (KH == 3 || KH == 5) && Cout % 128 == 0, "tile 9, stride 2: 3x3 or 5x5, Cout %% 128 == 0");
     const int bn = Cout % 128 == 0 ? 128 : 64;   // 64: the 64-channel layers (input gradient of flow_conv2)
-    const int blocks = N * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16) * (Cout / bn);
-    const size_t lds = (size_t)2 * (16 + KH - 1) * 1536 + 256;   // two patch buffers + the dump slot
-#define DIM_PATCH16_BN(KHc, KWc, BNc)                                                                                                 \
+    const int th = stride == 1 ? 16 : 8;
+    const int blocks = N * ((a.Ho + th - 1) / th) * ((a.Wo + 15) / 16) * (Cout / bn);
+    const size_t lds = (size_t)2 * ((th - 1) * stride + KH) * (1536 * stride) + 256;   // two patch buffers + the dump slot
+#define DIM_PATCH16_BN(KHc, KWc, BNc, Sc)                                                                                             \
   {                                                                                                                                   \
     static bool attr_set = false;                                                                                                     \
     if (!attr_set) {                                                                                                                  \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_patch_kernel<KHc, KWc, BNc>),                       \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_patch_kernel<KHc, KWc, BNc, Sc>),                   \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
       if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));             \
       attr_set = true;                                                                                                                \
     }                                                                                                                                 \
-    hipLaunchKernelGGL((conv_bf16_patch_kernel<KHc, KWc, BNc>), dim3(blocks, batch), dim3(256), lds, st, a);                          \
+    hipLaunchKernelGGL((conv_bf16_patch_kernel<KHc, KWc, BNc, Sc>), dim3(blocks, batch), dim3(256), lds, st, a);                      \
   }
 #define DIM_PATCH16(KHc, KWc)                                                                                                         \
   {                                                                                                                                   \
-    if (bn == 128) DIM_PATCH16_BN(KHc, KWc, 128) else DIM_PATCH16_BN(KHc, KWc, 64)                                                    \
+    if (bn == 128) DIM_PATCH16_BN(KHc, KWc, 128, 1) else DIM_PATCH16_BN(KHc, KWc, 64, 1)                                              \
   }
-    switch (KH * 4 + KW) {
-      case 1 * 4 + 2: DIM_PATCH16(1, 2) break;
-      case 2 * 4 + 1: DIM_PATCH16(2, 1) break;
-      case 1 * 4 + 3: DIM_PATCH16(1, 3) break;
-      case 3 * 4 + 1: DIM_PATCH16(3, 1) break;
-      case 2 * 4 + 2: DIM_PATCH16(2, 2) break;
-      case 2 * 4 + 3: DIM_PATCH16(2, 3) break;
-      case 3 * 4 + 2: DIM_PATCH16(3, 2) break;
-      default: DIM_PATCH16(3, 3) break;
+    if (stride == 2) {
+      if (KH == 5) DIM_PATCH16_BN(5, 5, 128, 2) else DIM_PATCH16_BN(3, 3, 128, 2)
+    } else {
+      switch (KH * 4 + KW) {
+        case 1 * 4 + 2: DIM_PATCH16(1, 2) break;
+        case 2 * 4 + 1: DIM_PATCH16(2, 1) break;
+        case 1 * 4 + 3: DIM_PATCH16(1, 3) break;
+        case 3 * 4 + 1: DIM_PATCH16(3, 1) break;
+        case 2 * 4 + 2: DIM_PATCH16(2, 2) break;
+        case 2 * 4 + 3: DIM_PATCH16(2, 3) break;
+        case 3 * 4 + 2: DIM_PATCH16(3, 2) break;
+        default: DIM_PATCH16(3, 3) break;
+      }
     }
 #undef DIM_PATCH16_BN
 #undef DIM_PATCH16

@@ -72,6 +72,13 @@ FWD_CASES = [
     (1, 16, 16, 32, 128, 3, 1, 1, 9, 1),
     (2, 20, 33, 64, 64, 3, 1, 1, 9, 1),    # 64-channel tile
     (1, 17, 16, 32, 192, 3, 1, 1, 9, 1),   # 192 = 3 x 64
+    # tile 9 at stride 2 (8 x 16 output blocks, even / odd input columns in two patch halves)
+    (2, 30, 40, 64, 128, 5, 2, 2, 9, 1),
+    (1, 23, 31, 64, 128, 5, 2, 2, 9, 1),
+    (1, 37, 53, 32, 128, 5, 2, 2, 9, 1),
+    (2, 15, 20, 256, 512, 3, 2, 1, 9, 1),
+    (3, 9, 11, 96, 128, 3, 2, 1, 9, 1),
+    (1, 32, 32, 32, 256, 3, 2, 1, 9, 1),
 ]
 
 
