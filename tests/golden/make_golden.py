@@ -7,7 +7,8 @@ only inputs and expected outputs are stored.
 Modules imported from /root/reference:
   lib/pair_matching/RT_transform.py  (numpy-2 alias shim for its module-level np.float uses, :246-247)
   lib/pair_matching/flow.py (calc_flow), lib/utils/pose_error.py (add, adi, arp_2d, re, te),
-  lib/utils/get_min_rect.py, lib/utils/projection.py (se3_mul, se3_inverse, backproject_camera), lib/utils/mask_dilate.py
+  lib/utils/get_min_rect.py, lib/utils/projection.py (se3_mul, se3_inverse, backproject_camera), lib/utils/mask_dilate.py,
+  deepim/core/callback.py (Speedometer)
 """
 import os
 import sys
@@ -191,15 +192,71 @@ def data_layer_vectors():
                         cf_visible=v_std.astype(np.float32), cf_X_valid=np.asarray(X_valid, dtype=np.float64))
 
 
+def callback_vectors():
+    """N2 (deepim/core/callback.py, importable: time + logging only): the lines Speedometer prints for a scripted sequence of batch-end
+    callbacks under a scripted clock (the module's `time.time` is replaced for the run) -- with a metric, without one, across an epoch
+    boundary (batch counter going backwards) and with a counter that skips multiples of `frequent`."""
+    import json
+    from collections import namedtuple
+
+    from deepim.core import callback as ref_cb
+
+    Param = namedtuple("Param", ["epoch", "nbatch", "eval_metric", "locals"])
+
+    class Metric(object):
+        def __init__(self, names, values):
+            self.names, self.values = names, values
+
+        def get(self):
+            return self.names, self.values
+
+    scripts = []
+    rng = np.random.default_rng(7)
+    for case, (batch, freq, with_metric) in enumerate([(16, 3, True), (4, 5, False), (64, 2, True), (1, 1, True)]):
+        events, t, clock = [], 100.0 * (case + 1), []
+        for epoch in range(3):
+            n = int(rng.integers(4, 12))
+            counts = list(range(n)) if case != 2 else [int(c) for c in np.cumsum(rng.integers(1, 3, size=n))]
+            for c in counts:
+                vals = [float(v) for v in rng.uniform(0.0, 3.0, size=3)]
+                events.append({"epoch": epoch, "nbatch": int(c), "metric": vals if with_metric else None})
+        names = ["Flow_L2Loss", "MaskLoss", "PointMatchingLoss"]
+        ticks = [float(v) for v in np.cumsum(rng.uniform(0.05, 0.4, size=3 * len(events) + 8)) + t]
+        it = iter(ticks)
+        lines = []
+        real_time, real_print = ref_cb.time.time, None
+        ref_cb.time.time = lambda: next(it)
+        import builtins
+        real_print = builtins.print
+        builtins.print = lambda *a, **k: lines.append(" ".join(str(x) for x in a))
+        try:
+            sp = ref_cb.Speedometer(batch, freq)
+            per_event = []
+            for e in events:
+                before = len(lines)
+                sp(Param(e["epoch"], e["nbatch"], Metric(names, e["metric"]) if e["metric"] is not None else None, None))
+                per_event.append(lines[before] if len(lines) > before else None)
+        finally:
+            ref_cb.time.time = real_time
+            builtins.print = real_print
+        scripts.append({"batch_size": batch, "frequent": freq, "metric_names": names, "events": events, "clock": ticks, "lines": per_event})
+    with open(os.path.join(HERE, "callback_golden.json"), "w") as f:
+        json.dump(scripts, f, indent=0)
+
+
 if __name__ == "__main__":
     if "--data-only" in sys.argv:
         data_layer_vectors()
+        sys.exit(0)
+    if "--callback-only" in sys.argv:
+        callback_vectors()
         sys.exit(0)
     se3_vectors()
     flow_vectors()
     pose_error_vectors()
     min_rect_vectors()
     data_layer_vectors()
+    callback_vectors()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
