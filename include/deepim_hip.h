@@ -315,6 +315,17 @@ int dim_logistic_grad(const float* logits, const float* label, float* grad, floa
                       void* stream);
 int dim_pm_l1_grad(const float* p_est, const float* p_obs, const float* weights, float* grad, long n, float norm_term, float grad_scale,
                    float* loss_sum, void* stream);
+/* the point-matching loss with SE3_PM_LOSS_TYPE 'L1' (0, = dim_pm_l1_grad) | 'L2' (1) | 'smooth_L1' (2, mx.sym.smooth_l1 with
+ * scalar = SE3_PM_SL1_SCALAR)   (deepIM_flownet.py:458-499) */
+int dim_pm_loss_grad(const float* p_est, const float* p_obs, const float* weights, float* grad, long n, float norm_term, float grad_scale,
+                     int loss_type, float smooth_l1_scalar, float* loss_sum, void* stream);
+/* SE3_DIST_LOSS (deepIM_flownet.py:396-437): rot_loss = 1 - (rot_gt . rot_est_norm)^2 with grad_scale LW_ROT and trans_loss =
+ * TRANS_LOSS_TYPE(zoom_trans_est - zoom_trans_gt) with grad_scale LW_TRANS; zoom_trans_est = trans_w fc7 + trans_b is recomputed from
+ * fc7 (B,256).  The gradients are ADDED to d_rot_norm (B,4) / d_zoom_trans (B,3), the inputs of dim_pose_head_bwd; loss_sums2 (2
+ * floats, may be NULL) accumulate the un-scaled rot / trans loss sums (metrics Rot_L2Loss / Trans_L2Loss). */
+int dim_se3_dist_loss_grad(const float* rot_est_norm, const float* rot_gt, const float* fc7, const float* trans_w, const float* trans_b,
+                           const float* zoom_trans_gt, float* d_rot_norm, float* d_zoom_trans, int B, float lw_rot, float lw_trans,
+                           int trans_loss_type, float smooth_l1_scalar, float* loss_sums2, void* stream);
 /* L2Normalization(instance, eps 1e-10) of the quaternion head; backward of the pose head down to dz6 (B,256) */
 int dim_quat_normalize(const float* rot, float* rot_norm, int B, void* stream);
 int dim_pose_head_bwd(const float* fc6a, const float* fc7, const float* rot_raw, const float* d_rot_norm, const float* d_trans,

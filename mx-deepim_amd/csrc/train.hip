@@ -116,6 +116,68 @@ __global__ void pm_l1_grad_kernel(const float* __restrict__ p_est, const float* 
   }
 }
 
+// The element losses get_loss offers besides |x| (deepIM_flownet.py:414-426, :460-487): value and derivative of
+//   type 0  |x|        type 1  x^2        type 2  mx.sym.smooth_l1(x, scalar = s): 0.5 (s x)^2 if |x| < 1 / s^2, else |x| - 0.5 / s^2
+__device__ __forceinline__ float elem_loss(int type, float x, float s, float* dfdx) {
+  const float ax = fabsf(x), sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+  if (type == 1) { *dfdx = 2.f * x; return x * x; }
+  if (type == 2) {
+    const float s2 = s * s;
+    if (ax < 1.f / s2) { *dfdx = s2 * x; return 0.5f * s2 * x * x; }
+    *dfdx = sg;
+    return ax - 0.5f / s2;
+  }
+  *dfdx = sg;
+  return ax;
+}
+
+// point-matching loss of any of the three types (dim_pm_l1_grad is type 0): grad = gs * w * f'(d) / norm, d = (p_est - p_obs) / norm
+__global__ void pm_loss_grad_kernel(const float* __restrict__ p_est, const float* __restrict__ p_obs, const float* __restrict__ wgt,
+                                    float* __restrict__ grad, long n, float inv_norm, float gs, int type, float sl1, float* __restrict__ loss_sum) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float local = 0.f;
+  if (i < n) {
+    float df;
+    const float v = elem_loss(type, (p_est[i] - p_obs[i]) * inv_norm, sl1, &df);
+    grad[i] = gs * wgt[i] * df * inv_norm;
+    local = wgt[i] * v;
+  }
+  if (loss_sum) {
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);
+  }
+}
+
+// SE3_DIST_LOSS (deepIM_flownet.py:396-437), one thread per sample:
+//   rot_loss   = 1 - (rot_gt . rot_est_norm)^2                      d / d rot_est_norm = -2 (rot_gt . rot_est_norm) rot_gt
+//   trans_loss = f(zoom_trans_est - zoom_trans_gt)  (3 values)      zoom_trans_est = the raw output of the `trans` layer, recomputed
+//                                                                    here from fc7 (3 x 256 multiply-adds) so the forward keeps its outputs
+// MakeLoss(grad_scale = LW_ROT / LW_TRANS), no normalisation: the gradients are ADDED to d_rot_norm / d_ztrans (which hold the
+// point-matching gradients, or zeros); loss_sums[0..1] accumulate the un-scaled sums for the Rot_L2Loss / Trans_L2Loss metrics.
+__global__ void se3_dist_loss_grad_kernel(const float* __restrict__ rot_norm, const float* __restrict__ rot_gt, const float* __restrict__ fc7,
+                                          const float* __restrict__ wt, const float* __restrict__ bt, const float* __restrict__ ztrans_gt,
+                                          float* __restrict__ d_rot_norm, float* __restrict__ d_ztrans, int B, float lw_rot, float lw_trans,
+                                          int trans_type, float sl1, float* __restrict__ loss_sums) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* q = rot_norm + 4 * b;
+  const float* g = rot_gt + 4 * b;
+  const float dot = g[0] * q[0] + g[1] * q[1] + g[2] * q[2] + g[3] * q[3];
+  for (int i = 0; i < 4; ++i) d_rot_norm[4 * b + i] += -2.f * lw_rot * dot * g[i];
+  float tl = 0.f;
+  for (int j = 0; j < 3; ++j) {
+    float tz = bt[j];
+    for (int k = 0; k < 256; ++k) tz = fmaf(fc7[(long)b * 256 + k], wt[j * 256 + k], tz);
+    float df;
+    tl += elem_loss(trans_type, tz - ztrans_gt[3 * b + j], sl1, &df);
+    d_ztrans[3 * b + j] += lw_trans * df;
+  }
+  if (loss_sums) {
+    atomicAdd(loss_sums, 1.f - dot * dot);
+    atomicAdd(loss_sums + 1, tl);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- pose head backward
 // L2Normalization(instance, eps=1e-10) forward: y = x / sqrt(sum x^2 + eps)
 __global__ void quat_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, int B) {
@@ -474,6 +536,28 @@ int dim_pm_l1_grad(const float* p_est, const float* p_obs, const float* weights,
   hipLaunchKernelGGL(pm_l1_grad_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), p_est, p_obs, weights, grad, n,
                      1.0f / norm_term, grad_scale, loss_sum);
   return check_launch("pm_l1_grad");
+}
+
+int dim_pm_loss_grad(const float* p_est, const float* p_obs, const float* weights, float* grad, long n, float norm_term, float grad_scale,
+                     int loss_type, float smooth_l1_scalar, float* loss_sum, void* stream) {
+  if (n == 0) return DIM_OK;
+  DIM_REQUIRE(p_est && p_obs && weights && grad, "null pointer");
+  DIM_REQUIRE(loss_type >= 0 && loss_type <= 2 && (loss_type != 2 || smooth_l1_scalar > 0.f), "loss_type 0 L1 | 1 L2 | 2 smooth_L1 (scalar > 0)");
+  hipLaunchKernelGGL(pm_loss_grad_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), p_est, p_obs, weights, grad, n,
+                     1.0f / norm_term, grad_scale, loss_type, smooth_l1_scalar, loss_sum);
+  return check_launch("pm_loss_grad");
+}
+
+int dim_se3_dist_loss_grad(const float* rot_est_norm, const float* rot_gt, const float* fc7, const float* trans_w, const float* trans_b,
+                           const float* zoom_trans_gt, float* d_rot_norm, float* d_zoom_trans, int B, float lw_rot, float lw_trans,
+                           int trans_loss_type, float smooth_l1_scalar, float* loss_sums2, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(rot_est_norm && rot_gt && fc7 && trans_w && trans_b && zoom_trans_gt && d_rot_norm && d_zoom_trans, "null pointer");
+  DIM_REQUIRE(trans_loss_type >= 0 && trans_loss_type <= 2 && (trans_loss_type != 2 || smooth_l1_scalar > 0.f),
+              "trans_loss_type 0 L1 | 1 L2 | 2 smooth_L1 (scalar > 0)");
+  hipLaunchKernelGGL(se3_dist_loss_grad_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), rot_est_norm, rot_gt, fc7, trans_w,
+                     trans_b, zoom_trans_gt, d_rot_norm, d_zoom_trans, B, lw_rot, lw_trans, trans_loss_type, smooth_l1_scalar, loss_sums2);
+  return check_launch("se3_dist_loss_grad");
 }
 
 int dim_quat_normalize(const float* rot, float* rot_norm, int B, void* stream) {

@@ -72,6 +72,28 @@ class Flow_CurLossMetric(EvalMetric):
         self.num_inst = 480 * 640
 
 
+class Rot_L2LossMetric(EvalMetric):
+    """sum of rot_loss = 1 - (rot_gt . rot_est_norm)^2 per update, one instance per update (reference metric.py:80-91)"""
+
+    def __init__(self, cfg, iter_idx=-1):
+        super(Rot_L2LossMetric, self).__init__("Rot_L2Loss")
+
+    def update(self, labels, preds):
+        self.sum_metric += _f(preds["rot_loss_sum"])
+        self.num_inst += 1
+
+
+class Trans_L2LossMetric(EvalMetric):
+    """sum of trans_loss (TRANS_LOSS_TYPE of zoom_trans_est - zoom_trans_gt) per update (reference metric.py:94-105)"""
+
+    def __init__(self, cfg, iter_idx=-1):
+        super(Trans_L2LossMetric, self).__init__("Trans_L2Loss")
+
+    def update(self, labels, preds):
+        self.sum_metric += _f(preds["trans_loss_sum"])
+        self.num_inst += 1
+
+
 class PointMatchingLossMetric(EvalMetric):
     def __init__(self, cfg, iter_idx=-1):
         super(PointMatchingLossMetric, self).__init__("PointMatchingLoss")

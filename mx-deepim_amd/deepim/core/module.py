@@ -48,10 +48,14 @@ class MutableModule(object):
         cfg = config
         assert compute_dtype in ("f32", "bf16"), compute_dtype
         self.bf16 = compute_dtype == "bf16"
-        if not (cfg.network.PRED_FLOW and cfg.network.PRED_MASK and cfg.train_iter.SE3_PM_LOSS and not cfg.train_iter.SE3_DIST_LOSS):
-            raise NotImplementedError("the HIP training graph covers the shipped configuration: PRED_FLOW, PRED_MASK, SE3_PM_LOSS (L1)")
-        if cfg.train_iter.SE3_PM_LOSS_TYPE != "L1":
-            raise Exception("Unknown Point Matching Loss Type on the HIP path: {}".format(cfg.train_iter.SE3_PM_LOSS_TYPE))
+        if not (cfg.network.PRED_FLOW and cfg.network.PRED_MASK):
+            raise NotImplementedError("the HIP training graph always carries the decoder with both heads (PRED_FLOW, PRED_MASK: every shipped "
+                                      "configuration); graphs without one of them are not wired")
+        if not (cfg.train_iter.SE3_PM_LOSS or cfg.train_iter.SE3_DIST_LOSS):
+            raise Exception("no pose loss: set train_iter.SE3_PM_LOSS and / or train_iter.SE3_DIST_LOSS")
+        for what, kind in (("SE3_PM_LOSS_TYPE", cfg.train_iter.SE3_PM_LOSS_TYPE), ("TRANS_LOSS_TYPE", cfg.train_iter.TRANS_LOSS_TYPE)):
+            if kind not in ops.LOSS_TYPE_ID:   # the reference raises for anything else too (deepIM_flownet.py:427-431, :486-491)
+                raise Exception("Unknown {}: {}".format(what, kind))
         self.cfg = cfg
         self.B = batch_size
         self.device = torch.device(device)
@@ -114,7 +118,7 @@ class MutableModule(object):
         self.mask_logit = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
         self.mask_prob = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
         self.rot_norm = torch.empty((B, 4), dtype=torch.float32, device=d)
-        self.loss_sums = torch.zeros(3, dtype=torch.float32, device=d)  # flow, pm (un-scaled sums; metrics only)
+        self.loss_sums = torch.zeros(5, dtype=torch.float32, device=d)  # flow, pm, -, rot, trans (un-scaled sums; metrics only)
         self.T_means = np.asarray(cfg.dataset.trans_means, dtype=np.float32)
         self.T_stds = np.asarray(cfg.dataset.trans_stds, dtype=np.float32)
 
@@ -264,12 +268,21 @@ class MutableModule(object):
         ops.flow_loss_grad(self.flow_est_crop, self.zoom_flow_lab, self.zoom_flow_w, self.dflow_full, cfg.dataset.NORMALIZE_FLOW,
                            ti.LW_FLOW / (480.0 * 640.0), loss_sum=self.loss_sums[0:1])
         ops.logistic_grad(self.mask_logit, self.zoom_mask_gt, self.dlogit, ti.LW_MASK / (480.0 * 640.0), prob=self.mask_prob)
-        if self.dpts is None:
-            self.dpts = torch.empty_like(self.pts_est)
-        ops.pm_l1_grad(self.pts_est, batch["point_cloud_observed"], batch["point_cloud_weights"], self.dpts,
-                       cfg.dataset.NORMALIZE_3D_POINT, ti.LW_PM / float(ti.NUM_3D_SAMPLE), loss_sum=self.loss_sums[1:2])
-        d_rn, d_t = ops.transform3d_bwd(self.dpts, batch["point_cloud_model"], self.rot_norm, self.trans_est, batch["src_pose"],
-                                        cfg.network.ROT_COORD, self.T_means, self.T_stds)
+        if ti.SE3_PM_LOSS:   # point matching (:440-499): L1 / L2 / smooth_L1 on (Transform3D(model points) - observed points) / norm
+            if self.dpts is None:
+                self.dpts = torch.empty_like(self.pts_est)
+            ops.pm_loss_grad(self.pts_est, batch["point_cloud_observed"], batch["point_cloud_weights"], self.dpts,
+                             cfg.dataset.NORMALIZE_3D_POINT, ti.LW_PM / float(ti.NUM_3D_SAMPLE), ti.SE3_PM_LOSS_TYPE, ti.SE3_PM_SL1_SCALAR,
+                             loss_sum=self.loss_sums[1:2])
+            d_rn, d_t = ops.transform3d_bwd(self.dpts, batch["point_cloud_model"], self.rot_norm, self.trans_est, batch["src_pose"],
+                                            cfg.network.ROT_COORD, self.T_means, self.T_stds)
+        else:
+            d_rn = torch.zeros((B, 4), dtype=torch.float32, device=self.device)
+            d_t = torch.zeros((B, 3), dtype=torch.float32, device=self.device)
+        if ti.SE3_DIST_LOSS:   # :396-437; labels "rot" / "trans" = calc_RT_delta(src, gt) as the data layer delivers them (data_pair.py:201-251)
+            zt_gt = ops.zoom_trans(net.zoom_factor, batch["trans"].contiguous(), 1)   # ZoomTrans, b_inv_zoom False (:659-665)
+            ops.se3_dist_loss_grad(self.rot_norm, batch["rot"].contiguous(), net.fc7, w, zt_gt, d_rn, d_t, ti.LW_ROT, ti.LW_TRANS,
+                                   ti.TRANS_LOSS_TYPE, ti.TRANS_SMOOTH_L1_SCALAR, loss_sums2=self.loss_sums[3:5])
         # ---------------- flow / mask heads
         ops.upsample16_bwd(self.dflow_full, w["upsampling_weight"], self.dflow4)
         ops.conv_small_cout_bwd(net.concat3, 770, self.dflow4, w["Convolution3_weight"], self.dconcat3, g["Convolution3_weight"],
@@ -507,6 +520,7 @@ def fit_batch(module, data_batch, batch_updater, lr):
                      "loss_sums": module.loss_sums.clone(),
                      # what deepim/core/metric.py reads (Flow_L2Loss, PointMatchingLoss, MaskLoss)
                      "flow_loss_sum": module.loss_sums[0].clone(), "point_matching_loss_sum": module.loss_sums[1].clone(),
+                     "rot_loss_sum": module.loss_sums[3].clone(), "trans_loss_sum": module.loss_sums[4].clone(),
                      "mask_prob": module.mask_prob, "mask_gt": module.zoom_mask_gt})
         module.update(lr(module.num_update + 1) if callable(lr) else lr)
         if iter_idx != n_iter - 1:

@@ -92,6 +92,9 @@ def train_net(args):
     if config.network.PRED_FLOW:
         eval_metrics.add(metric.Flow_L2LossMetric(config))
         eval_metrics.add(metric.Flow_CurLossMetric(config))
+    if config.train_iter.SE3_DIST_LOSS:   # reference train.py:293-295
+        eval_metrics.add(metric.Rot_L2LossMetric(config))
+        eval_metrics.add(metric.Trans_L2LossMetric(config))
     if config.train_iter.SE3_PM_LOSS:
         eval_metrics.add(metric.PointMatchingLossMetric(config))
     if config.network.PRED_MASK:

@@ -64,6 +64,8 @@ SIGNATURES = {
     "dim_flow_loss_grad": (I, [P, P, P, P, L, F, F, P, P]),
     "dim_logistic_grad": (I, [P, P, P, P, L, F, P]),
     "dim_pm_l1_grad": (I, [P, P, P, P, L, F, F, P, P]),
+    "dim_pm_loss_grad": (I, [P, P, P, P, L, F, F, I, F, P, P]),
+    "dim_se3_dist_loss_grad": (I, [P, P, P, P, P, P, P, P, I, F, F, I, F, P, P]),
     "dim_quat_normalize": (I, [P, P, I, P]),
     "dim_pose_head_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, P]),
     "dim_fc_wgrad": (I, [P, P, P, P, I, I, I, P]),

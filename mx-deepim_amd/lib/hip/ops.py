@@ -601,6 +601,25 @@ def pm_l1_grad(p_est, p_obs, weights, grad, norm_term, grad_scale, loss_sum=None
     return grad
 
 
+LOSS_TYPE_ID = {"L1": 0, "L2": 1, "smooth_L1": 2}
+
+
+def pm_loss_grad(p_est, p_obs, weights, grad, norm_term, grad_scale, loss_type="L1", smooth_l1_scalar=1.0, loss_sum=None):
+    """point-matching loss gradient for SE3_PM_LOSS_TYPE 'L1' | 'L2' | 'smooth_L1' (deepIM_flownet.py:458-499)"""
+    check(lib().dim_pm_loss_grad(dptr(p_est, f32), dptr(p_obs, f32), dptr(weights, f32), dptr(grad, f32), p_est.numel(), float(norm_term),
+                                 float(grad_scale), LOSS_TYPE_ID[loss_type], float(smooth_l1_scalar), dptr(loss_sum, f32), current_stream()))
+    return grad
+
+
+def se3_dist_loss_grad(rot_est_norm, rot_gt, fc7, p, zoom_trans_gt, d_rot_norm, d_zoom_trans, lw_rot, lw_trans, trans_loss_type="L2",
+                       smooth_l1_scalar=3.0, loss_sums2=None):
+    """SE3_DIST_LOSS (deepIM_flownet.py:396-437): adds the rot / trans loss gradients to d_rot_norm (B,4) / d_zoom_trans (B,3)"""
+    check(lib().dim_se3_dist_loss_grad(dptr(rot_est_norm, f32), dptr(rot_gt, f32), dptr(fc7, f32), dptr(p["trans_weight"], f32),
+                                       dptr(p["trans_bias"], f32), dptr(zoom_trans_gt, f32), dptr(d_rot_norm, f32), dptr(d_zoom_trans, f32),
+                                       rot_est_norm.shape[0], float(lw_rot), float(lw_trans), LOSS_TYPE_ID[trans_loss_type],
+                                       float(smooth_l1_scalar), dptr(loss_sums2, f32), current_stream()))
+
+
 def quat_normalize(rot, out=None):
     out = out if out is not None else torch.empty_like(rot)
     check(lib().dim_quat_normalize(dptr(rot, f32), dptr(out, f32), rot.shape[0], current_stream()))

@@ -43,6 +43,18 @@ class _InvZoomTrans(torch.autograd.Function):
         return g, None
 
 
+def _elem_loss(x, kind, scalar):
+    """|x|, x^2, or mx.sym.smooth_l1(x, scalar): 0.5 (scalar x)^2 where |x| < 1 / scalar^2, |x| - 0.5 / scalar^2 elsewhere"""
+    if kind == "L1":
+        return x.abs()
+    if kind == "L2":
+        return x * x
+    if kind == "smooth_L1":
+        s2 = float(scalar) ** 2
+        return torch.where(x.abs() < 1.0 / s2, 0.5 * s2 * x * x, x.abs() - 0.5 / s2)
+    raise Exception("Unknown loss type: {}".format(kind))
+
+
 def loss_and_grads(params, batch, cfg, K, dtype=torch.float64):
     """-> (outputs dict, grads dict name -> numpy in MXNet layouts).  batch: numpy blobs with the reference names."""
     H, W = 480, 640
@@ -84,9 +96,22 @@ def loss_and_grads(params, batch, cfg, K, dtype=torch.float64):
     flow_loss_ = t(zfw) * (flow_est - t(zflow) / cfg.dataset.NORMALIZE_FLOW) ** 2
     pts_est = _Transform3D.apply(t(batch["point_cloud_model"]), rot_norm, trans_est, batch["src_pose"], np.asarray(cfg.dataset.trans_means, np.float32),
                                  np.asarray(cfg.dataset.trans_stds, np.float32), cfg.network.ROT_COORD)
-    pm_loss_ = t(batch["point_cloud_weights"]) * torch.abs((pts_est - t(batch["point_cloud_observed"])) / cfg.dataset.NORMALIZE_3D_POINT)
+    # point matching: SE3_PM_LOSS_TYPE 'L1' | 'L2' | 'smooth_L1' (deepIM_flownet.py:458-499)
+    pm_loss_ = t(batch["point_cloud_weights"]) * _elem_loss((pts_est - t(batch["point_cloud_observed"])) / cfg.dataset.NORMALIZE_3D_POINT,
+                                                             ti.SE3_PM_LOSS_TYPE, ti.SE3_PM_SL1_SCALAR)
     bce = F.binary_cross_entropy_with_logits(logit, t(zmg), reduction="sum")  # d/dx = sigmoid(x) - y
-    L = (ti.LW_FLOW / (480.0 * 640.0)) * flow_loss_.sum() + (ti.LW_PM / float(ti.NUM_3D_SAMPLE)) * pm_loss_.sum() + (ti.LW_MASK / (480.0 * 640.0)) * bce
+    L = (ti.LW_FLOW / (480.0 * 640.0)) * flow_loss_.sum() + (ti.LW_MASK / (480.0 * 640.0)) * bce
+    if ti.SE3_PM_LOSS:
+        L = L + (ti.LW_PM / float(ti.NUM_3D_SAMPLE)) * pm_loss_.sum()
+    rot_loss_ = trans_loss_ = torch.zeros(1, dtype=dtype)
+    if ti.SE3_DIST_LOSS:
+        # deepIM_flownet.py:396-437: rot_loss = 1 - (rot_gt . rot_est_norm)^2, trans_loss = TRANS_LOSS_TYPE(zoom_trans_est - zoom_trans_gt);
+        # zoom_trans_gt = ZoomTrans(zoom_factor, trans label, b_inv_zoom False) = (dx, dy) / wx, dz (:659-665, zoom_trans.py:37-41)
+        rot_loss_ = 1.0 - ((t(batch["rot"]) * rot_norm).sum(dim=1)) ** 2
+        zt_gt = t(batch["trans"]).clone()
+        zt_gt[:, :2] = zt_gt[:, :2] / torch.from_numpy(zf[:, 0].astype(np.float64)).to(dtype)[:, None]
+        trans_loss_ = _elem_loss(tz - zt_gt, ti.TRANS_LOSS_TYPE, ti.TRANS_SMOOTH_L1_SCALAR)
+        L = L + ti.LW_ROT * rot_loss_.sum() + ti.LW_TRANS * trans_loss_.sum()
     for tnsr in (cat2, cat3, r10, r8, r6):
         tnsr.retain_grad()
     L.backward()
@@ -95,7 +120,8 @@ def loss_and_grads(params, batch, cfg, K, dtype=torch.float64):
         grads[k] = np.zeros_like(grads[k])
     out = {"rot_est_norm": rot_norm.detach().numpy(), "trans_est": trans_est.detach().numpy(), "flow_est_crop": flow_est.detach().numpy(),
            "mask_logit": logit.detach().numpy(), "zoom_factor": zf, "cat2": cat2.detach().numpy(), "cat3": cat3.detach().numpy(), "r10": r10.detach().numpy(), "d_cat2": cat2.grad.numpy(), "d_cat3": cat3.grad.numpy(),
-           "d_r10": r10.grad.numpy(), "d_r8": r8.grad.numpy(), "d_r6": r6.grad.numpy(), "flow_loss_sum": float(flow_loss_.sum()), "pm_loss_sum": float(pm_loss_.sum())}
+           "d_r10": r10.grad.numpy(), "d_r8": r8.grad.numpy(), "d_r6": r6.grad.numpy(), "flow_loss_sum": float(flow_loss_.sum()), "pm_loss_sum": float(pm_loss_.sum()),
+           "rot_loss_sum": float(rot_loss_.sum()), "trans_loss_sum": float(trans_loss_.sum())}
     return out, grads
 
 

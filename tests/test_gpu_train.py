@@ -210,3 +210,46 @@ def test_batch_updater_multiclass(hip_lib):
     fw, rfw = new["flow_weights"].cpu().numpy(), ref["flow_weights"]
     assert (fw != rfw).sum() <= 300 and fw.sum() > 1000
     cfg.dataset.class_name = ["ape"]
+
+
+@pytest.mark.parametrize("variant", [
+    dict(SE3_PM_LOSS=True, SE3_PM_LOSS_TYPE="L2", SE3_DIST_LOSS=False),
+    dict(SE3_PM_LOSS=True, SE3_PM_LOSS_TYPE="smooth_L1", SE3_PM_SL1_SCALAR=2.0, SE3_DIST_LOSS=False),
+    dict(SE3_PM_LOSS=False, SE3_DIST_LOSS=True, LW_ROT=1.5, LW_TRANS=0.7, TRANS_LOSS_TYPE="L2"),
+    dict(SE3_PM_LOSS=True, SE3_PM_LOSS_TYPE="L1", SE3_DIST_LOSS=True, LW_ROT=0.8, LW_TRANS=1.3, TRANS_LOSS_TYPE="smooth_L1",
+         TRANS_SMOOTH_L1_SCALAR=3.0),
+    dict(SE3_PM_LOSS=False, SE3_DIST_LOSS=True, LW_ROT=1.0, LW_TRANS=1.0, TRANS_LOSS_TYPE="L1"),
+])
+def test_pose_loss_variants(setup, variant):
+    """The pose losses the shipped YAMLs leave off (deepIM_flownet.py:396-437, :458-499): SE3_DIST_LOSS (rot_loss + trans_loss with
+    TRANS_LOSS_TYPE L2 / smooth_L1 / L1) and SE3_PM_LOSS_TYPE L2 / smooth_L1 -- loss sums and every gradient that does not pass a
+    LeakyReLU' flip (pose head, fc6) against torch autograd of the oracle; the flip-exposed tensors keep the bar of the main test."""
+    import copy
+
+    from deepim.core.module import MutableModule
+
+    cfg0, params, scene = setup
+    cfg = copy.deepcopy(cfg0)
+    for k, v in variant.items():
+        cfg.train_iter[k] = v
+    B = 2
+    mod = MutableModule(cfg, params, B)
+    batch = {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in scene["blobs"].items()}
+    mod.forward_backward(batch)
+    ref_out, ref_g = otrain.loss_and_grads(params, scene["blobs"], cfg, scene["K"])
+    sums = mod.loss_sums.cpu().numpy()
+    if cfg.train_iter.SE3_PM_LOSS:
+        np.testing.assert_allclose(sums[1], ref_out["pm_loss_sum"], rtol=2e-3)
+    if cfg.train_iter.SE3_DIST_LOSS:
+        np.testing.assert_allclose(sums[3], ref_out["rot_loss_sum"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(sums[4], ref_out["trans_loss_sum"], rtol=1e-4, atol=1e-7)
+    got = mod.get_grads()
+    for k, rg in ref_g.items():
+        scale = np.abs(rg).max()
+        err = np.abs(got[k] - rg).max()
+        exact_path = k.startswith(("fc", "rot", "trans", "Convolution", "deconv4", "upsample_flow", "mask_conv3"))
+        # exact paths: f32 against f64 through fc6 (81920 products per output) with gradients 100x smaller than in the main test when only
+        # the distance loss drives the head (measured 4e-5 on fc6_weight)
+        assert err <= (1e-4 if exact_path else 5e-2) * scale + 1e-9, (variant, k, err, scale)
+    for k in ("rot_weight", "trans_weight", "fc7_weight"):
+        assert np.abs(ref_g[k]).max() > 0, k   # the variant really drives the pose head
