@@ -1523,6 +1523,7 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   DIM_REQUIRE((long)N * a.OH * a.OW * a.out_cstride * 4 < (1L << 31), "output too large for 32-bit byte offsets (%ld bytes)",
               (long)N * a.OH * a.OW * a.out_cstride * 4);
   a.y_bytes = (unsigned)((long)N * a.OH * a.OW * a.out_cstride * 4);
+  DIM_REQUIRE(splits == 1 || (long)a.M * Cout * 4 < (1L << 31), "split-K slab too large for 32-bit byte offsets (%ld bytes)", (long)a.M * Cout * 4);
   a.tile_off = 0;
   a.slab_row0 = 0;
   a.slab_stride = (long)N * a.Ho * a.Wo * Cout;
