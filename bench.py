@@ -51,6 +51,7 @@ def parse_args():
                     "multi-rank path on a box with fewer GPUs than ranks, together with DIM_BENCH_DEVICE)")
     ap.add_argument("--no-winograd", action="store_true", help="run every encoder layer through the direct kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-deadline", type=float, default=240.0, help="seconds the `train` object may take with several ranks before the line is printed without it")
     ap.add_argument("--no-fresh-batch", action="store_true", help="skip the (non-headline) `fresh_batch` object: a new batch uploaded every step")
     ap.add_argument("--no-train", action="store_true", help="skip the (non-headline) `train` object: timed training iterations at 16 pairs per GPU")
     ap.add_argument("--train-steps", type=int, default=5, help="timed training iterations per phase for the `train` object")
@@ -383,11 +384,31 @@ def main():
     if not args.no_train:
         del refiner, pred
         torch.cuda.empty_cache()
-        try:
-            out["train"] = train_bench(cfg, models, rm, int(cfg.TRAIN.BATCH_PAIRS) if args.batch_pairs is None else B, dev, rank, world, dist,
-                                       args.train_steps)
-        except Exception as e:  # the non-headline object must never take the headline line down with it
-            out["train"] = {"error": "{}: {}".format(type(e).__name__, e)}
+
+        def run_train():
+            try:
+                torch.cuda.set_device(dev_index)
+                out["train"] = train_bench(cfg, models, rm, int(cfg.TRAIN.BATCH_PAIRS) if args.batch_pairs is None else B, dev, rank, world,
+                                           dist, args.train_steps)
+            except Exception as e:  # the non-headline object must never take the headline line down with it
+                out["train"] = {"error": "{}: {}".format(type(e).__name__, e)}
+
+        if world == 1:
+            run_train()
+        else:
+            # With several ranks the training object is the only part of this program that posts data-path collectives (the gradient
+            # all-reduce).  An exception is caught above; a collective that never completes is not an exception, so the object runs
+            # under a deadline: past it rank 0 still prints the headline line and the process leaves without waiting for the thread.
+            import threading
+
+            th = threading.Thread(target=run_train, daemon=True)
+            th.start()
+            th.join(args.train_deadline)
+            if th.is_alive():
+                out["train"] = {"error": "no result within {} s (a collective of the training object did not complete)".format(args.train_deadline)}
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, params, models, batch, args.cpu_pairs)
     if rank == 0:
