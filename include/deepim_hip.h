@@ -74,7 +74,8 @@ int dim_zoom_net_input(const float* image_observed, const float* image_rendered,
                        float* z_mask_rendered, void* stream);
 /* the other input arities of get_convs (deepIM_flownet.py:33-66): mode 0 = masks (as dim_zoom_net_input), 1 = images only (INPUT_MASK
  * off, ZoomImage path: channels 6, 7 of X are zero), 2 = depth_observed / depth_rendered in place of the masks (INPUT_DEPTH without
- * masks: ZoomDepth's plain bilinear sample, / 255).  X stays (B,H,W,8) NHWC. */
+ * masks: ZoomDepth's plain bilinear sample, / 255), 3 = the two zoomed masks alone in lanes 0, 1 (lanes 2-7 zero; images not read): the
+ * second 8-lane group of the 10-channel first layer (INPUT_DEPTH with masks; the first group is mode 2).  X stays (B,H,W,8) NHWC. */
 int dim_zoom_net_input_ex(const float* image_observed, const float* image_rendered, const float* extra_observed, const float* extra_rendered,
                           const float* zoom_factor, float* X_nhwc8, int B, int H, int W, const float* means3, int mode, void* stream);
 

@@ -277,6 +277,14 @@ __global__ __launch_bounds__(256) void zoom_net_input_kernel(const float* __rest
   const Affine a = load_affine(zoom_factor + 4 * b, false, H, W);
   const Tap t = make_tap(a, py, px, H, W);
   const long plane = (long)H * W;
+  if (MODE == 3) {   // the two mask lanes alone (second 8-lane group of the 10-channel first layer): [mask_obs, mask_ren, 0 x 6]
+    const float mo = mx_round(sample<PRE_NONE>(mask_obs + (long)b * plane, t, 0.f));
+    const float mr = mx_round(sample<PRE_BIN02>(mask_ren + (long)b * plane, t, 0.f));
+    float4* dst = reinterpret_cast<float4*>(X + ((long)b * plane + (long)py * W + px) * 8);
+    dst[0] = make_float4(mo, mr, 0.f, 0.f);
+    dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const float* io = img_obs + (long)b * 3 * plane;
   const float* ir = img_ren + (long)b * 3 * plane;
   float v[8];
@@ -386,8 +394,8 @@ int dim_zoom_net_input_ex(const float* image_observed, const float* image_render
                           const float* zoom_factor, float* X_nhwc8, int B, int H, int W, const float* means3, int mode, void* stream) {
   if (B == 0) return DIM_OK;
   DIM_REQUIRE(image_observed && image_rendered && zoom_factor && X_nhwc8 && means3, "null pointer");
-  DIM_REQUIRE(mode == 0 || mode == 1 || mode == 2, "mode 0 (masks), 1 (images only) or 2 (depth planes)");
-  DIM_REQUIRE(mode == 1 || (extra_observed && extra_rendered), "modes 0 and 2 need the two extra planes");
+  DIM_REQUIRE(mode >= 0 && mode <= 3, "mode 0 (masks), 1 (images only), 2 (depth planes) or 3 (mask lanes alone)");
+  DIM_REQUIRE(mode == 1 || (extra_observed && extra_rendered), "modes 0, 2 and 3 need the two extra planes");
   const int bx = (W % 256 != 0 && W % 128 == 0) ? 128 : 256;
   dim3 grid(ceil_div(W, bx), H, B), block(bx);
   hipStream_t st = as_stream(stream);
@@ -397,7 +405,8 @@ int dim_zoom_net_input_ex(const float* image_observed, const float* image_render
                      (float*)nullptr)
   if (mode == 0) DIM_ZNI(0);
   else if (mode == 1) DIM_ZNI(1);
-  else DIM_ZNI(2);
+  else if (mode == 2) DIM_ZNI(2);
+  else DIM_ZNI(3);
 #undef DIM_ZNI
   return check_launch("zoom_net_input_ex");
 }

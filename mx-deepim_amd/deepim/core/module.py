@@ -48,6 +48,9 @@ class MutableModule(object):
         cfg = config
         assert compute_dtype in ("f32", "bf16"), compute_dtype
         self.bf16 = compute_dtype == "bf16"
+        if cfg.network.INPUT_DEPTH or not cfg.network.INPUT_MASK:
+            raise NotImplementedError("the HIP training graph feeds the shipped first-layer input (images + masks, 8 channels); the other "
+                                      "arities (images only, depth planes, 10 channels) exist in the test graph only (FlowNetHip)")
         if not (cfg.network.PRED_FLOW and cfg.network.PRED_MASK):
             raise NotImplementedError("the HIP training graph always carries the decoder with both heads (PRED_FLOW, PRED_MASK: every shipped "
                                       "configuration); graphs without one of them are not wired")

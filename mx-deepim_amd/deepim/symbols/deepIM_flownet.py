@@ -200,11 +200,11 @@ class FlowNetHip(object):
         #   mode 0  images + masks            (INPUT_MASK and PRED_MASK; the shipped graph)
         #   mode 1  images only, 2 zero lanes (no masks in the Concat: Cin = 6; the weights of the two spare lanes are zero)
         #   mode 2  images + two depth planes (INPUT_DEPTH without masks: Cin = 8)
+        #   mode 3  images + depth planes + masks (INPUT_DEPTH with masks: Cin = 10) as TWO 8-lane groups -- X as in mode 2 and X2 =
+        #           [mask_obs, mask_ren, 0 x 6] -- and flow_conv1 as the sum of two 8-channel convolutions (weights [:, :8] and [:, 8:10]
+        #           zero-padded) followed by the LeakyReLU; three launches instead of one, no shipped configuration uses it
         with_masks = bool(cfg.network.INPUT_MASK and cfg.network.PRED_MASK)
-        if cfg.network.INPUT_DEPTH and with_masks:
-            raise NotImplementedError("INPUT_DEPTH together with the mask channels is a 10-channel first layer: the 8-lane first-layer "
-                                      "kernel does not cover it (no shipped configuration uses INPUT_DEPTH)")
-        self.input_mode = 0 if with_masks else (2 if cfg.network.INPUT_DEPTH else 1)
+        self.input_mode = (3 if cfg.network.INPUT_DEPTH else 0) if with_masks else (2 if cfg.network.INPUT_DEPTH else 1)
         self.zoom_from_masks = bool(cfg.network.INPUT_MASK)   # ZoomMask vs ZoomImage for the zoom window (:783-819)
         d = self.device
         self.params = {k: torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float32).to(d) for k, v in arg_params.items()}
@@ -212,6 +212,12 @@ class FlowNetHip(object):
             w1 = self.params["flow_conv1_weight"]
             self.params["flow_conv1_weight"] = torch.cat([w1, torch.zeros((w1.shape[0], 2) + tuple(w1.shape[2:]), device=d)], dim=1).contiguous()
         self.packed = {}
+        if self.input_mode == 3:  # 10 input channels: [:, :8] for the images + depth group, [:, 8:10] (+ 6 zero lanes) for the mask group
+            w1 = self.params["flow_conv1_weight"]
+            assert w1.shape[1] == 10, w1.shape
+            self.packed["flow_conv1_masks"] = self.pack_conv(
+                torch.cat([w1[:, 8:], torch.zeros((w1.shape[0], 6) + tuple(w1.shape[2:]), device=d)], dim=1).contiguous())
+            self.params["flow_conv1_weight"] = w1[:, :8].contiguous()
         for name, cout, k, s, p in ENCODER:
             self.packed[name] = self.pack_conv(self.params[name + "_weight"])
         self.packed["fc6"] = ops.fc_pack_weight(self.params["fc6_weight"], 1024, 8, 10)
@@ -252,6 +258,7 @@ class FlowNetHip(object):
             self.conv_plan.update(conv_plan)
         B, H, W = batch_size, self.H, self.W
         self.X = torch.empty((B, H, W, 8), dtype=torch.float32, device=d)
+        self.X2 = torch.empty((B, H, W, 8), dtype=torch.float32, device=d) if self.input_mode == 3 else None   # the mask lanes of the 10-channel input
         self.acts = {}
         h, w, c = H, W, 8
         max_ws = 0
@@ -370,6 +377,9 @@ class FlowNetHip(object):
         else:
             ops.zoom_net_input_ex(batch["image_observed"], batch["image_rendered"], batch["depth_observed"], batch["depth_rendered"],
                                   self.zoom_factor, self.plane_means, 2, X=self.X)
+            if self.input_mode == 3:
+                ops.zoom_net_input_ex(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"],
+                                      self.zoom_factor, self.plane_means, 3, X=self.X2)
         return self.X
 
     def encoder(self, X=None, events=None):
@@ -387,9 +397,13 @@ class FlowNetHip(object):
                                                  events=None if events is None else events.setdefault(name, []))
                 continue
             tile, splits = self.conv_plan[name]
-            x = ops.conv2d_fwd(x, self.packed[name], self.params[name + "_bias"], cout, k, k, s, p, slope=0.1, splits=splits, tile=tile,
-                               out=self.acts[name], workspace=self.workspace,
+            first10 = name == "flow_conv1" and self.input_mode == 3
+            x = ops.conv2d_fwd(x, self.packed[name], self.params[name + "_bias"], cout, k, k, s, p, slope=1.0 if first10 else 0.1, splits=splits,
+                               tile=tile, out=self.acts[name], workspace=self.workspace,
                                events=None if events is None else events.setdefault(name, []))
+            if first10:   # + the mask group's convolution, then the activation (y *= y > 0 ? 1 : 0.1 is what dim_lrelu_bwd does with dy = y)
+                ops.conv2d_fwd_ex(self.X2, 0, 8, self.packed["flow_conv1_masks"], None, x, 0, cout, k, k, s, p, slope=1.0, tile=3, accumulate=True)
+                ops.lrelu_bwd(x, x, cout, slope=0.1)
         # fc6: a pure weight stream at these batch sizes (84 MB per forward) -> its own kernel instead of the 8x10 "convolution"
         ops.fc_fwd(x, self.packed["fc6"], self.params["fc6_bias"], 256, slope=0.1, out=self.fc6, workspace=self.workspace,
                    events=None if events is None else events.setdefault("fc6", []))
