@@ -55,8 +55,13 @@ class Refiner(object):
             "src_pose": torch.zeros((B, 3, 4), dtype=torch.float32, device=d),
             "class_index": torch.zeros((B,), dtype=torch.int32, device=d),
         }
+        self.input_depth = bool(cfg.network.INPUT_DEPTH)
+        if self.input_depth:   # the two depth planes of get_convs (:33-50); the rendered one is refreshed by every re-render (tester.py:573-574)
+            self.batch["depth_observed"] = torch.zeros((B, 1, H, W), dtype=torch.float32, device=d)
+            self.batch["depth_rendered"] = torch.zeros((B, 1, H, W), dtype=torch.float32, device=d)
         # pristine copies of the blobs the loop overwrites, so refine() can be replayed on the same batch
-        self.init = {k: torch.zeros_like(self.batch[k]) for k in ("image_rendered", "mask_observed", "mask_rendered")}
+        self.init = {k: torch.zeros_like(self.batch[k]) for k in ("image_rendered", "mask_observed", "mask_rendered")
+                     + (("depth_rendered",) if self.input_depth else ())}
         self.pose_init = torch.zeros((B, 3, 4), dtype=torch.float32, device=d)
         self.poses_iter = torch.zeros((self.test_iter, B, 3, 4), dtype=torch.float32, device=d)
         self.se3_iter = torch.zeros((self.test_iter, B, 7), dtype=torch.float32, device=d)
@@ -80,9 +85,14 @@ class Refiner(object):
         self._want_graph = capture_graph
 
     # ------------------------------------------------------------------------------------------
-    def load(self, image_observed, image_rendered, mask_observed, mask_rendered, src_pose, class_index):
-        """copy one batch of blobs (any device) into the resident buffers"""
+    def load(self, image_observed, image_rendered, mask_observed, mask_rendered, src_pose, class_index, depth_observed=None,
+             depth_rendered=None):
+        """copy one batch of blobs (any device) into the resident buffers (the depth planes: INPUT_DEPTH graphs only)"""
         b = self.batch
+        if self.input_depth:
+            assert depth_observed is not None and depth_rendered is not None, "INPUT_DEPTH: the loop needs depth_observed / depth_rendered"
+            b["depth_observed"].copy_(torch.as_tensor(depth_observed))
+            self.init["depth_rendered"].copy_(torch.as_tensor(depth_rendered))
         b["image_observed"].copy_(torch.as_tensor(image_observed))
         self.init["image_rendered"].copy_(torch.as_tensor(image_rendered))
         self.init["mask_observed"].copy_(torch.as_tensor(mask_observed))
@@ -129,6 +139,8 @@ class Refiner(object):
                 extra = {"light_intensity": self.light_int[it]} if self.lit else {}
                 # (the loop needs the depth only for mask_rendered = depth > 0.2, tester.py:575-577: the resolve pass writes the mask itself
                 # and the depth plane is not materialised -- 1.2 MB per pair and render less to write)
+                if self.input_depth:
+                    extra["depth"] = b["depth_rendered"]   # INPUT_DEPTH: the rendered depth is a network input (tester.py:573-574)
                 self.render_machine.render_batch(b["class_index"], self.poses_iter[it], image=b["image_rendered"],
                                                  mask=b["mask_rendered"], bbox=self.bbox, plane_means=net.plane_means, mask_thr=0.2,
                                                  status=self.status_iter[it], **extra)

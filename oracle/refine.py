@@ -64,6 +64,8 @@ def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord=
             batch["image_rendered"] = image_transform(image_refined.astype(np.float64), pixel_means).astype(np.float32)
             batch["mask_rendered"] = mask_r[np.newaxis, np.newaxis].astype(np.float32)
             batch["mask_observed"] = update_mask_observed_box_rendered(mask_r)[np.newaxis, np.newaxis].astype(np.float32)
+            if graph.get("input_depth"):  # tester.py:573-574 + update_data_batch (data_pair.py:96-101): the rendered depth as it is
+                batch["depth_rendered"] = depth[np.newaxis, np.newaxis].astype(np.float32)
             batch["src_pose"] = pose_new[np.newaxis].astype(np.float32)  # nd.array -> float32
             pose_rendered = pose_new
             out = flownet.forward_test(params, batch, K, pixel_means, fast_test=fast_test, **graph)

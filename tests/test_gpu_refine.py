@@ -302,13 +302,16 @@ def test_graph_variants_images_only_and_depth_input(hip_lib):
             np.testing.assert_array_equal(pred.net.X2[..., :2].cpu().numpy(), ref["data"].transpose(0, 2, 3, 1)[..., 8:])
             assert float(pred.net.X2[..., 2:].abs().max()) == 0.0
         np.testing.assert_allclose(out["se3_output"].cpu().numpy(), ref["se3"], atol=5e-5)
-        if not input_depth:   # the loop re-renders images (and masks): run it for the image-only variants
+        if True:   # the loop re-renders images, masks and -- INPUT_DEPTH -- the rendered depth plane
             rm = Render_Py(None, cfg.dataset.class_name, scene["K"], meshes=scene["models"])
             refiner = Refiner(cfg, pred, rm, B, capture_graph=True)
-            refiner.load(bl["image_observed"], bl["image_rendered"], bl["mask_observed"], bl["mask_rendered"], bl["src_pose"], bl["class_index"])
+            dkw = dict(depth_observed=depth["depth_observed"], depth_rendered=depth["depth_rendered"]) if input_depth else {}
+            refiner.load(bl["image_observed"], bl["image_rendered"], bl["mask_observed"], bl["mask_rendered"], bl["src_pose"], bl["class_index"],
+                         **dkw)
             poses = refiner.refine().cpu().numpy()
             for b in range(B):
-                blobs_b = {k: bl[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
+                blobs_b = {k: host[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")
+                           + (("depth_observed", "depth_rendered") if input_depth else ())}
                 o_poses, _ = orefine.refine_pair(params, scene["models"][int(bl["class_index"][b])], blobs_b, scene["K"], cfg.network.PIXEL_MEANS,
                                                  z3, o3, "CAMERA", test_iter=2, **kw)
                 for it in range(2):
