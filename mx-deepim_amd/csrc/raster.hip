@@ -272,8 +272,9 @@ struct ResolveHdr {
 __global__ __launch_bounds__(256) void raster_resolve_stream_kernel(const unsigned long long* __restrict__ zbuf, int H, int W, float pm0,
                                                                     float pm1, float pm2, float mask_thr, float* __restrict__ image,
                                                                     float* __restrict__ depth, float* __restrict__ mask,
-                                                                    float* __restrict__ bgr, int* __restrict__ bbox,
-                                                                    ResolveHdr* __restrict__ hdr, unsigned* __restrict__ list) {
+                                                                    float* __restrict__ bgr, int4* __restrict__ wave_ext,
+                                                                    int waves_per_sample, ResolveHdr* __restrict__ hdr,
+                                                                    unsigned* __restrict__ list) {
   const int b = blockIdx.y;
   const int plane = H * W;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;  // quad index inside the image
@@ -308,8 +309,13 @@ __global__ __launch_bounds__(256) void raster_resolve_stream_kernel(const unsign
     }
   }
   const unsigned long long any = __ballot(cov != 0);
-  if (any == 0) return;  // wave-uniform
   const int lane = threadIdx.x & 63;
+  // this wave's slot in the per-sample extent table (bbox of the mask; see raster_bbox_reduce_kernel)
+  int4* ext = wave_ext ? wave_ext + (long)b * waves_per_sample + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) : nullptr;
+  if (any == 0) {  // wave-uniform: nothing covered
+    if (ext && lane == 0) *ext = make_int4(0x7FFFFFFF, -1, 0x7FFFFFFF, -1);
+    return;
+  }
   // ---- append: exclusive prefix of popcount(cov) over the wave from three ballots (the count has three bits)
   const unsigned n = __popc(cov);
   unsigned before = 0, total = 0;
@@ -326,8 +332,11 @@ __global__ __launch_bounds__(256) void raster_resolve_stream_kernel(const unsign
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (cov & (1u << k)) list[slot++] = (unsigned)(b * plane + pix + k);
-  // ---- bbox of the mask (z > mask_thr): per-lane extent of its quad, min / max over the wave, one atomic set per wave
-  if (bbox) {
+  // ---- bbox of the mask (z > mask_thr): per-lane extent of its quad, min / max over the wave, ONE PLAIN STORE per wave into its slot
+  // of the extent table; raster_bbox_reduce_kernel folds the table.  (The first version did atomicMin / atomicMax on bbox[4 b + i]
+  // from every covered wave: ~200 atomics per address and launch, which L2 retires one after the other at ~175 ns each -- 35 of the
+  // 62 us of this pass, found by switching the block off.)
+  if (ext) {
     const int y = pix / W, x0 = pix - y * W;
     int lo = 0x7FFFFFFF, hi = -1, ylo = 0x7FFFFFFF, yhi = -1;
 #pragma unroll
@@ -344,12 +353,33 @@ __global__ __launch_bounds__(256) void raster_resolve_stream_kernel(const unsign
       ylo = min(ylo, __shfl_xor(ylo, d));
       yhi = max(yhi, __shfl_xor(yhi, d));
     }
-    if (lane == 0 && hi >= 0) {
-      atomicMin(&bbox[4 * b + 0], lo);
-      atomicMax(&bbox[4 * b + 1], hi);
-      atomicMin(&bbox[4 * b + 2], ylo);
-      atomicMax(&bbox[4 * b + 3], yhi);
-    }
+    if (lane == 0) *ext = make_int4(lo, hi, ylo, yhi);
+  }
+}
+
+// bbox[b] = (min x, max x, min y, max y) over the wave extents of sample b; (W, -1, H, -1) when the mask is empty, as raster_init_kernel
+// leaves it for the one-pass path
+__global__ __launch_bounds__(256) void raster_bbox_reduce_kernel(const int4* __restrict__ wave_ext, int waves_per_sample, int H, int W,
+                                                                 int* __restrict__ bbox) {
+  const int b = blockIdx.x;
+  int lo = 0x7FFFFFFF, hi = -1, ylo = 0x7FFFFFFF, yhi = -1;
+  for (int i = threadIdx.x; i < waves_per_sample; i += 256) {
+    const int4 e = wave_ext[(long)b * waves_per_sample + i];
+    lo = min(lo, e.x); hi = max(hi, e.y); ylo = min(ylo, e.z); yhi = max(yhi, e.w);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    lo = min(lo, __shfl_xor(lo, d));
+    hi = max(hi, __shfl_xor(hi, d));
+    ylo = min(ylo, __shfl_xor(ylo, d));
+    yhi = max(yhi, __shfl_xor(yhi, d));
+  }
+  __shared__ int red[4][4];
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lo; red[threadIdx.x >> 6][1] = hi; red[threadIdx.x >> 6][2] = ylo; red[threadIdx.x >> 6][3] = yhi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) { lo = min(lo, red[w][0]); hi = max(hi, red[w][1]); ylo = min(ylo, red[w][2]); yhi = max(yhi, red[w][3]); }
+    bbox[4 * b + 0] = min(lo, W); bbox[4 * b + 1] = hi; bbox[4 * b + 2] = min(ylo, H); bbox[4 * b + 3] = yhi;
   }
 }
 
@@ -506,11 +536,14 @@ using namespace dim;
 
 extern "C" {
 
-// workspace layout: z-buffer (u64 per pixel) | projected vertices (3 floats each, padded to 256 B) | header (256 B) | covered-pixel list
+// workspace layout: z-buffer (u64 per pixel) | projected vertices (3 floats each, padded to 256 B) | header (256 B) | covered-pixel list |
+// wave extents (one int4 per wave of the stream pass)
 static long raster_scr_bytes(int B, int vmax) { return ((long)B * vmax * 3 * 4 + 255) / 256 * 256; }
+static int raster_waves_per_sample(int H, int W) { return (int)(ceil_div((long)H * W / 4, 256) * 4); }   // workgroups of 256 quads x 4 waves
 
 long dim_raster_workspace_bytes(int B, int vmax, int H, int W) {
-  return (long)B * H * W * 8 + raster_scr_bytes(B, vmax) + (long)sizeof(ResolveHdr) + (long)B * H * W * 4;
+  return (long)B * H * W * 8 + raster_scr_bytes(B, vmax) + (long)sizeof(ResolveHdr) + (long)B * H * W * 4 +
+         (long)B * raster_waves_per_sample(H, W) * 16;
 }
 
 static int raster_render_impl(const float* verts, const float* normals, const float* uvs, const int* faces, const int* mesh_table,
@@ -546,8 +579,11 @@ static int raster_render_impl(const float* verts, const float* normals, const fl
   // takes the one-thread-per-pixel kernel
   if (W % 4 == 0 && aligned16(workspace) && aligned16(image) && aligned16(depth) && aligned16(mask) && aligned16(bgr)) {
     // pass 1 streams the z-buffer once and finishes depth / mask / bbox / background; pass 2 colours the listed pixels on full waves
+    const int wps = raster_waves_per_sample(H, W);
+    int4* wave_ext = bbox ? reinterpret_cast<int4*>(reinterpret_cast<char*>(list) + (long)B * H * W * 4) : nullptr;
     hipLaunchKernelGGL(raster_resolve_stream_kernel, dim3(ceil_div((long)H * W / 4, 256), B), dim3(256), 0, st, zbuf, H, W, p0, p1, p2,
-                       mask_thr, image, depth, mask, bgr, bbox, hdr, list);
+                       mask_thr, image, depth, mask, bgr, wave_ext, wps, hdr, list);
+    if (bbox) hipLaunchKernelGGL(raster_bbox_reduce_kernel, dim3(B), dim3(256), 0, st, wave_ext, wps, H, W, bbox);
     if (image || bgr) {
       const int grid = (int)(nkeys / 256 < 2048 ? (nkeys + 255) / 256 : 2048);
       if (normals)

@@ -22,7 +22,7 @@ def test_pure_host_queries(hip_lib):
     assert hip_lib.dim_conv2d_packed_weight_floats(128, 64, 5, 5) == 25 * 64 * 128
     assert hip_lib.dim_conv2d_workspace_floats(2, 8, 10, 512, 1024, 3, 3, 1, 1, 4) == 4 * 2 * 8 * 10 * 1024
     # z-buffer (8 B / pixel) + projected vertices (padded to 256 B) + 256-byte header + covered-pixel list (4 B / pixel)
-    assert hip_lib.dim_raster_workspace_bytes(2, 100, 480, 640) == 2 * 480 * 640 * 8 + 2560 + 256 + 2 * 480 * 640 * 4
+    assert hip_lib.dim_raster_workspace_bytes(2, 100, 480, 640) == 2 * 480 * 640 * 8 + 2560 + 256 + 2 * 480 * 640 * 4 + 2 * 1200 * 16
     # Winograd paths: packed weights = planes x K x Cout, workspace = planes x tiles x (K + Cout)
     assert hip_lib.dim_winograd_packed_weight_floats(256, 128, 4) == 36 * 256 * 128
     assert hip_lib.dim_winograd_packed_weight_floats(256, 128, 2) == 16 * 256 * 128
