@@ -71,16 +71,17 @@ __global__ void pack_fc_dgrad_weight_kernel(const float* __restrict__ w, float* 
 __global__ __launch_bounds__(256) void flow_loss_grad_kernel(const float* __restrict__ f_est, const float* __restrict__ f_lab,
                                                              const float* __restrict__ wgt, float* __restrict__ grad, long n, float inv_nf,
                                                              float gs, float* __restrict__ loss_sum) {
-  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  // grid-stride: at most 1024 workgroups, so at most 1024 adds meet on the one loss_sum address (same-line atomics retire one after
+  // the other, ~10 ns each: one per wave cost 0.5 ms, one per workgroup of 1024 elements still 0.09 of this kernel's 0.13 ms)
   float local = 0.f;
-  if (i < n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
     float4 a = *reinterpret_cast<const float4*>(f_est + i), b = *reinterpret_cast<const float4*>(f_lab + i),
            w = *reinterpret_cast<const float4*>(wgt + i);
     float4 d = make_float4(a.x - b.x * inv_nf, a.y - b.y * inv_nf, a.z - b.z * inv_nf, a.w - b.w * inv_nf);
     *reinterpret_cast<float4*>(grad + i) = make_float4(gs * w.x * 2.f * d.x, gs * w.y * 2.f * d.y, gs * w.z * 2.f * d.z, gs * w.w * 2.f * d.w);
-    local = w.x * d.x * d.x + w.y * d.y * d.y + w.z * d.z * d.z + w.w * d.w * d.w;
+    local += w.x * d.x * d.x + w.y * d.y * d.y + w.z * d.z * d.z + w.w * d.w * d.w;
   }
-  if (loss_sum) {  // metric only; gradients never depend on it.  One atomic per workgroup (per-wave atomics serialised: 0.5 ms)
+  if (loss_sum) {  // metric only; gradients never depend on it.  One atomic per workgroup
     __shared__ float red[4];
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
@@ -99,23 +100,6 @@ __global__ __launch_bounds__(256) void logistic_grad_kernel(const float* __restr
   grad[i] = gs_over_n * (p - y[i]);
 }
 
-// PM (L1): g = gs * w * sign(p_est - p_obs) / norm_term     (all (B,3,N))
-__global__ void pm_l1_grad_kernel(const float* __restrict__ p_est, const float* __restrict__ p_obs, const float* __restrict__ wgt,
-                                  float* __restrict__ grad, long n, float inv_norm, float gs, float* __restrict__ loss_sum) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  float local = 0.f;
-  if (i < n) {
-    float d = (p_est[i] - p_obs[i]) * inv_norm;
-    float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    grad[i] = gs * wgt[i] * s * inv_norm;
-    local = wgt[i] * fabsf(d);
-  }
-  if (loss_sum) {
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);
-  }
-}
-
 // The element losses get_loss offers besides |x| (deepIM_flownet.py:414-426, :460-487): value and derivative of
 //   type 0  |x|        type 1  x^2        type 2  mx.sym.smooth_l1(x, scalar = s): 0.5 (s x)^2 if |x| < 1 / s^2, else |x| - 0.5 / s^2
 __device__ __forceinline__ float elem_loss(int type, float x, float s, float* dfdx) {
@@ -132,19 +116,21 @@ __device__ __forceinline__ float elem_loss(int type, float x, float s, float* df
 }
 
 // point-matching loss of any of the three types (dim_pm_l1_grad is type 0): grad = gs * w * f'(d) / norm, d = (p_est - p_obs) / norm
-__global__ void pm_loss_grad_kernel(const float* __restrict__ p_est, const float* __restrict__ p_obs, const float* __restrict__ wgt,
+__global__ __launch_bounds__(256) void pm_loss_grad_kernel(const float* __restrict__ p_est, const float* __restrict__ p_obs, const float* __restrict__ wgt,
                                     float* __restrict__ grad, long n, float inv_norm, float gs, int type, float sl1, float* __restrict__ loss_sum) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   float local = 0.f;
-  if (i < n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float df;
     const float v = elem_loss(type, (p_est[i] - p_obs[i]) * inv_norm, sl1, &df);
     grad[i] = gs * wgt[i] * df * inv_norm;
-    local = wgt[i] * v;
+    local += wgt[i] * v;
   }
-  if (loss_sum) {
+  if (loss_sum) {  // one add per workgroup, at most 128 workgroups (see flow_loss_grad_kernel)
+    __shared__ float red[4];
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, (red[0] + red[1]) + (red[2] + red[3]));
   }
 }
 
@@ -515,7 +501,8 @@ int dim_flow_loss_grad(const float* flow_est, const float* flow_label, const flo
   if (n == 0) return DIM_OK;
   DIM_REQUIRE(flow_est && flow_label && flow_weights && grad, "null pointer");
   DIM_REQUIRE(n % 4 == 0, "element count must be a multiple of 4");
-  hipLaunchKernelGGL(flow_loss_grad_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, as_stream(stream), flow_est, flow_label, flow_weights,
+  const long wgs = ceil_div(n / 4, 256);
+  hipLaunchKernelGGL(flow_loss_grad_kernel, dim3((unsigned)(wgs < 1024 ? wgs : 1024)), dim3(256), 0, as_stream(stream), flow_est, flow_label, flow_weights,
                      grad, n, 1.0f / normalize_flow, grad_scale, loss_sum);
   return check_launch("flow_loss_grad");
 }
@@ -533,8 +520,9 @@ int dim_pm_l1_grad(const float* p_est, const float* p_obs, const float* weights,
                    float* loss_sum, void* stream) {
   if (n == 0) return DIM_OK;
   DIM_REQUIRE(p_est && p_obs && weights && grad, "null pointer");
-  hipLaunchKernelGGL(pm_l1_grad_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), p_est, p_obs, weights, grad, n,
-                     1.0f / norm_term, grad_scale, loss_sum);
+  const long l1_wgs = ceil_div(n, 256);
+  hipLaunchKernelGGL(pm_loss_grad_kernel, dim3((unsigned)(l1_wgs < 128 ? l1_wgs : 128)), dim3(256), 0, as_stream(stream), p_est, p_obs, weights, grad, n,
+                     1.0f / norm_term, grad_scale, 0, 1.0f, loss_sum);
   return check_launch("pm_l1_grad");
 }
 
@@ -543,7 +531,8 @@ int dim_pm_loss_grad(const float* p_est, const float* p_obs, const float* weight
   if (n == 0) return DIM_OK;
   DIM_REQUIRE(p_est && p_obs && weights && grad, "null pointer");
   DIM_REQUIRE(loss_type >= 0 && loss_type <= 2 && (loss_type != 2 || smooth_l1_scalar > 0.f), "loss_type 0 L1 | 1 L2 | 2 smooth_L1 (scalar > 0)");
-  hipLaunchKernelGGL(pm_loss_grad_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), p_est, p_obs, weights, grad, n,
+  const long pm_wgs = ceil_div(n, 256);
+  hipLaunchKernelGGL(pm_loss_grad_kernel, dim3((unsigned)(pm_wgs < 128 ? pm_wgs : 128)), dim3(256), 0, as_stream(stream), p_est, p_obs, weights, grad, n,
                      1.0f / norm_term, grad_scale, loss_type, smooth_l1_scalar, loss_sum);
   return check_launch("pm_loss_grad");
 }

@@ -183,7 +183,7 @@ def test_config2_training_gradients_batch16(hip_lib):
     # (1) additivity over 2-pair sub-batches + (2) two sub-batches vs the oracle
     mod2 = MutableModule(cfg, params, 2)
     acc = {k: np.zeros(v.shape, np.float64) for k, v in g16.items()}
-    sums = np.zeros(3)
+    sums = np.zeros(5)   # flow, point matching, -, rot, trans (MutableModule.loss_sums)
     for s in range(B // 2):
         sub = {k: v[2 * s:2 * s + 2].contiguous() for k, v in dev.items()}
         out2 = mod2.forward_backward(sub)
