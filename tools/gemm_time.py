@@ -26,7 +26,7 @@ else:
     tiles = B * ((ho + 3) // 4) * ((wo + 3) // 4)
     flops = 2.0 * 36 * tiles * 4 * c * cout
     run = lambda tile, ev: ops.conv2d_fwd_winograd5x5s2(x, c, wp, bias, cout, tile=tile, out=y, workspace=ws, events=ev)
-for tile in ((5, 4) if cout % 256 == 0 else (4,)):
+for tile in ((5, 4, 3) if cout % 256 == 0 else (4, 3)):
     tot, n = 0.0, 0
     for r in range(reps):
         ev = []
