@@ -514,11 +514,17 @@ __global__ void modelnet_light_kernel(const float* __restrict__ poses, float dx,
   light_pos[3 * b + 2] = (float)(0.5 * (double)dz - (double)P[11]);
 }
 
-__global__ __launch_bounds__(256) void zbuf_clear_kernel(unsigned long long* __restrict__ zbuf, long n) {
+__global__ __launch_bounds__(256) void zbuf_clear_kernel(unsigned long long* __restrict__ zbuf, long n, int wide) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (i + k < n) zbuf[i + k] = 0xFFFFFFFFFFFFFFFFull;
+  if (wide && i + 3 < n) {  // two 16-byte stores (wide = the workspace is 16-byte aligned); four 8-byte stores ran at 2.6 TB/s
+    const ulonglong2 ff = make_ulonglong2(0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull);
+    ulonglong2* p = reinterpret_cast<ulonglong2*>(zbuf + i);
+    p[0] = ff;
+    p[1] = ff;
+  } else {
+    for (int k = 0; k < 4; ++k)
+      if (i + k < n) zbuf[i + k] = 0xFFFFFFFFFFFFFFFFull;
+  }
 }
 
 // empty boxes + an empty covered-pixel list
@@ -566,7 +572,8 @@ static int raster_render_impl(const float* verts, const float* normals, const fl
   // z-buffer clear as a KERNEL, not hipMemsetAsync: inside a captured hipGraph the memset node was seen overlapping the
   // resolve pass of the same replay (keys half overwritten -> face ids out of range -> memory fault on the 2nd replay)
   const long nkeys = (long)B * H * W;
-  hipLaunchKernelGGL(zbuf_clear_kernel, dim3(ceil_div(nkeys, 256 * 4)), dim3(256), 0, st, zbuf, nkeys);
+  hipLaunchKernelGGL(zbuf_clear_kernel, dim3(ceil_div(nkeys, 256 * 4)), dim3(256), 0, st, zbuf, nkeys,
+                     (int)((reinterpret_cast<uintptr_t>(workspace) & 15) == 0));
   hipLaunchKernelGGL(raster_vertex_kernel, dim3(ceil_div(vmax, 256), B), dim3(256), 0, st, verts, mesh_table, class_index, poses,
                      K9[0], K9[4], K9[2], K9[5], vmax, n_classes, status, scr);
   hipLaunchKernelGGL(raster_tri_kernel, dim3(ceil_div(fmax, 256), B), dim3(256), 0, st, faces, mesh_table, class_index, scr, vmax, H,
