@@ -276,17 +276,26 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
         *reinterpret_cast<wbf16x4*>(&sX[buf][(xr0 + XR_STEP * i) * LDX + c * 32 + xq * 4]) = wg_to_bf16x4(rx[i][c]);
   };
 
-  f32x16 acc[NCH];
+  // Wave -> accumulator tiles.  NW = 4, NCH = 4 (the wide layers): the four waves sit 2 x 2 on the 128 (co) x 128 (packed columns)
+  // workgroup tile, 64 x 64 each -- per k-step 2 A + 2 B fragments (8 transposing reads) feed 4 MFMAs; the first layout, one 32-row
+  // strip x all 4 chunks per wave, needed 10 reads per 4 MFMAs, and with both operands zeroed at the source the kernel still took 146
+  // of its 237 us on conv3_1: the LDS read path, not the global loads, sets its pace.  Other shapes keep the strip layout.
+  constexpr bool SQ = NW == 4 && NCH == 4;
+  constexpr int TI = SQ ? 2 : 1, TJ = SQ ? 2 : NCH;
+  const int wr = SQ ? wave >> 1 : wave, wc = SQ ? wave & 1 : 0;
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // transposing-read addresses: lane 4q+p of 16-lane group g points at pixel row 8 (g >> 1) + q, channels 16 (g & 1) + 4p .. +3 of
   // the block; it receives channel 16 (g & 1) + (lane & 15) for the four pixels 8 (g >> 1) + {0..3} (+4 for the second read)
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  const int z_el = (8 * (g >> 1) + tq) * LDZ + wave * 32 + 16 * (g & 1) + 4 * tp;
-  const int x_el = (8 * (g >> 1) + tq) * LDX + 16 * (g & 1) + 4 * tp;
+  const int z_el = (8 * (g >> 1) + tq) * LDZ + wr * (32 * TI) + 16 * (g & 1) + 4 * tp;
+  const int x_el = (8 * (g >> 1) + tq) * LDX + wc * (32 * TJ) + 16 * (g & 1) + 4 * tp;
   typedef ws16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
   if (step_begin < step_end) {
@@ -299,37 +308,45 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
     load_step(min(st + 1, a.nsteps - 1), st + 1 < step_end);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      union { ws16x4 h[2]; wbf16x8 v; } fa;
-      const __bf16* pz = &sZ[buf][z_el + 16 * ks * LDZ];
-      fa.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pz));
-      fa.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pz + 4 * LDZ));
+      union { ws16x4 h[2]; wbf16x8 v; } fa[TI];
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
+      for (int i = 0; i < TI; ++i) {
+        const __bf16* pz = &sZ[buf][z_el + 16 * ks * LDZ + 32 * i];
+        fa[i].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pz));
+        fa[i].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pz + 4 * LDZ));
+      }
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
         union { ws16x4 h[2]; wbf16x8 v; } fb;
-        const __bf16* px = &sX[buf][x_el + 16 * ks * LDX + 32 * c];
+        const __bf16* px = &sX[buf][x_el + 16 * ks * LDX + 32 * j];
         fb.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(px));
         fb.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(px + 4 * LDX));
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].v, fb.v, acc[i][j], 0, 0, 0);
       }
     }
     store_step(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
-  // D: col = lane&31 -> kin, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co within the wave's 32
+  // D: col = lane&31 -> kin, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co within the tile's 32
   const int fi = lane & 31, fh = lane >> 5;
   const bool add = gridDim.z == 1 && a.accumulate;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
+  for (int j = 0; j < TJ; ++j) {
+    const int c = wc * TJ + j;
     if (kc0 + c >= a.nchunks) break;
-    float* out = (gridDim.z == 1 ? a.dw : a.dw + (long)split * a.nchunks * a.Cout * 32) +
-                 ((long)(kc0 + c) * a.Cout + co0 + wave * 32 + 4 * fh) * 32 + fi;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float* o = out + (long)((r & 3) + 8 * (r >> 2)) * 32;
-      float v = acc[c][r];
-      if (add) v += *o;
-      *o = v;
+    for (int i = 0; i < TI; ++i) {
+      float* out = (gridDim.z == 1 ? a.dw : a.dw + (long)split * a.nchunks * a.Cout * 32) +
+                   ((long)(kc0 + c) * a.Cout + co0 + wr * (32 * TI) + 32 * i + 4 * fh) * 32 + fi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float* o = out + (long)((r & 3) + 8 * (r >> 2)) * 32;
+        float v = acc[i][j][r];
+        if (add) v += *o;
+        *o = v;
+      }
     }
   }
 }
