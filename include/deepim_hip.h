@@ -277,6 +277,14 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
  * taps and runs the single-tap phase on the gathered-tap kernel. */
 int dim_f32_to_bf16(const float* src, void* dst_bf16, long n, void* stream);
 int dim_bf16_to_f32(const void* src_bf16, float* dst, long n, void* stream);
+/* The packers with the rounding folded in: each writes exactly dim_f32_to_bf16 of its f32 twin's output (same element count, same
+ * order) in one pass over the MXNet-layout weights -- the training executor re-packs every layer after every update.
+ * dim_conv2d_pack_weight_bf16 covers both dim_conv2d_pack_weight (CoutPad == Cout) and dim_conv2d_pack_weight_padded. */
+int dim_conv2d_pack_weight_bf16(const float* w_oihw, void* w_packed_bf16, int Cout, int CoutPad, int Cin, int KH, int KW, void* stream);
+int dim_conv2d_dgrad_pack_weight_bf16(const float* w_oihw, void* w_packed_bf16, int Cout, int Cin, int KH, int KW, int stride, int pad,
+                                      void* stream);
+int dim_deconv4x4s2_pack_weight_bf16(const float* w_iohw, void* w_packed_bf16, int Cin, int Cout, void* stream);
+int dim_fc_dgrad_pack_weight_bf16(const float* w_out_in, void* w_packed_bf16, int Out, int C, int H, int W, void* stream);
 int dim_conv2d_fwd_bf16(const float* x, const void* w_packed_bf16, const float* bias, float* y, float* workspace, int N, int H, int W,
                         int Cin, int Cout, int KH, int KW, int stride, int pad, float slope, int splits, int tile, void* stream);
 int dim_conv2d_fwd_ex_bf16(const float* x, const void* w_packed_bf16, const float* bias, float* y, int N, int H, int W, int Cin,

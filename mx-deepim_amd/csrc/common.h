@@ -76,6 +76,135 @@ __device__ __forceinline__ float4 buf_load16_nt(__amdgpu_buffer_rsrc_t r, int vo
   f.w = __uint_as_float(v.w);
   return f;
 }
+
+// Weight layout converters (MXNet arrays <-> the kernels' [chunk][n][32] arrays; ~100 MB each way per training iteration plus fc6's
+// 84 MB) as LDS-tiled transposes.  A workgroup (bx, by) moves G sub-blocks of 32 (r) x Q (q) elements between
+//   "rows" side:   rows[bx * rows_x + by * rows_y + g * sg + r * sr + q]     q contiguous (the taps of one (out, in) channel pair, or
+//                                                                            fc6's pixels); g_fast says whether g or r is the next
+//                                                                            contiguous index (sg < sr), which orders the load loop
+//   "packed" side: nj runs of 32 G contiguous elements, run j at jbase[j] + bx * jx[j] + by * 32 G holding tap jq[j] (-1: zeros)
+//                  -- or, table-free (nj == 0): run q at bx * packed_x + by * 32 G + q * dq for every q < Q
+// through an LDS image with an odd lane stride on both sides.  Sub-blocks g >= gmax - by G and rows r >= rmax - 32 bx are padding:
+// zeros on the packed side, untouched on the rows side.  The element-per-thread versions these replace gathered one side with a
+// 36..320-byte lane stride and ran at 0.6-1.3 TB/s.  TO_PACKED: rows -> packed (PT = float or __bf16); else packed -> rows with
+// rows = (accumulate ? rows : 0) + scale * packed.
+struct WTileArgs {
+  const void* src;
+  void* dst;
+  int G, Q, gmax, rmax, g_fast, nj;
+  long sg, sr, rows_x, rows_y, dq, packed_x;
+  float scale;
+  int accumulate;
+  int jq[32];
+  long jbase[32], jx[32];
+};
+template <bool TO_PACKED, typename PT>
+__global__ __launch_bounds__(256) void weight_tile_kernel(WTileArgs a) {
+  extern __shared__ float wt_tile[];
+  __shared__ int s_jq[32];
+  __shared__ long s_jb[32];
+  const int G = a.G, Q = a.Q, P = Q | 1, lg = 31 - __builtin_clz(G);  // G is a power of two
+  const int bx = blockIdx.x, by = blockIdx.y;
+  const bool table = a.nj > 0;
+  const int nj = table ? a.nj : Q;
+  if (table && threadIdx.x < a.nj) {
+    s_jq[threadIdx.x] = a.jq[threadIdx.x];
+    s_jb[threadIdx.x] = a.jbase[threadIdx.x] + bx * a.jx[threadIdx.x];
+  }
+  const int gvalid = min(G, a.gmax - by * G), rvalid = min(32, a.rmax - bx * 32);
+  const long rbase = bx * a.rows_x + by * a.rows_y, pbase = (long)by * 32 * G;
+  const int n_rows = G * 32 * Q, n_packed = nj * 32 * G;
+  // LDS address of (g, r, q): the load order's (g, r) index times P, skewed by r when g is the fast one (lane stride G P + 1: odd)
+#define WT_ADDR(g, r, q) (a.g_fast ? (((r) << lg) + (g)) * P + (q) + (r) : (((g) << 5) + (r)) * P + (q))
+  // rows side: element i = u Q + q walked in steps of 256 without divisions, four elements per thread and pass so that four loads
+  // are in flight (one load per pass left every workgroup at ~25 us whatever its size)
+  const int step_q = 256 % Q, step_u = 256 / Q;
+  int wq = threadIdx.x % Q, wu = threadIdx.x / Q;
+#define WT_ROWS_BATCH                                                             \
+    bool ok[4];                                                                    \
+    long roff[4];                                                                  \
+    int laddr[4];                                                                  \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                \
+      const int g = a.g_fast ? wu & (G - 1) : wu >> 5, r = a.g_fast ? wu >> lg : wu & 31; \
+      ok[e] = i0 + 256 * e < n_rows && g < gvalid && r < rvalid;                   \
+      roff[e] = g * a.sg + r * a.sr + wq;                                          \
+      laddr[e] = WT_ADDR(g, r, wq);                                                \
+      wq += step_q; wu += step_u;                                                  \
+      if (wq >= Q) { wq -= Q; ++wu; }                                              \
+    }
+  if (TO_PACKED) {
+    const float* rows = reinterpret_cast<const float*>(a.src) + rbase;
+    PT* packed = reinterpret_cast<PT*>(a.dst) + pbase;
+    for (int i0 = threadIdx.x; i0 < n_rows; i0 += 1024) {
+      WT_ROWS_BATCH
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = *(ok[e] ? rows + roff[e] : reinterpret_cast<const float*>(a.src));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (ok[e]) wt_tile[laddr[e]] = v[e];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n_packed; i += 256) {
+      const int t = i & (32 * G - 1), j = i >> (5 + lg), g = t >> 5, r = t & 31;
+      const int q = table ? s_jq[j] : j;
+      const long off = table ? s_jb[j] : bx * a.packed_x + j * a.dq;
+      const bool okp = q >= 0 && g < gvalid && r < rvalid;
+      const float v = wt_tile[okp ? WT_ADDR(g, r, q) : 0];
+      packed[off + t] = (PT)(okp ? v : 0.f);
+    }
+  } else {
+    const float* packed = reinterpret_cast<const float*>(a.src) + pbase;
+    float* rows = reinterpret_cast<float*>(a.dst) + rbase;
+    __syncthreads();
+    for (int i0 = threadIdx.x; i0 < n_packed; i0 += 1024) {
+      bool okp[4];
+      int laddr[4];
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = i0 + 256 * e;
+        const int t = i & (32 * G - 1), j = min(i >> (5 + lg), nj - 1), g = t >> 5, r = t & 31;
+        const int q = table ? s_jq[j] : j;
+        const long off = table ? s_jb[j] : bx * a.packed_x + j * a.dq;
+        okp[e] = i < n_packed && q >= 0 && g < gvalid && r < rvalid;
+        laddr[e] = WT_ADDR(g, r, max(q, 0));
+        v[e] = *(okp[e] ? packed + off + t : reinterpret_cast<const float*>(a.src));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (okp[e]) wt_tile[laddr[e]] = v[e];
+    }
+    __syncthreads();
+    for (int i0 = threadIdx.x; i0 < n_rows; i0 += 1024) {
+      WT_ROWS_BATCH
+      float old[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) old[e] = a.accumulate ? *(ok[e] ? rows + roff[e] : reinterpret_cast<float*>(a.dst)) : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (ok[e]) rows[roff[e]] = old[e] + a.scale * wt_tile[laddr[e]];
+    }
+  }
+#undef WT_ROWS_BATCH
+#undef WT_ADDR
+}
+inline size_t wtile_lds_bytes(int G, int Q) { return ((size_t)G * 32 * (Q | 1) + 32) * 4; }
+// sub-blocks per workgroup: a power of two <= 8 that divides `count` and keeps the LDS image within 64 KB -- the largest one that
+// still leaves >= 2048 workgroups (`outer` = the other grid dimension), else the smallest; 0 = none fits
+inline int wtile_group(int count, int Q, int outer = 1) {
+  int best = 0;
+  for (int g = 1; g <= 8; g <<= 1) {
+    if (count % g || wtile_lds_bytes(g, Q) > 65536) break;
+    if (best == 0 || (long)outer * (count / g) >= 2048) best = g;
+  }
+  return best;
+}
+template <bool TO_PACKED, typename PT>
+inline void wtile_launch(const WTileArgs& a, int gx, int gy, hipStream_t st) {
+  hipLaunchKernelGGL((weight_tile_kernel<TO_PACKED, PT>), dim3(gx, gy), dim3(256), wtile_lds_bytes(a.G, a.Q), st, a);
+}
 #endif
 
 // ---- plane GEMMs of the Winograd layers (wino_gemm.hip): launch plan, shared with the input-transform kernels of conv.hip, whose

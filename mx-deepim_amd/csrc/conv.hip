@@ -1104,8 +1104,50 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const floa
   *reinterpret_cast<float4*>(y + i) = s;
 }
 
+// the same sum for many slabs of a small array (the first layers' weight gradients: 512 slabs of 26 624 floats, where one thread per
+// float4 walking all slabs left 26 workgroups with 512 dependent-latency loads each: 181 us): workgroup = 8 float4 columns x 32 slab
+// lanes, lane p sums slabs p, p + 32, ..., then a fixed binary tree over the 32 partial sums (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_par_kernel(const float* __restrict__ slabs, const float* __restrict__ bias,
+                                                                float* __restrict__ y, long MC, int Cout, int splits, float slope,
+                                                                int has_bias) {
+  __shared__ float4 red[32][8];
+  const int qi = threadIdx.x & 7, part = threadIdx.x >> 3;
+  const long i = ((long)blockIdx.x * 8 + qi) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < MC)
+    for (int k = part; k < splits; k += 32) {
+      const float4 p = *reinterpret_cast<const float4*>(slabs + (long)k * MC + i);
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+  red[part][qi] = s;
+  __syncthreads();
+#pragma unroll
+  for (int h = 16; h >= 1; h >>= 1) {
+    if (part < h) {
+      const float4 u = red[part + h][qi];
+      float4 t = red[part][qi];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      red[part][qi] = t;
+    }
+    __syncthreads();
+  }
+  if (part == 0 && i < MC) {
+    s = red[0][qi];
+    if (has_bias) {
+      int c = (int)(i % Cout);
+      s.x += bias[c]; s.y += bias[c + 1]; s.z += bias[c + 2]; s.w += bias[c + 3];
+    }
+    s.x = s.x > 0.f ? s.x : s.x * slope;
+    s.y = s.y > 0.f ? s.y : s.y * slope;
+    s.z = s.z > 0.f ? s.z : s.z * slope;
+    s.w = s.w > 0.f ? s.w : s.w * slope;
+    *reinterpret_cast<float4*>(y + i) = s;
+  }
+}
+
 // OIHW (MXNet / reference layout) -> packed [chunk][Cout][32]  (a workgroup's B chunk is one contiguous block)
-__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KH, int KW,
+template <typename PT>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, PT* __restrict__ wp, int Cout, int Cin, int KH, int KW,
                                         int nchunks, int cin8, int CoutValid) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)nchunks * 32 * Cout;
@@ -1130,7 +1172,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
   }
   float v = 0.f;
   if (kh < KH && kw < KW && c < Cin && co < CoutValid) v = w[(((long)co * Cin + c) * KH + kh) * KW + kw];
-  wp[idx] = v;
+  wp[idx] = (PT)v;
 }
 
 // FullyConnected weight (out, in) with `in` flattened (c,h,w) [mx Flatten of NCHW] -> packed
@@ -1151,7 +1193,8 @@ __global__ void pack_fc_weight_kernel(const float* __restrict__ w, float* __rest
 // Deconvolution(k=4, s=2, p=0) weight (Cin, Cout, 4, 4) [MXNet layout] -> four packed 2x2 convolution weights, one per output
 // phase (py,px): out[2t+py, 2u+px] = sum_{dy,dx} in[t-1+dy, u-1+dx] * w[ci][co][py+2(1-dy)][px+2(1-dx)]   (pad 1, stride 1).
 // Cin is zero-padded to CinPad (multiple of 32).  Layout per phase: [chunk][Cout][32], chunk = (channel slice, dy, dx).
-__global__ void pack_deconv4x4s2_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int CinPad, int Cout) {
+template <typename PT>
+__global__ void pack_deconv4x4s2_weight_kernel(const float* __restrict__ w, PT* __restrict__ wp, int Cin, int CinPad, int Cout) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long per_phase = (long)CinPad * 4 * Cout;
   if (idx >= 4 * per_phase) return;
@@ -1166,7 +1209,7 @@ __global__ void pack_deconv4x4s2_weight_kernel(const float* __restrict__ w, floa
   int py = phase / 2, px = phase % 2;
   float v = 0.f;
   if (ci < Cin) v = w[(((long)ci * Cout + co) * 4 + (py + 2 * (1 - dy))) * 4 + (px + 2 * (1 - dx))];
-  wp[idx] = v;
+  wp[idx] = (PT)v;
 }
 
 // Convolution with a handful of output channels (flow / mask heads, Cout <= 2): one wave per output pixel, lanes stride the
@@ -1365,34 +1408,67 @@ long dim_conv2d_packed_weight_floats(int Cout, int Cin, int KH, int KW) {
   return (long)KH * KW * Cin * Cout;
 }
 
+// OIHW -> [chunk][CoutPad][32], rows >= Cout zero.  Cin % 32 == 0: tiled (workgroup = (32-channel slice, G output channels):
+// rows = w[co][cc * 32 + r][tap], packed run tap at ((cc * T + tap) * CoutPad + co) * 32); the 8-channel first layer: per element
+extern "C++" template <typename PT>
+int pack_conv_weight_any(const float* w_oihw, PT* w_packed, int Cout, int CoutPad, int Cin, int KH, int KW, void* stream) {
+  const int cin8 = Cin == 8, T = KH * KW;
+  const int nchunks = cin8 ? (T + 3) / 4 : T * (Cin / 32);
+  const int G = cin8 ? 0 : wtile_group(CoutPad, T, Cin / 32);
+  if (G) {
+    WTileArgs a = {};
+    a.src = w_oihw; a.dst = w_packed;
+    a.G = G; a.Q = T; a.gmax = Cout; a.rmax = Cin; a.g_fast = 0; a.nj = 0;
+    a.sg = (long)Cin * T; a.sr = T; a.rows_x = 32L * T; a.rows_y = (long)G * Cin * T;
+    a.dq = (long)CoutPad * 32; a.packed_x = (long)T * CoutPad * 32;
+    wtile_launch<true, PT>(a, Cin / 32, CoutPad / G, as_stream(stream));
+  } else {
+    long total = (long)nchunks * 32 * CoutPad;
+    hipLaunchKernelGGL((pack_conv_weight_kernel<PT>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, CoutPad,
+                       Cin, KH, KW, nchunks, cin8, Cout);
+  }
+  return check_launch("pack_conv_weight");
+}
+
 int dim_conv2d_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream) {
   DIM_REQUIRE(w_oihw && w_packed, "null weight pointer");
   DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
   DIM_REQUIRE(Cin != 8 || KW <= 8, "Cin==8 path needs KW<=8 (got %d)", KW);
-  int cin8 = Cin == 8;
-  int nchunks = cin8 ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
-  long total = (long)nchunks * 32 * Cout;
-  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed,
-                     Cout, Cin, KH, KW, nchunks, cin8, Cout);
-  return check_launch("pack_conv_weight");
+  return pack_conv_weight_any(w_oihw, w_packed, Cout, Cout, Cin, KH, KW, stream);
 }
 
 // same, with the output-channel count padded with zero rows up to CoutPad (a multiple of 64): w_oihw has Cout rows
 int dim_conv2d_pack_weight_padded(const float* w_oihw, float* w_packed, int Cout, int CoutPad, int Cin, int KH, int KW, void* stream) {
   DIM_REQUIRE(w_oihw && w_packed, "null weight pointer");
   DIM_REQUIRE(Cin % 32 == 0 && CoutPad >= Cout && CoutPad % 64 == 0, "Cin %% 32 == 0 and CoutPad a multiple of 64 >= Cout required");
-  int nchunks = KH * KW * (Cin / 32);
-  long total = (long)nchunks * 32 * CoutPad;
-  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed,
-                     CoutPad, Cin, KH, KW, nchunks, 0, Cout);
-  return check_launch("pack_conv_weight_padded");
+  return pack_conv_weight_any(w_oihw, w_packed, Cout, CoutPad, Cin, KH, KW, stream);
+}
+
+// the bf16 image of the same packed array in one pass (== dim_f32_to_bf16 of dim_conv2d_pack_weight_padded's output); CoutPad == Cout
+// for an unpadded layer
+int dim_conv2d_pack_weight_bf16(const float* w_oihw, void* w_packed_bf16, int Cout, int CoutPad, int Cin, int KH, int KW, void* stream) {
+  DIM_REQUIRE(w_oihw && w_packed_bf16, "null weight pointer");
+  DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
+  DIM_REQUIRE(Cin != 8 || KW <= 8, "Cin==8 path needs KW<=8 (got %d)", KW);
+  DIM_REQUIRE(CoutPad >= Cout, "CoutPad < Cout");
+  return pack_conv_weight_any(w_oihw, reinterpret_cast<__bf16*>(w_packed_bf16), Cout, CoutPad, Cin, KH, KW, stream);
 }
 
 int dim_fc_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream) {
   DIM_REQUIRE(w_out_in && w_packed, "null weight pointer");
   long total = (long)Out * C * H * W;
-  hipLaunchKernelGGL(pack_fc_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_out_in, w_packed, Out,
-                     C, H, W);
+  const int HW = H * W, G = C % 32 == 0 ? wtile_group(Out, HW, C / 32) : 0;
+  if (G) {  // workgroup (channel slice cb, G outputs): rows = w[o][cb * 32 + r][q], packed run q at ((cb * HW + q) * Out + o) * 32
+    WTileArgs a = {};
+    a.src = w_out_in; a.dst = w_packed;
+    a.G = G; a.Q = HW; a.gmax = Out; a.rmax = C; a.g_fast = 0; a.nj = 0;
+    a.sg = (long)C * HW; a.sr = HW; a.rows_x = 32L * HW; a.rows_y = (long)G * C * HW;
+    a.dq = (long)Out * 32; a.packed_x = (long)HW * Out * 32;
+    wtile_launch<true, float>(a, C / 32, Out / G, as_stream(stream));
+  } else {
+    hipLaunchKernelGGL(pack_fc_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_out_in, w_packed, Out,
+                       C, H, W);
+  }
   return check_launch("pack_fc_weight");
 }
 
@@ -1456,8 +1532,12 @@ int dim_splitk_reduce(const float* slabs, const float* bias, float* y, long M, i
   DIM_REQUIRE(slabs && y, "null pointer");
   DIM_REQUIRE(Cout % 4 == 0 && splits >= 1, "bad geometry");
   long MC = M * Cout;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MC / 4, 256)), dim3(256), 0, as_stream(stream), slabs, bias, y, MC, Cout,
-                     splits, slope, bias != nullptr);
+  if (MC / 4 < 65536 && splits >= 64)  // fewer than 256 workgroups of serial sums: spread the slabs over lanes instead
+    hipLaunchKernelGGL(splitk_reduce_par_kernel, dim3(ceil_div(MC / 4, 8)), dim3(256), 0, as_stream(stream), slabs, bias, y, MC, Cout,
+                       splits, slope, bias != nullptr);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MC / 4, 256)), dim3(256), 0, as_stream(stream), slabs, bias, y, MC, Cout,
+                       splits, slope, bias != nullptr);
   return check_launch("splitk_reduce");
 }
 
@@ -1743,7 +1823,8 @@ static inline DgAxis dg_axis(int K, int stride, int p, int ph) {
   return {emax - emin + 1, emin};
 }
 
-__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int CinPad, int KH, int KW,
+extern "C++" template <typename PT>
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, PT* __restrict__ wp, int Cout, int Cin, int CinPad, int KH, int KW,
                                          int stride, int pad, int py, int px, int nth, int ntw, int eminh, int eminw, int deconv_layout) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)(Cout / 32) * nth * ntw * CinPad * 32;
@@ -1761,7 +1842,7 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __r
   if (ci < Cin && ky >= 0 && ky < KH && kx >= 0 && kx < KW)
     v = deconv_layout ? w[(((long)ci * Cout + co) * KH + ky) * KW + kx]   // never used (deconv dgrad is a plain forward conv)
                       : w[(((long)co * Cin + ci) * KH + ky) * KW + kx];
-  wp[idx] = v;
+  wp[idx] = (PT)v;
 }
 
 long dim_conv2d_dgrad_packed_weight_floats(int Cout, int Cin, int KH, int KW, int stride, int pad) {
@@ -1774,25 +1855,58 @@ long dim_conv2d_dgrad_packed_weight_floats(int Cout, int Cin, int KH, int KW, in
   return total;
 }
 
-int dim_conv2d_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, int stride, int pad,
-                                 void* stream) {
+// tiled: workgroup = (32-slice cc of Cout, G input channels): rows = w[cc * 32 + r][ci][ky][kx], packed run (phase, jy, jx) at
+// phase offset + ((cc * taps + jtap) * CinPad + ci) * 32 -- all phases in one launch through the tap table (<= 32 runs)
+extern "C++" template <typename PT>
+int dgrad_pack_weight_any(const float* w_oihw, PT* w_packed, int Cout, int Cin, int KH, int KW, int stride, int pad, void* stream) {
   DIM_REQUIRE(w_oihw && w_packed, "null pointer");
   DIM_REQUIRE(stride == 1 || stride == 2, "dgrad supports stride 1 or 2");
   DIM_REQUIRE(Cout % 32 == 0, "Cout must be a multiple of 32 (it is the contraction dimension of dgrad)");
   int CinPad = (Cin + 63) / 64 * 64;
   int nph = stride == 1 ? 1 : 2;
+  int runs = 0;
+  for (int py = 0; py < nph; ++py)
+    for (int px = 0; px < nph; ++px) runs += dg_axis(KH, stride, pad, py).ntaps * dg_axis(KW, stride, pad, px).ntaps;
+  const int T = KH * KW, G = runs <= 32 ? wtile_group(CinPad, T, Cout / 32) : 0;
+  WTileArgs t = {};
   long off = 0;
   for (int py = 0; py < nph; ++py)
     for (int px = 0; px < nph; ++px) {
       DgAxis ah = dg_axis(KH, stride, pad, py), aw = dg_axis(KW, stride, pad, px);
       long total = (long)(Cout / 32) * ah.ntaps * aw.ntaps * CinPad * 32;
-      if (total > 0) {
-        hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw,
+      if (total > 0 && !G) {
+        hipLaunchKernelGGL((pack_dgrad_weight_kernel<PT>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw,
                            w_packed + off, Cout, Cin, CinPad, KH, KW, stride, pad, py, px, ah.ntaps, aw.ntaps, ah.emin, aw.emin, 0);
+      } else if (total > 0) {
+        for (int jy = 0; jy < ah.ntaps; ++jy)
+          for (int jx = 0; jx < aw.ntaps; ++jx) {
+            const int ky = (stride == 1) ? KH - 1 - jy : py + pad - 2 * (jy + ah.emin);
+            const int kx = (stride == 1) ? KW - 1 - jx : px + pad - 2 * (jx + aw.emin);
+            t.jq[t.nj] = (ky >= 0 && ky < KH && kx >= 0 && kx < KW) ? ky * KW + kx : -1;
+            t.jbase[t.nj] = off + (long)(jy * aw.ntaps + jx) * CinPad * 32;
+            t.jx[t.nj] = (long)ah.ntaps * aw.ntaps * CinPad * 32;
+            ++t.nj;
+          }
       }
       off += total;
     }
+  if (G && t.nj > 0) {
+    t.src = w_oihw; t.dst = w_packed;
+    t.G = G; t.Q = T; t.gmax = Cin; t.rmax = Cout; t.g_fast = 1;
+    t.sg = T; t.sr = (long)Cin * T; t.rows_x = 32L * Cin * T; t.rows_y = (long)G * T;
+    wtile_launch<true, PT>(t, Cout / 32, CinPad / G, as_stream(stream));
+  }
   return check_launch("pack_dgrad_weight");
+}
+
+int dim_conv2d_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, int stride, int pad,
+                                 void* stream) {
+  return dgrad_pack_weight_any(w_oihw, w_packed, Cout, Cin, KH, KW, stride, pad, stream);
+}
+
+int dim_conv2d_dgrad_pack_weight_bf16(const float* w_oihw, void* w_packed_bf16, int Cout, int Cin, int KH, int KW, int stride, int pad,
+                                      void* stream) {
+  return dgrad_pack_weight_any(w_oihw, reinterpret_cast<__bf16*>(w_packed_bf16), Cout, Cin, KH, KW, stride, pad, stream);
 }
 
 // dx (N,H,W,dx_cstride)[..., :Cin] (+)= dgrad(dy (N,Ho,Wo,dy_cstride)[..., :Cout]).  accumulate != 0 adds to dx (skip connections).
@@ -1860,13 +1974,42 @@ long dim_deconv4x4s2_packed_weight_floats(int Cin, int Cout) {
   return 4L * CinPad * 4 * Cout;
 }
 
-int dim_deconv4x4s2_pack_weight(const float* w_iohw, float* w_packed, int Cin, int Cout, void* stream) {
+// tiled: workgroup = (32-slice cc of Cin, G output channels): rows = w[cc * 32 + r][co][ky][kx], packed run (phase, dy, dx) at
+// phase * per_phase + ((cc * 4 + tap) * Cout + co) * 32
+extern "C++" template <typename PT>
+int deconv_pack_weight_any(const float* w_iohw, PT* w_packed, int Cin, int Cout, void* stream) {
   DIM_REQUIRE(w_iohw && w_packed, "null pointer");
   int CinPad = (Cin + 31) / 32 * 32;
   long total = 4L * CinPad * 4 * Cout;
-  hipLaunchKernelGGL(pack_deconv4x4s2_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_iohw, w_packed,
-                     Cin, CinPad, Cout);
+  const int G = wtile_group(Cout, 16, CinPad / 32);
+  if (G) {
+    WTileArgs t = {};
+    const long per_phase = (long)CinPad * 4 * Cout;
+    for (int phase = 0; phase < 4; ++phase)
+      for (int tap = 0; tap < 4; ++tap) {
+        const int py = phase / 2, px = phase % 2, dy = tap / 2, dx = tap % 2;
+        t.jq[t.nj] = (py + 2 * (1 - dy)) * 4 + (px + 2 * (1 - dx));
+        t.jbase[t.nj] = phase * per_phase + (long)tap * Cout * 32;
+        t.jx[t.nj] = 4L * Cout * 32;
+        ++t.nj;
+      }
+    t.src = w_iohw; t.dst = w_packed;
+    t.G = G; t.Q = 16; t.gmax = Cout; t.rmax = Cin; t.g_fast = 1;
+    t.sg = 16; t.sr = (long)Cout * 16; t.rows_x = 32L * Cout * 16; t.rows_y = (long)G * 16;
+    wtile_launch<true, PT>(t, CinPad / 32, Cout / G, as_stream(stream));
+  } else {
+    hipLaunchKernelGGL((pack_deconv4x4s2_weight_kernel<PT>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_iohw, w_packed,
+                       Cin, CinPad, Cout);
+  }
   return check_launch("pack_deconv_weight");
+}
+
+int dim_deconv4x4s2_pack_weight(const float* w_iohw, float* w_packed, int Cin, int Cout, void* stream) {
+  return deconv_pack_weight_any(w_iohw, w_packed, Cin, Cout, stream);
+}
+
+int dim_deconv4x4s2_pack_weight_bf16(const float* w_iohw, void* w_packed_bf16, int Cin, int Cout, void* stream) {
+  return deconv_pack_weight_any(w_iohw, reinterpret_cast<__bf16*>(w_packed_bf16), Cin, Cout, stream);
 }
 
 // y[:, oy, ox, out_coff : out_coff+Cout] = LeakyReLU(Crop(Deconvolution(x, k=4, s=2, p=0) + bias, offset=(crop,crop)))   (NHWC)

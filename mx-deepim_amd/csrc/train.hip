@@ -53,7 +53,8 @@ __global__ void unpack_fc_weight_kernel(const float* __restrict__ wp, float* __r
 
 // fc dgrad weights: dX (B, (h,w,c)) = dz (B, Out) * W  as a 1x1 "convolution" with Cin' = Out, Cout' = C*H*W (NHWC order):
 // wp[kc][n = (h,w,c)][kin] = W[o = kc*32+kin][c*H*W + h*W + w]
-__global__ void pack_fc_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Out, int C, int H, int W) {
+template <typename PT>
+__global__ void pack_fc_dgrad_weight_kernel(const float* __restrict__ w, PT* __restrict__ wp, int Out, int C, int H, int W) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)Out * C * H * W;
   if (idx >= total) return;
@@ -63,7 +64,7 @@ __global__ void pack_fc_dgrad_weight_kernel(const float* __restrict__ w, float* 
   int kc = (int)(t / ((long)C * H * W));
   int c = (int)(n % C);
   long hw = n / C;
-  wp[idx] = w[(long)(kc * 32 + kin) * C * H * W + (long)c * H * W + hw];
+  wp[idx] = (PT)w[(long)(kc * 32 + kin) * C * H * W + (long)c * H * W + hw];
 }
 
 // ---------------------------------------------------------------------------------------------- loss gradients
@@ -475,25 +476,67 @@ int dim_conv2d_unpack_weight(const float* w_packed, float* w_oihw, int Cout, int
   DIM_REQUIRE(w_packed && w_oihw, "null pointer");
   DIM_REQUIRE(CoutPad >= Cout, "CoutPad < Cout");
   long total = (long)Cout * Cin * KH * KW;
-  hipLaunchKernelGGL(unpack_conv_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_packed, w_oihw, Cout, CoutPad,
-                     Cin, KH, KW, Cin == 8, scale, accumulate);
+  const int T = KH * KW, G = (Cin % 32 == 0) ? wtile_group(CoutPad, T, Cin / 32) : 0;
+  if (G) {  // the inverse of dim_conv2d_pack_weight's tiling
+    WTileArgs a = {};
+    a.src = w_packed; a.dst = w_oihw;
+    a.G = G; a.Q = T; a.gmax = Cout; a.rmax = Cin; a.g_fast = 0; a.nj = 0;
+    a.sg = (long)Cin * T; a.sr = T; a.rows_x = 32L * T; a.rows_y = (long)G * Cin * T;
+    a.dq = (long)CoutPad * 32; a.packed_x = (long)T * CoutPad * 32;
+    a.scale = scale; a.accumulate = accumulate;
+    wtile_launch<false, float>(a, Cin / 32, CoutPad / G, as_stream(stream));
+  } else {
+    hipLaunchKernelGGL(unpack_conv_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_packed, w_oihw, Cout, CoutPad,
+                       Cin, KH, KW, Cin == 8, scale, accumulate);
+  }
   return check_launch("unpack_conv_weight");
 }
 
 int dim_fc_unpack_weight(const float* w_packed, float* w_out_in, int Out, int C, int H, int W, void* stream) {
   DIM_REQUIRE(w_packed && w_out_in, "null pointer");
   long total = (long)Out * C * H * W;
-  hipLaunchKernelGGL(unpack_fc_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_packed, w_out_in, Out, C, H, W);
+  const int HW = H * W, G = C % 32 == 0 ? wtile_group(Out, HW, C / 32) : 0;
+  if (G) {  // the inverse of dim_fc_pack_weight's tiling
+    WTileArgs a = {};
+    a.src = w_packed; a.dst = w_out_in;
+    a.G = G; a.Q = HW; a.gmax = Out; a.rmax = C; a.g_fast = 0; a.nj = 0;
+    a.sg = (long)C * HW; a.sr = HW; a.rows_x = 32L * HW; a.rows_y = (long)G * C * HW;
+    a.dq = (long)Out * 32; a.packed_x = (long)HW * Out * 32;
+    a.scale = 1.0f; a.accumulate = 0;
+    wtile_launch<false, float>(a, C / 32, Out / G, as_stream(stream));
+  } else {
+    hipLaunchKernelGGL(unpack_fc_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_packed, w_out_in, Out, C, H, W);
+  }
   return check_launch("unpack_fc_weight");
 }
 
-int dim_fc_dgrad_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream) {
+// workgroup (output slice ob, G channels): rows = w[ob * 32 + r][c][q], packed run q at ((ob * HW + q) * C + c) * 32
+extern "C++" template <typename PT>
+int fc_dgrad_pack_weight_any(const float* w_out_in, PT* w_packed, int Out, int C, int H, int W, void* stream) {
   DIM_REQUIRE(w_out_in && w_packed, "null pointer");
   DIM_REQUIRE(Out % 32 == 0, "Out must be a multiple of 32");
   long total = (long)Out * C * H * W;
-  hipLaunchKernelGGL(pack_fc_dgrad_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_out_in, w_packed, Out, C, H,
-                     W);
+  const int HW = H * W, G = wtile_group(C, HW, Out / 32);
+  if (G) {
+    WTileArgs a = {};
+    a.src = w_out_in; a.dst = w_packed;
+    a.G = G; a.Q = HW; a.gmax = C; a.rmax = Out; a.g_fast = 1; a.nj = 0;
+    a.sg = HW; a.sr = (long)C * HW; a.rows_x = 32L * C * HW; a.rows_y = (long)G * HW;
+    a.dq = (long)C * 32; a.packed_x = (long)HW * C * 32;
+    wtile_launch<true, PT>(a, Out / 32, C / G, as_stream(stream));
+  } else {
+    hipLaunchKernelGGL((pack_fc_dgrad_weight_kernel<PT>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_out_in, w_packed, Out, C, H,
+                       W);
+  }
   return check_launch("pack_fc_dgrad_weight");
+}
+
+int dim_fc_dgrad_pack_weight(const float* w_out_in, float* w_packed, int Out, int C, int H, int W, void* stream) {
+  return fc_dgrad_pack_weight_any(w_out_in, w_packed, Out, C, H, W, stream);
+}
+
+int dim_fc_dgrad_pack_weight_bf16(const float* w_out_in, void* w_packed_bf16, int Out, int C, int H, int W, void* stream) {
+  return fc_dgrad_pack_weight_any(w_out_in, reinterpret_cast<__bf16*>(w_packed_bf16), Out, C, H, W, stream);
 }
 
 int dim_flow_loss_grad(const float* flow_est, const float* flow_label, const float* flow_weights, float* grad, long n, float normalize_flow,

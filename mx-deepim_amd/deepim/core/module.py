@@ -205,7 +205,6 @@ class MutableModule(object):
         """master (MXNet layout) -> the kernels' packed copies: forward layouts (FlowNetHip.packed) and dgrad layouts
         (bf16 mode: bf16 images of the same packed arrays)"""
         net, w = self.net, self.w
-        cvt = ops.to_bf16 if self.bf16 else (lambda t: t)
         for name, cout, k, s, p in ENCODER:
             if forward:
                 if name in net.wino:   # 3x3 / stride-1 layers run their forward through Winograd: re-transform the weights
@@ -219,17 +218,17 @@ class MutableModule(object):
             elif name in net.wino5:  # 5x5 / stride-2 layers: input gradient through Winograd too (four phase images of dX)
                 self.wino5_dgrad[name] = ops.winograd5x5s2_dgrad_pack_weight(w[name + "_weight"])
             elif name != "flow_conv1":
-                self.dgrad_packed[name] = cvt(ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p))
+                self.dgrad_packed[name] = ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p, as_bf16=self.bf16)
         if forward:
             net.packed["fc6"] = ops.fc_pack_weight(w["fc6_weight"], 1024, 8, 10)
             net.packed["deconv5"] = net.pack_deconv(w["deconv5_weight"])
             net.packed["deconv4"] = net.pack_deconv(w["deconv4_weight"])
             for n in ("Convolution1", "Convolution2", "Convolution3", "mask_conv3"):
                 net.packed[n] = ops.conv_small_cout_pack_weight(w[n + "_weight"])
-        self.dgrad_packed["fc6"] = cvt(ops.fc_dgrad_pack_weight(w["fc6_weight"], 1024, 8, 10))
+        self.dgrad_packed["fc6"] = ops.fc_dgrad_pack_weight(w["fc6_weight"], 1024, 8, 10, as_bf16=self.bf16)
         # deconv dgrad = a plain stride-2 convolution of the output gradient with the deconv weight read as (O=Cin, I=Cout, 4, 4)
-        self.dgrad_packed["deconv5"] = cvt(ops.conv2d_pack_weight_padded(w["deconv5_weight"], 1024))
-        self.dgrad_packed["deconv4"] = cvt(ops.conv2d_pack_weight_padded(w["deconv4_weight"], ops.pad64(1026)))
+        self.dgrad_packed["deconv5"] = ops.conv2d_pack_weight_padded(w["deconv5_weight"], 1024, as_bf16=self.bf16)
+        self.dgrad_packed["deconv4"] = ops.conv2d_pack_weight_padded(w["deconv4_weight"], ops.pad64(1026), as_bf16=self.bf16)
 
     # ------------------------------------------------------------------------------------------------------------
     def forward(self, batch):

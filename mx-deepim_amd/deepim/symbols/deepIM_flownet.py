@@ -324,12 +324,10 @@ class FlowNetHip(object):
 
     def pack_conv(self, w_oihw):
         """MXNet (Cout,Cin,kh,kw) -> the forward kernel's packed array (bf16 copy in bf16 mode)"""
-        wp = ops.conv2d_pack_weight(w_oihw)
-        return ops.to_bf16(wp) if self.bf16 else wp
+        return ops.conv2d_pack_weight(w_oihw, as_bf16=self.bf16)
 
     def pack_deconv(self, w_iohw):
-        wp = ops.deconv4x4s2_pack_weight(w_iohw)
-        return ops.to_bf16(wp) if self.bf16 else wp
+        return ops.deconv4x4s2_pack_weight(w_iohw, as_bf16=self.bf16)
 
     @staticmethod
     def _wino_tile(cout, tiles):

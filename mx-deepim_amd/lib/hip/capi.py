@@ -50,6 +50,10 @@ SIGNATURES = {
     "dim_conv2d_fwd_partial": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_splitk_reduce": (I, [P, P, P, L, I, I, F, P]),
     "dim_f32_to_bf16": (I, [P, P, L, P]),
+    "dim_conv2d_pack_weight_bf16": (I, [P, P, I, I, I, I, I, P]),
+    "dim_conv2d_dgrad_pack_weight_bf16": (I, [P, P, I, I, I, I, I, I, P]),
+    "dim_deconv4x4s2_pack_weight_bf16": (I, [P, P, I, I, P]),
+    "dim_fc_dgrad_pack_weight_bf16": (I, [P, P, I, I, I, I, P]),
     "dim_bf16_to_f32": (I, [P, P, L, P]),
     "dim_conv2d_fwd_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, P]),
     "dim_conv2d_fwd_ex_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),

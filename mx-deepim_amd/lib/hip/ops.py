@@ -180,11 +180,14 @@ def test_blobs_from_raw(obs_bgr, ren_bgr, depth_ren, depth_factor, pixel_means_b
                                         dptr(mask_rendered, f32), dptr(bbox, i32), current_stream()))
 
 
-def conv2d_pack_weight(w_oihw):
+def conv2d_pack_weight(w_oihw, as_bf16=False):
     Cout, Cin, KH, KW = w_oihw.shape
     n = lib().dim_conv2d_packed_weight_floats(Cout, Cin, KH, KW)
-    wp = _new((n,), w_oihw)
-    check(lib().dim_conv2d_pack_weight(dptr(w_oihw.contiguous(), f32), dptr(wp, f32), Cout, Cin, KH, KW, current_stream()))
+    wp = torch.empty((n,), dtype=bf16 if as_bf16 else f32, device=w_oihw.device)
+    if as_bf16:
+        check(lib().dim_conv2d_pack_weight_bf16(dptr(w_oihw.contiguous(), f32), dptr(wp, bf16), Cout, Cout, Cin, KH, KW, current_stream()))
+    else:
+        check(lib().dim_conv2d_pack_weight(dptr(w_oihw.contiguous(), f32), dptr(wp, f32), Cout, Cin, KH, KW, current_stream()))
     return wp
 
 
@@ -419,10 +422,18 @@ def pad32(c):
     return (c + 31) // 32 * 32
 
 
-def deconv4x4s2_pack_weight(w_iohw):
+def _new_packed(n, like, as_bf16):
+    return torch.empty((n,), dtype=bf16 if as_bf16 else f32, device=like.device)
+
+
+def deconv4x4s2_pack_weight(w_iohw, as_bf16=False):
+    """as_bf16: the bf16 image of the packed array in one pass (== to_bf16 of the f32 result); same for the packers below"""
     Cin, Cout = w_iohw.shape[:2]
-    wp = _new((lib().dim_deconv4x4s2_packed_weight_floats(Cin, Cout),), w_iohw)
-    check(lib().dim_deconv4x4s2_pack_weight(dptr(w_iohw.contiguous(), f32), dptr(wp, f32), Cin, Cout, current_stream()))
+    wp = _new_packed(lib().dim_deconv4x4s2_packed_weight_floats(Cin, Cout), w_iohw, as_bf16)
+    if as_bf16:
+        check(lib().dim_deconv4x4s2_pack_weight_bf16(dptr(w_iohw.contiguous(), f32), dptr(wp, bf16), Cin, Cout, current_stream()))
+    else:
+        check(lib().dim_deconv4x4s2_pack_weight(dptr(w_iohw.contiguous(), f32), dptr(wp, f32), Cin, Cout, current_stream()))
     return wp
 
 
@@ -473,10 +484,14 @@ def pad64(c):
     return (c + 63) // 64 * 64
 
 
-def conv2d_dgrad_pack_weight(w_oihw, stride, pad):
+def conv2d_dgrad_pack_weight(w_oihw, stride, pad, as_bf16=False):
     Cout, Cin, KH, KW = w_oihw.shape
-    wp = _new((lib().dim_conv2d_dgrad_packed_weight_floats(Cout, Cin, KH, KW, stride, pad),), w_oihw)
-    check(lib().dim_conv2d_dgrad_pack_weight(dptr(w_oihw.contiguous(), f32), dptr(wp, f32), Cout, Cin, KH, KW, stride, pad, current_stream()))
+    wp = _new_packed(lib().dim_conv2d_dgrad_packed_weight_floats(Cout, Cin, KH, KW, stride, pad), w_oihw, as_bf16)
+    if as_bf16:
+        check(lib().dim_conv2d_dgrad_pack_weight_bf16(dptr(w_oihw.contiguous(), f32), dptr(wp, bf16), Cout, Cin, KH, KW, stride, pad,
+                                                      current_stream()))
+    else:
+        check(lib().dim_conv2d_dgrad_pack_weight(dptr(w_oihw.contiguous(), f32), dptr(wp, f32), Cout, Cin, KH, KW, stride, pad, current_stream()))
     return wp
 
 
@@ -536,10 +551,13 @@ def _p(t, off=0):
     return dptr(t, f32) + 4 * off
 
 
-def conv2d_pack_weight_padded(w_oihw, CoutPad):
+def conv2d_pack_weight_padded(w_oihw, CoutPad, as_bf16=False):
     Cout, Cin, KH, KW = w_oihw.shape
-    wp = _new((KH * KW * Cin * CoutPad,), w_oihw)
-    check(lib().dim_conv2d_pack_weight_padded(dptr(w_oihw.contiguous(), f32), dptr(wp, f32), Cout, CoutPad, Cin, KH, KW, current_stream()))
+    wp = _new_packed(KH * KW * Cin * CoutPad, w_oihw, as_bf16)
+    if as_bf16:
+        check(lib().dim_conv2d_pack_weight_bf16(dptr(w_oihw.contiguous(), f32), dptr(wp, bf16), Cout, CoutPad, Cin, KH, KW, current_stream()))
+    else:
+        check(lib().dim_conv2d_pack_weight_padded(dptr(w_oihw.contiguous(), f32), dptr(wp, f32), Cout, CoutPad, Cin, KH, KW, current_stream()))
     return wp
 
 
@@ -555,10 +573,13 @@ def fc_unpack_weight(w_packed, out_w, C, H, W):
     return out_w
 
 
-def fc_dgrad_pack_weight(w_out_in, C, H, W, out=None):
+def fc_dgrad_pack_weight(w_out_in, C, H, W, out=None, as_bf16=False):
     Out = w_out_in.shape[0]
-    out = out if out is not None else _new((Out * C * H * W,), w_out_in)
-    check(lib().dim_fc_dgrad_pack_weight(dptr(w_out_in, f32), dptr(out, f32), Out, C, H, W, current_stream()))
+    out = out if out is not None else _new_packed(Out * C * H * W, w_out_in, as_bf16)
+    if as_bf16:
+        check(lib().dim_fc_dgrad_pack_weight_bf16(dptr(w_out_in, f32), dptr(out, bf16), Out, C, H, W, current_stream()))
+    else:
+        check(lib().dim_fc_dgrad_pack_weight(dptr(w_out_in, f32), dptr(out, f32), Out, C, H, W, current_stream()))
     return out
 
 

@@ -218,3 +218,45 @@ def test_deconv4x4s2_bf16_forward_and_backward(ops, shape):
     dw = torch.empty((Cin, Cout, 4, 4), device=DEV)
     ops.conv2d_unpack_weight(gp, dw, CoutPad=cpad)
     assert (dw.cpu().double() - wr.grad).abs().max().item() <= 1e-4 * wr.grad.abs().max().item() + 1e-6
+
+
+def _pack_index_reference(w, cout_pad):
+    """[chunk = (32-channel slice, kh, kw)][CoutPad][32] restated with torch indexing (dim_conv2d_pack_weight's documented layout)"""
+    cout, cin, kh, kw = w.shape
+    wp = torch.zeros((cin // 32, kh * kw, cout_pad, 32), dtype=w.dtype)
+    wp[:, :, :cout, :] = w.reshape(cout, cin // 32, 32, kh * kw).permute(1, 3, 0, 2)
+    return wp.reshape(-1)
+
+
+def test_weight_packers_tiled_and_bf16(ops):
+    """The LDS-tiled layout converters: the forward packer against an index restatement of its layout, pack -> unpack round trips
+    (scale / accumulate), and every bf16 packer bit-for-bit against to_bf16 of its f32 twin (conv, padded, stride-1 / stride-2 input
+    gradient incl. 5x5, deconvolution with a channel count that is not a multiple of 32, fc6's input gradient)."""
+    g = torch.Generator().manual_seed(11)
+    for cout, cin, k in ((64, 32, 3), (256, 128, 5), (96, 64, 1), (128, 96, 4)):
+        w = torch.randn(cout, cin, k, k, generator=g)
+        wd = w.to(DEV)
+        wp = ops.conv2d_pack_weight(wd)
+        assert torch.equal(wp.cpu(), _pack_index_reference(w, cout))
+        assert torch.equal(ops.conv2d_pack_weight(wd, as_bf16=True), ops.to_bf16(wp))
+        pad = ops.pad64(cout + 2)
+        wpp = ops.conv2d_pack_weight_padded(wd, pad)
+        assert torch.equal(wpp.cpu(), _pack_index_reference(w, pad))
+        assert torch.equal(ops.conv2d_pack_weight_padded(wd, pad, as_bf16=True), ops.to_bf16(wpp))
+        back = torch.full_like(wd, 3.0)
+        ops.conv2d_unpack_weight(wpp, back, CoutPad=pad)
+        assert torch.equal(back, wd)
+        ops.conv2d_unpack_weight(wpp, back, CoutPad=pad, scale=0.5, accumulate=True)
+        assert torch.equal(back, wd + 0.5 * wd)
+        for s, p in ((1, k // 2), (2, k // 2)):
+            if k == 1 and s == 2:
+                continue
+            assert torch.equal(ops.conv2d_dgrad_pack_weight(wd, s, p, as_bf16=True), ops.to_bf16(ops.conv2d_dgrad_pack_weight(wd, s, p)))
+    for cin, cout in ((1026, 64), (64, 256)):
+        wd = torch.randn(cin, cout, 4, 4, generator=g).to(DEV)
+        assert torch.equal(ops.deconv4x4s2_pack_weight(wd, as_bf16=True), ops.to_bf16(ops.deconv4x4s2_pack_weight(wd)))
+    wf = torch.randn(64, 64 * 3 * 5, generator=g).to(DEV)
+    assert torch.equal(ops.fc_dgrad_pack_weight(wf, 64, 3, 5, as_bf16=True), ops.to_bf16(ops.fc_dgrad_pack_weight(wf, 64, 3, 5)))
+    back = torch.empty_like(wf)
+    ops.fc_unpack_weight(ops.fc_pack_weight(wf, 64, 3, 5), back, 64, 3, 5)
+    assert torch.equal(back, wf)
