@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void conv_small_cout_dgrad_kernel(const float*
 }
 
 // small-Cout conv backward, weights: dW[co][ci][kh][kw] = sum_pix dY[pix][co] * X[pix + tap][ci]; db[co] = sum_pix dY[pix][co]
-//   = sum over X pixels q of X[q][ci] * dY[q - tap][co]: each X row is read ONCE per workgroup (coalesced over ci) and scattered to
+//   = sum over X pixels q of X[q][ci] * dY[q - tap][co]: each X row is read ONCE per wave (coalesced over ci) and feeds
 //   the KH*KW*Cout accumulators of the thread; the dY values of the q - tap neighbours are wave-uniform scalars.
 // stage 1: grid (pixel chunks, ceil(Cin/256)); partial[chunk][co][tap][ci] (deterministic, no atomics);  stage 2 sums the chunks.
 template <int COUT, int TAPS>
@@ -318,30 +318,43 @@ __global__ __launch_bounds__(64) void conv_small_cout_wgrad_partial_kernel(const
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int c = 0; c < COUT; ++c) acc[t][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // dW[tap] pairs output pixel p with input pixel p + (tap - pad): walk the output pixels of the chunk and read X at the 9 shifted
-  // rows (re-read from L1 / L2 within the chunk, never from HBM); the dY values and the border tests are wave-uniform
+  // dW[tap] pairs input pixel q with output pixel q - (tap - pad): walk the INPUT pixels of the chunk, one 16-byte load each, and feed
+  // all TAPS x COUT accumulators from it; the dY values of the neighbours and the border tests are wave-uniform (scalar loads, selected
+  // branch-free so that the loads of the following pixels are not held behind a branch).  The first version walked output pixels and
+  // loaded X once per tap behind a border branch: 576 dependent L2 round trips per wave, 173 us for the 770-channel head.
+  // the dY window of the chunk -- output pixels p0 - mhi .. p1 - 1 + mlo -- goes to LDS first (scalar loads per pixel and tap left
+  // the wave waiting on the scalar cache five times per pixel: 0.55 us per pixel)
+  extern __shared__ float s_dy[];
+  const int mlo = pad * W + pad, mhi = (KH - 1 - pad) * W + (KW - 1 - pad);
+  const int wn = (int)(p1 - p0) + mlo + mhi;
+  for (int i = threadIdx.x; i < wn * COUT; i += 64) {
+    const long pp = p0 - mhi + i / COUT;
+    s_dy[i] = (pp >= 0 && pp < P) ? dy[pp * COUT + i % COUT] : 0.f;
+  }
+  __syncthreads();
   if (ci < CinP) {
-    for (long p = p0; p < p1; ++p) {
-      const int xx = (int)(p % W);
-      const int y = (int)((p / W) % H);
-      float g[COUT];
-#pragma unroll
-      for (int c = 0; c < COUT; ++c) g[c] = dy[p * COUT + c];
+    int xx = (int)(p0 % W), y = (int)((p0 / W) % H);
+#pragma unroll 4
+    for (long q = p0; q < p1; ++q) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + q * in_cstride + ci);
+      const int o0 = (int)(q - p0) + mhi;
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int kh = t / KW, kw = t - kh * KW;
-        const int iy = y - pad + kh, ix = xx - pad + kw;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-          const float4 xv = *reinterpret_cast<const float4*>(x + (p + (long)(kh - pad) * W + (kw - pad)) * in_cstride + ci);
+        const int oy = y + pad - kh, ox = xx + pad - kw;
+        const bool ok = (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
+        const int o = o0 + (pad - kh) * W + (pad - kw);
 #pragma unroll
-          for (int c = 0; c < COUT; ++c) {
-            acc[t][c].x = fmaf(g[c], xv.x, acc[t][c].x);
-            acc[t][c].y = fmaf(g[c], xv.y, acc[t][c].y);
-            acc[t][c].z = fmaf(g[c], xv.z, acc[t][c].z);
-            acc[t][c].w = fmaf(g[c], xv.w, acc[t][c].w);
-          }
+        for (int c = 0; c < COUT; ++c) {
+          const float gl = s_dy[o * COUT + c];
+          const float g = ok ? gl : 0.f;
+          acc[t][c].x = fmaf(g, xv.x, acc[t][c].x);
+          acc[t][c].y = fmaf(g, xv.y, acc[t][c].y);
+          acc[t][c].z = fmaf(g, xv.z, acc[t][c].z);
+          acc[t][c].w = fmaf(g, xv.w, acc[t][c].w);
         }
       }
+      if (++xx == W) { xx = 0; if (++y == H) y = 0; }
     }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
@@ -356,18 +369,25 @@ __global__ __launch_bounds__(64) void conv_small_cout_wgrad_partial_kernel(const
   }
 }
 
-// workgroup = 64 outputs x 4 chunk groups (the chunk count is in the hundreds: a serial loop per output took 100 us)
+// workgroup = 32 outputs x 8 chunk groups, four loads in flight per thread (the chunk count is in the hundreds: a serial loop per
+// output took 100 us, 64 outputs x 4 groups without unrolling 40 us); fixed summation order: per group in chunk order, then a tree
 __global__ __launch_bounds__(256) void conv_small_cout_wgrad_final_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b,
                                                                           float* __restrict__ dw, float* __restrict__ db, int nchunk, int Cin,
                                                                           int CinP, int Cout, int KH, int KW) {
-  const int ol = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const long idx = (long)blockIdx.x * 64 + ol;
+  const int ol = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const long idx = (long)blockIdx.x * 32 + ol;
   const long per = (long)Cout * KH * KW * Cin, perP = (long)Cout * KH * KW * CinP;   // partial rows are CinP (multiple of 4) long
-  __shared__ float red[4][64];
+  __shared__ float red[8][32];
   float s = 0.f;
   if (idx < per) {
     const long pidx = (idx / Cin) * CinP + idx % Cin;
-    for (int c = grp; c < nchunk; c += 4) s += partial[(long)c * perP + pidx];
+    int c = grp;
+    for (; c + 24 < nchunk; c += 32) {
+      const float v0 = partial[(long)c * perP + pidx], v1 = partial[(long)(c + 8) * perP + pidx], v2 = partial[(long)(c + 16) * perP + pidx],
+                  v3 = partial[(long)(c + 24) * perP + pidx];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; c < nchunk; c += 8) s += partial[(long)c * perP + pidx];
   }
   red[grp][ol] = s;
   __syncthreads();
@@ -376,7 +396,8 @@ __global__ __launch_bounds__(256) void conv_small_cout_wgrad_final_kernel(const 
     const long t = idx / Cin;
     const int tap = (int)(t % (KH * KW));
     const int co = (int)(t / (KH * KW));
-    dw[((long)co * Cin + ci) * KH * KW + tap] = (red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol]);
+    dw[((long)co * Cin + ci) * KH * KW + tap] =
+        ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol])) + ((red[4][ol] + red[5][ol]) + (red[6][ol] + red[7][ol]));
   }
   if (blockIdx.x == 0 && db && threadIdx.x < Cout) {
     float sb = 0.f;
@@ -658,14 +679,16 @@ int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw
                        dx_cstride, Cout, KH, KW, pad, accumulate_dx);
   }
   dim3 grid(nchunk, ceil_div(CinPad, 256));
+  const size_t dy_lds = (size_t)(kSmallCoutChunkPx + (KH - 1) * W + (KW - 1)) * Cout * 4;  // the chunk's dY window
+  DIM_REQUIRE(dy_lds <= 65536, "small-Cout backward: image too wide for the dY window in LDS (W = %d)", W);
   if (Cout == 2)
-    hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<2, 9>), grid, dim3(64), 0, st, x, dy, partial, partial_b, N, H, W, Cin, CinPad,
+    hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<2, 9>), grid, dim3(64), dy_lds, st, x, dy, partial, partial_b, N, H, W, Cin, CinPad,
                        in_cstride, KH, KW, pad, kSmallCoutChunkPx);
   else
-    hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<1, 9>), grid, dim3(64), 0, st, x, dy, partial, partial_b, N, H, W, Cin, CinPad,
+    hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<1, 9>), grid, dim3(64), dy_lds, st, x, dy, partial, partial_b, N, H, W, Cin, CinPad,
                        in_cstride, KH, KW, pad, kSmallCoutChunkPx);
   long per = (long)Cout * KH * KW * Cin;
-  hipLaunchKernelGGL(conv_small_cout_wgrad_final_kernel, dim3(ceil_div(per, 64)), dim3(256), 0, st, partial, partial_b, dw_oihw, db,
+  hipLaunchKernelGGL(conv_small_cout_wgrad_final_kernel, dim3(ceil_div(per, 32)), dim3(256), 0, st, partial, partial_b, dw_oihw, db,
                      nchunk, Cin, CinPad, Cout, KH, KW);
   return check_launch("conv_small_cout_bwd");
 }
