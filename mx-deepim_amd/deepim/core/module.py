@@ -358,7 +358,7 @@ class MutableModule(object):
                     ops.conv2d_dgrad_winograd5x5s2(dy, cout, self.wino5_dgrad[name], self.dacts[prev[name]], cin[name], workspace=self.wino_ws)
                 else:
                     # bf16: operand-traffic bound, so the widest tile the channel count allows (dX channels are the GEMM's N)
-                    dg_tile = bf16_tile(ops.pad64(cin[name])) if self.bf16 else 3
+                    dg_tile = self._bf16_gemm_tile(dy.shape[0] * dy.shape[1] * dy.shape[2], ops.pad64(cin[name])) if self.bf16 else 3
                     if (dg_tile != 3 and s == 1 and k == 3 and dy.shape[1] * dy.shape[2] >= 1200 and os.environ.get("DIM_BF16_HALO", "1") != "0"):
                         dg_tile = 7   # stride-1 input gradient of a large map: LDS-halo kernel
                     if self.bf16 and BF16_PATCH and k in (3, 5) and dy.shape[1] * dy.shape[2] >= 1200:
@@ -427,7 +427,18 @@ class MutableModule(object):
         ops.bias_grad(dz, cout, g[name + "_bias"], dz_coff=dz_coff, workspace=self.bias_ws)
         # data gradient: the same convolution applied to dz
         ops.conv2d_fwd_ex(dz, dz_coff, cout, self.dgrad_packed[name], None, dx, 0, x_cpad, 4, 4, 2, 1, Ho=h, Wo=wd, accumulate=False,
-                          tile=bf16_tile(x_cpad) if self.bf16 else 3)
+                          tile=self._bf16_gemm_tile(N * h * wd, x_cpad) if self.bf16 else 3)
+
+    @staticmethod
+    def _bf16_gemm_tile(rows, cols):
+        """workgroup tile of a bf16 input-gradient GEMM with `rows` output pixels (per launch: a stride-2 gradient runs one launch per
+        input phase, each with as many rows as dY has pixels) x `cols` channels: the wide tile only when it fills the chip -- conv6_1's
+        gradient is 10 x 8 tiles of 128 x 128 with K = 9216, 80 workgroups on 256 CUs (149 us); 64 x 64 tiles give 320.
+        DIM_BF16_SMALL_TILE=0: the wide tile wherever the channel count allows."""
+        t = bf16_tile(cols)
+        if t != 3 and os.environ.get("DIM_BF16_SMALL_TILE", "1") != "0" and -(-rows // 128) * (cols // 128) < 200:
+            return 3
+        return t
 
     def forward_backward(self, batch):
         out = self.forward(batch)

@@ -38,12 +38,12 @@ WINO_M_DEFAULT = {}
 # workgroup tile of the wide-Cout bf16 layers: 4 = 128 x 128 on 8 waves (64 x 32 each), 1 = 128 x 128 on 4 waves (64 x 64 each)
 BF16_BIG_TILE = int(os.environ.get("DIM_BF16_BIG_TILE", "4"))
 # the stride-1 patch kernel (tile 9) for the 3x3 / stride-1 layers, their input gradients and the phases of the stride-2 input gradients
-BF16_PATCH = os.environ.get("DIM_BF16_PATCH", "1") != "0"
-# DIM_BF16_PATCH=2 also puts the stride-2 forward layers on it (8 x 16 pixel blocks).  Measured at B = 16: conv2 251 vs 240 us on the
-# gathered-tap kernel, conv3 195 vs 217, conv4 97 vs 95 -- a wave of 64 pixels x 64 channels loads 4 KB of weight fragments per 8 MFMAs,
-# which is the 64 B/clk a CU's vector L1 delivers; the stride-1 blocks (128 pixels per wave) need half of that.  Off by default.
-BF16_PATCH_S2 = os.environ.get("DIM_BF16_PATCH", "1") == "2"
-
+BF16_PATCH = os.environ.get("DIM_BF16_PATCH", "") != "0"
+# ... and for the stride-2 forward layers (8 x 16 pixel blocks).  Measured at B = 16 against the gathered-tap kernel: conv2 (5x5) 247 vs
+# 249 us, conv3 (5x5) 191 vs 223, conv4 (3x3) 95 vs 95 -- a wave of 64 pixels x 64 channels loads 4 KB of weight fragments per 8 MFMAs,
+# which is the 64 B/clk a CU's vector L1 delivers; the stride-1 blocks (128 pixels per wave) need half of that.  Default: the 5x5 layers;
+# DIM_BF16_PATCH=1: stride-1 layers only, =2: every stride-2 layer.
+BF16_PATCH_S2_KERNELS = {"": (5,), "1": (), "2": (3, 5)}.get(os.environ.get("DIM_BF16_PATCH", ""), ())
 
 def bf16_tile(cout):
     """workgroup tile of a bf16 layer with `cout` GEMM columns: 8 = 128 x 256 (only when DIM_BF16_BIG_TILE=8), 4 / 1 = 128 x 128, 3 = 64 x 64"""
@@ -251,7 +251,7 @@ class FlowNetHip(object):
                 if c % 32 == 0 and cout % 128 == 0 and h * w >= 1200 and ((halo == "1" and k == 3 and s == 1) or (halo == "2" and k in (3, 5))):
                     self.conv_plan[name] = (7, 1)
                 if BF16_PATCH and c % 32 == 0 and cout % 128 == 0 and h * w >= 1200 and (
-                        (k == 3 and s == 1) or (BF16_PATCH_S2 and s == 2 and k in (3, 5))):
+                        (k == 3 and s == 1) or (s == 2 and k in BF16_PATCH_S2_KERNELS)):
                     self.conv_plan[name] = (9, 1)   # patch kernel (conv.hip conv_bf16_patch_kernel): 3x3 / stride 1, 3x3 and 5x5 / stride 2
                 c = cout
         if conv_plan:

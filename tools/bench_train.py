@@ -38,7 +38,7 @@ res["batch_updater_ms"] = timed(lambda: upd.forward(batch, preds))
 t = timed(lambda: (mod.forward_backward(batch), mod.update(1e-4)))
 res["train_iteration_ms"] = t
 res["pair_iterations_per_s"] = B / t * 1e3
-res["config"] = "LINEMOD 'ape' training graph (encoder + decoder + flow / mask / point-matching losses), SGD momentum, fp32, 1x MI355X, synthetic pairs"
+res["config"] = "LINEMOD 'ape' training graph (encoder + decoder + flow / mask / point-matching losses), SGD momentum, %s, 1x MI355X, synthetic pairs" % DTYPE
 for k, v in res.items():
     print(k, ("%.2f" % v) if isinstance(v, float) else v)
 print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res.items()}))
