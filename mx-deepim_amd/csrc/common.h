@@ -197,9 +197,9 @@ inline int wtile_group(int count, int Q, int outer = 1) {
   int best = 0;
   for (int g = 1; g <= 8; g <<= 1) {
     if (count % g || wtile_lds_bytes(g, Q) > 65536) break;
-    if (best == 0 || (long)outer * (count / g) >= 2048) best = g;
+    if (best == 0 || (long)outer * (count / g) >= 2048 || count / best > 65535) best = g;
   }
-  return best;
+  return (best && count / best <= 65535 && outer <= 65535) ? best : 0;  // grid.y = count / G
 }
 template <bool TO_PACKED, typename PT>
 inline void wtile_launch(const WTileArgs& a, int gx, int gy, hipStream_t st) {
