@@ -44,6 +44,10 @@ int dim_device_info(char* name, int n);
  * hipMemcpyAsync / hipMemsetAsync inside captured hipGraphs: a captured memset node was observed to overlap the kernel
  * after it on replay (ROCm 7.2), so no copy / fill node is left in the graph (deepim/core/tester.py Refiner._loop). */
 int dim_copy_words(void* dst, const void* src, long nwords, void* stream);
+/* The same for `rows` runs of `width_words` words with different pitches on the two sides: a channel window [:, a:b] of an
+ * (O, I, kh, kw) weight is one run of (b - a) kh kw words per output channel (the training executor's first layer when the network
+ * input has 6 or 10 channels: reference get_convs, deepim/symbols/deepIM_flownet.py:33-66). */
+int dim_copy_rows(void* dst, long dst_pitch_words, const void* src, long src_pitch_words, long rows, long width_words, void* stream);
 
 /* ---------------------------------------------------------------- zoom ops
  * bbox of {x > thr} (mode 0, C==1) or {sum_c (x_c + means3[c]) > thr} (mode 1, C==3):

@@ -27,9 +27,27 @@ __global__ __launch_bounds__(256) void copy_words_kernel(unsigned* __restrict__ 
   }
 }
 
+// rows x width words between arrays with different row pitches (a channel window of an (O, I, kh, kw) weight: width = channels * kh * kw)
+__global__ void copy_rows_kernel(unsigned* __restrict__ dst, long dst_pitch, const unsigned* __restrict__ src, long src_pitch, long rows, long width) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * width) return;
+  const long r = i / width, c = i - r * width;
+  dst[r * dst_pitch + c] = src[r * src_pitch + c];
+}
+
 }  // namespace dim
 
 extern "C" {
+
+int dim_copy_rows(void* dst, long dst_pitch_words, const void* src, long src_pitch_words, long rows, long width_words, void* stream) {
+  if (rows == 0 || width_words == 0) return DIM_OK;
+  DIM_REQUIRE(dst && src, "null pointer");
+  DIM_REQUIRE(rows > 0 && width_words > 0 && dst_pitch_words >= width_words && src_pitch_words >= width_words, "bad geometry");
+  hipLaunchKernelGGL(dim::copy_rows_kernel, dim3(dim::ceil_div(rows * width_words, 256)), dim3(256), 0, dim::as_stream(stream),
+                     reinterpret_cast<unsigned*>(dst), dst_pitch_words, reinterpret_cast<const unsigned*>(src), src_pitch_words, rows,
+                     width_words);
+  return dim::check_launch("copy_rows");
+}
 
 int dim_copy_words(void* dst, const void* src, long nwords, void* stream) {
   if (nwords == 0) return DIM_OK;

@@ -48,9 +48,6 @@ class MutableModule(object):
         cfg = config
         assert compute_dtype in ("f32", "bf16"), compute_dtype
         self.bf16 = compute_dtype == "bf16"
-        if cfg.network.INPUT_DEPTH or not cfg.network.INPUT_MASK:
-            raise NotImplementedError("the HIP training graph feeds the shipped first-layer input (images + masks, 8 channels); the other "
-                                      "arities (images only, depth planes, 10 channels) exist in the test graph only (FlowNetHip)")
         if not (cfg.network.PRED_FLOW and cfg.network.PRED_MASK):
             raise NotImplementedError("the HIP training graph always carries the decoder with both heads (PRED_FLOW, PRED_MASK: every shipped "
                                       "configuration); graphs without one of them are not wired")
@@ -129,6 +126,10 @@ class MutableModule(object):
         d, net = self.device, self.net
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=d)  # noqa: E731
         self.dacts = {name: torch.empty_like(net.acts[name]) for name, *_ in ENCODER}
+        # flow_conv1 with 6 or 10 input channels: 8-lane images of the master weight / of its gradient (spare lanes stay zero)
+        nl = 0 if net.cin == 8 else (2 if net.input_mode == 3 else 1)
+        self.w1_lanes = [z(64, 8, 7, 7) for _ in range(nl)]
+        self.g1_lanes = [z(64, 8, 7, 7) for _ in range(nl)]
         self.dconcat3 = z(B, 30, 40, ops.pad64(770))
         self.dconcat2 = z(B, 15, 20, ops.pad64(1026))
         self.dflow4, self.dmask4 = z(B, 30, 40, 2), z(B, 30, 40, 1)
@@ -211,6 +212,13 @@ class MutableModule(object):
                     net.wino[name] = ops.winograd_pack_weight(w[name + "_weight"], m=net.wino_m[name])
                 elif name in net.wino5:  # 5x5 / stride-2 layers: phase-image Winograd forward (backward: wino5_dgrad below)
                     net.wino5[name] = ops.winograd5x5s2_pack_weight(w[name + "_weight"])
+                elif name == "flow_conv1" and net.cin != 8:
+                    # 6 input channels (no masks in the Concat) or 10 (depth planes and masks): the kernels take 8-lane groups
+                    ops.copy_channels(self.w1_lanes[0], 0, w[name + "_weight"], 0, min(net.cin, 8))
+                    net.packed[name] = net.pack_conv(self.w1_lanes[0])
+                    if net.input_mode == 3:
+                        ops.copy_channels(self.w1_lanes[1], 0, w[name + "_weight"], 8, 2)
+                        net.packed["flow_conv1_masks"] = net.pack_conv(self.w1_lanes[1])
                 else:
                     net.packed[name] = net.pack_conv(w[name + "_weight"])
             if name in net.wino:
@@ -239,8 +247,7 @@ class MutableModule(object):
         ops.mask_bbox(batch["mask_gt_observed"], 0.3, out=net.bbox_obs)
         ops.mask_bbox(batch["mask_rendered"], 0.2, out=net.bbox_ren)
         ops.zoom_factor(net.bbox_obs, net.bbox_ren, batch["src_pose"], net.K, H, W, out=net.zoom_factor, status=net.status)
-        ops.zoom_net_input(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"], net.zoom_factor,
-                           net.plane_means, X=net.X)
+        net.net_input(batch)   # images (+ depth planes) (+ masks): the Concat of get_convs (:33-66) for this configuration's arity
         ops.zoom_planes(batch["mask_gt_observed"], net.zoom_factor, post=1, out=self.zoom_mask_gt)
         ops.zoom_planes(batch["flow"], net.zoom_factor, scale_mode=1, out=self.zoom_flow_lab)          # ZoomFlow :689-698
         ops.zoom_planes(batch["flow_weights"], net.zoom_factor, post=2, out=self.zoom_flow_w)
@@ -340,6 +347,13 @@ class MutableModule(object):
             if name in self.wino_wgrad:
                 S, sp = self.wino_wgrad[name]
                 ops.conv2d_wgrad_winograd(x, cin[name], dy, cout, g[name + "_weight"], S=S, splits=sp, workspace=self.wino_wgrad_ws)
+            elif name == "flow_conv1" and net.cin != 8:
+                # one weight gradient per 8-lane input group, each copied into its channel window of the (64, cin, 7, 7) gradient
+                for lane, xin, c0, nch in ((0, net.X, 0, min(net.cin, 8)),) + (((1, net.X2, 8, 2),) if net.input_mode == 3 else ()):
+                    ops.conv2d_wgrad(xin, 8, dy, cout, k, k, s, p, self.gpack, splits=self.wgrad_splits[name], workspace=self.ws,
+                                     bf16_mfma=self.bf16)
+                    ops.conv2d_unpack_weight(self.gpack, self.g1_lanes[lane])
+                    ops.copy_channels(g[name + "_weight"], c0, self.g1_lanes[lane], 0, nch)
             else:
                 ops.conv2d_wgrad(x, cin[name], dy, cout, k, k, s, p, self.gpack, splits=self.wgrad_splits[name], workspace=self.ws,
                                  bf16_mfma=self.bf16)

@@ -367,6 +367,11 @@ class FlowNetHip(object):
             bbox_ren = ops.mask_bbox(batch["image_rendered"], 0.01, mode=1, means3=self.plane_means, out=self.bbox_ren)
         ops.zoom_factor(bbox_obs, bbox_ren, batch["src_pose"] if src_pose is None else src_pose, self.K, self.H, self.W,
                         out=self.zoom_factor, status=self.status if status is None else status)
+        return self.net_input(batch, nchw_out=nchw_out)
+
+    def net_input(self, batch, nchw_out=None):
+        """the first layer's input from the blobs and self.zoom_factor: ZoomImageWithFactor (+ ZoomDepth) (+ the zoomed masks) in the
+        Concat order of get_convs (reference :33-66), as one or two 8-lane NHWC tensors (see input_mode)"""
         if self.input_mode == 0:
             ops.zoom_net_input(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"],
                                self.zoom_factor, self.plane_means, X=self.X, nchw_out=nchw_out)

@@ -93,6 +93,7 @@ SIGNATURES = {
     "dim_fc_fwd": (I, [P, P, P, P, P, I, I, I, I, I, F, P]),
     "dim_conv2d_fwd_winograd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, P, P]),
     "dim_copy_words": (I, [P, P, L, P]),
+    "dim_copy_rows": (I, [P, L, P, L, L, L, P]),
     "dim_sgd_momentum": (I, [P, P, P, L, F, F, F, F, P]),
     "dim_adam": (I, [P, P, P, P, L, F, F, F, F, F, F, P]),
     "dim_deconv4x4s2_packed_weight_floats": (L, [I, I]),

@@ -237,6 +237,19 @@ def copy(dst, src):
     return dst
 
 
+def copy_channels(dst_oihw, dst_c0, src_oihw, src_c0, nch):
+    """dst[:, dst_c0:dst_c0+nch] <- src[:, src_c0:src_c0+nch] for two contiguous (O, I, kh, kw) f32 weights with the same O, kh, kw
+    (dim_copy_rows: one run of nch*kh*kw floats per output channel)"""
+    O, Id, kh, kw = dst_oihw.shape
+    Os, Is = src_oihw.shape[:2]
+    assert O == Os and tuple(src_oihw.shape[2:]) == (kh, kw) and dst_oihw.is_contiguous() and src_oihw.is_contiguous()
+    assert 0 <= dst_c0 and dst_c0 + nch <= Id and 0 <= src_c0 and src_c0 + nch <= Is
+    t = kh * kw
+    check(lib().dim_copy_rows(dptr(dst_oihw, f32) + 4 * dst_c0 * t, Id * t, dptr(src_oihw, f32) + 4 * src_c0 * t, Is * t, O, nch * t,
+                              current_stream()))
+    return dst_oihw
+
+
 def winograd_pack_weight(w_oihw, m=2):
     """(Cout,Cin,3,3) -> the (m+2)^2 transformed 1x1 weight sets of the Winograd F(m x m, 3x3) path, m = 2 or 4"""
     Cout, Cin, KH, KW = w_oihw.shape

@@ -1,7 +1,8 @@
 """Training graph + gradients + SGD, torch-CPU autograd restatement (oracle; test-only).
 
 Restates /root/reference/deepim/symbols/deepIM_flownet.py get_train_symbol :562-762 and get_loss :303-560 for the shipped
-configuration (INPUT_MASK, PRED_MASK, PRED_FLOW, SE3_PM_LOSS type L1, no SE3_DIST_LOSS), with the MXNet-internal gradient
+configuration (INPUT_MASK, PRED_MASK, PRED_FLOW, SE3_PM_LOSS type L1, no SE3_DIST_LOSS) and its variants (first-layer input without
+masks / with depth planes :33-66, SE3_DIST_LOSS, the other point-matching / translation loss types), with the MXNet-internal gradient
 conventions listed in SURVEY.md A11 ("parity unpinned": MXNet is absent):
   MakeLoss backward = grad_scale * dloss/dx; LogisticRegressionOutput backward = grad_scale/num_output * (sigmoid(x) - y);
   gradients summed over the batch; Transform3D / ZoomTrans use the reference's HAND-WRITTEN backward (oracle.transform3d,
@@ -62,7 +63,13 @@ def loss_and_grads(params, batch, cfg, K, dtype=torch.float64):
     zmo, zmg, zmr, zf = ozoom.zoom_mask(batch["mask_observed"], batch["mask_gt_observed"], batch["mask_rendered"], batch["src_pose"], K, H, W)
     zio, zir = ozoom.zoom_image_with_factor(zf, batch["image_observed"], batch["image_rendered"], cfg.network.PIXEL_MEANS, H, W)
     zflow, zfw = ozoom.zoom_flow(zf, batch["flow"], batch["flow_weights"], b_inv_zoom=False, H=H, W=W)
-    data = oflow.network_input(zio, zir, zmo, zmr)
+    # the Concat of get_convs (deepIM_flownet.py:33-66) for this configuration: the zoom window always comes from the masks in
+    # training (:589-612, PRED_MASK), the masks are network inputs only with INPUT_MASK, the zoomed depth planes with INPUT_DEPTH (:670-683)
+    with_masks = bool(cfg.network.INPUT_MASK and cfg.network.PRED_MASK)
+    zdo = zdr = None
+    if cfg.network.INPUT_DEPTH:
+        zdo, zdr = ozoom.zoom_depth(zf, batch["depth_observed"], batch["depth_rendered"], H, W)
+    data = oflow.network_input(zio, zir, zmo if with_masks else None, zmr if with_masks else None, zdo, zdr)
     P = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype).requires_grad_(True) for k, v in params.items()}
     x = torch.from_numpy(data).to(dtype)
     feats = {}

@@ -253,3 +253,59 @@ def test_pose_loss_variants(setup, variant):
         assert err <= (1e-4 if exact_path else 5e-2) * scale + 1e-9, (variant, k, err, scale)
     for k in ("rot_weight", "trans_weight", "fc7_weight"):
         assert np.abs(ref_g[k]).max() > 0, k   # the variant really drives the pose head
+
+
+@pytest.mark.parametrize("input_mask,input_depth", [(False, False), (False, True), (True, True)])
+def test_train_input_arities(setup, input_mask, input_depth):
+    """The first-layer input arities of get_convs (reference deepIM_flownet.py:33-66) in the TRAINING executor: 6 channels (images only:
+    INPUT_MASK off, the zoom window still comes from the masks, :589-612), 8 (images + depth planes), 10 (+ masks, two 8-lane groups).
+    Forward outputs and every gradient -- flow_conv1's in its (64, cin, 7, 7) layout -- against torch autograd of the oracle; one SGD
+    step + repack gives the same forward as a fresh executor built from the updated parameters."""
+    from deepim.core.module import MutableModule
+    from deepim.symbols.deepIM_flownet import deepIM_flownet, input_channels
+
+    cfg0, params0, scene = setup
+    cfg = make_train_config()
+    cfg.network.INPUT_MASK, cfg.network.INPUT_DEPTH = input_mask, input_depth
+    cin = input_channels(cfg)
+    assert cin == {(False, False): 6, (False, True): 8, (True, True): 10}[(input_mask, input_depth)]
+    rng = np.random.RandomState(7)
+    params = dict(params0)
+    w1 = params0["flow_conv1_weight"]
+    params["flow_conv1_weight"] = (rng.randn(64, cin, 7, 7) * float(w1.std())).astype(np.float32)
+    B = 2
+    blobs = dict(scene["blobs"])
+    if input_depth:
+        blobs["depth_observed"] = (rng.rand(B, 1, 480, 640) * 300).astype(np.float32)
+        blobs["depth_rendered"] = (rng.rand(B, 1, 480, 640) * 300).astype(np.float32)
+    mod = MutableModule(cfg, params, B)
+    assert tuple(mod.w["flow_conv1_weight"].shape) == (64, cin, 7, 7)
+    batch = {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in blobs.items()}
+    out = mod.forward_backward(batch)
+    ref_out, ref_g = otrain.loss_and_grads(params, blobs, cfg, scene["K"])
+    np.testing.assert_allclose(out["rot_est_norm"].cpu().numpy(), ref_out["rot_est_norm"], atol=1e-5)
+    np.testing.assert_allclose(out["trans_est"].cpu().numpy(), ref_out["trans_est"], atol=1e-5)
+    np.testing.assert_allclose(out["mask_logit"].cpu().numpy(), ref_out["mask_logit"], atol=1e-4)
+    got = mod.get_grads()
+    for k, rg in ref_g.items():
+        scale = np.abs(rg).max()
+        l2 = np.linalg.norm((got[k] - rg).ravel()) / (np.linalg.norm(rg.ravel()) + 1e-30)
+        exact_path = k.startswith(("fc", "rot", "trans", "Convolution", "deconv4", "upsample_flow", "mask_conv3"))
+        # same bars as test_train_step_gradients_and_sgd (LeakyReLU' flips of pre-activations within f32 noise of zero below the decoder)
+        err = np.abs(got[k] - rg).max()
+        print("grad {:28s} max|g| {:.3e}  max err {:.3e}  l2 {:.2e}".format(k, scale, err, l2))
+        # (a single LeakyReLU' flip in deconv5's output moves one entry of deconv4's gradient by 1.05e-4 of the largest, of
+        # Convolution1's bias gradient by 1.3e-3: max bar 5e-3)
+        assert err <= (5e-3 if exact_path else 5e-2) * scale + 1e-9, (k, float(err), float(scale))
+        # "exact" = few LeakyReLU' sites upstream, not none: Convolution1's gradient passes deconv4's activation, and with the random
+        # first-layer weights of this test one flip there shows as 1.2e-3 L2 (10-channel case); 1e-4 holds for the shipped weights
+        assert l2 <= (2e-3 if exact_path else 1e-2), (k, l2)
+    g1 = got["flow_conv1_weight"]
+    assert g1.shape == (64, cin, 7, 7) and all(np.abs(g1[:, c]).max() > 0 for c in range(cin))   # every input channel got its gradient
+    mod.update(cfg.TRAIN.lr)
+    new = mod.get_params()
+    assert np.abs(new["flow_conv1_weight"] - params["flow_conv1_weight"]).max() > 0
+    out2 = mod.forward(batch)
+    out3 = MutableModule(cfg, new, B).forward(batch)
+    np.testing.assert_array_equal(out2["rot_est_norm"].cpu().numpy(), out3["rot_est_norm"].cpu().numpy())
+    np.testing.assert_allclose(out2["flow_est_crop"].cpu().numpy(), out3["flow_est_crop"].cpu().numpy(), atol=1e-6)
