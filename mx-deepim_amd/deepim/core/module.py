@@ -48,9 +48,9 @@ class MutableModule(object):
         cfg = config
         assert compute_dtype in ("f32", "bf16"), compute_dtype
         self.bf16 = compute_dtype == "bf16"
-        if not (cfg.network.PRED_FLOW and cfg.network.PRED_MASK):
-            raise NotImplementedError("the HIP training graph always carries the decoder with both heads (PRED_FLOW, PRED_MASK: every shipped "
-                                      "configuration); graphs without one of them are not wired")
+        # heads of this configuration (every shipped one has both): the decoder exists when either does (deepIM_flownet.py:213)
+        self.pred_flow, self.pred_mask = bool(cfg.network.PRED_FLOW), bool(cfg.network.PRED_MASK)
+        self.has_decoder = self.pred_flow or self.pred_mask
         if not (cfg.train_iter.SE3_PM_LOSS or cfg.train_iter.SE3_DIST_LOSS):
             raise Exception("no pose loss: set train_iter.SE3_PM_LOSS and / or train_iter.SE3_DIST_LOSS")
         for what, kind in (("SE3_PM_LOSS_TYPE", cfg.train_iter.SE3_PM_LOSS_TYPE), ("TRANS_LOSS_TYPE", cfg.train_iter.TRANS_LOSS_TYPE)):
@@ -229,43 +229,60 @@ class MutableModule(object):
                 self.dgrad_packed[name] = ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p, as_bf16=self.bf16)
         if forward:
             net.packed["fc6"] = ops.fc_pack_weight(w["fc6_weight"], 1024, 8, 10)
-            net.packed["deconv5"] = net.pack_deconv(w["deconv5_weight"])
-            net.packed["deconv4"] = net.pack_deconv(w["deconv4_weight"])
+            if self.has_decoder:
+                net.packed["deconv5"] = net.pack_deconv(w["deconv5_weight"])
+                net.packed["deconv4"] = net.pack_deconv(w["deconv4_weight"])
             for n in ("Convolution1", "Convolution2", "Convolution3", "mask_conv3"):
-                net.packed[n] = ops.conv_small_cout_pack_weight(w[n + "_weight"])
+                if n + "_weight" in w:
+                    net.packed[n] = ops.conv_small_cout_pack_weight(w[n + "_weight"])
         self.dgrad_packed["fc6"] = ops.fc_dgrad_pack_weight(w["fc6_weight"], 1024, 8, 10, as_bf16=self.bf16)
-        # deconv dgrad = a plain stride-2 convolution of the output gradient with the deconv weight read as (O=Cin, I=Cout, 4, 4)
-        self.dgrad_packed["deconv5"] = ops.conv2d_pack_weight_padded(w["deconv5_weight"], 1024, as_bf16=self.bf16)
-        self.dgrad_packed["deconv4"] = ops.conv2d_pack_weight_padded(w["deconv4_weight"], ops.pad64(1026), as_bf16=self.bf16)
+        if self.has_decoder:
+            # deconv dgrad = a plain stride-2 convolution of the output gradient with the deconv weight read as (O=Cin, I=Cout, 4, 4)
+            self.dgrad_packed["deconv5"] = ops.conv2d_pack_weight_padded(w["deconv5_weight"], 1024, as_bf16=self.bf16)
+            self.dgrad_packed["deconv4"] = ops.conv2d_pack_weight_padded(w["deconv4_weight"], ops.pad64(1026), as_bf16=self.bf16)
 
     # ------------------------------------------------------------------------------------------------------------
     def forward(self, batch):
         """train graph forward (get_train_symbol :562-762).  batch: reference blob names (data + labels), CUDA tensors."""
         cfg, net = self.cfg, self.net
         H, W = 480, 640
-        # ZoomMask: the zoom window comes from mask_GT_observed and mask_rendered (zoom_mask.py:35-37)
-        ops.mask_bbox(batch["mask_gt_observed"], 0.3, out=net.bbox_obs)
-        ops.mask_bbox(batch["mask_rendered"], 0.2, out=net.bbox_ren)
+        if cfg.network.INPUT_MASK or self.pred_mask:
+            # ZoomMask: the zoom window comes from mask_GT_observed and mask_rendered (zoom_mask.py:35-37; get_train_symbol :589-612)
+            ops.mask_bbox(batch["mask_gt_observed"], 0.3, out=net.bbox_obs)
+            ops.mask_bbox(batch["mask_rendered"], 0.2, out=net.bbox_ren)
+        else:
+            # ZoomImage (:625-640, zoom_image.py:31-37): the validity "mask" of an image is sum_c(image + mean) > 0.01
+            ops.mask_bbox(batch["image_observed"], 0.01, mode=1, means3=net.plane_means, out=net.bbox_obs)
+            ops.mask_bbox(batch["image_rendered"], 0.01, mode=1, means3=net.plane_means, out=net.bbox_ren)
         ops.zoom_factor(net.bbox_obs, net.bbox_ren, batch["src_pose"], net.K, H, W, out=net.zoom_factor, status=net.status)
         net.net_input(batch)   # images (+ depth planes) (+ masks): the Concat of get_convs (:33-66) for this configuration's arity
-        ops.zoom_planes(batch["mask_gt_observed"], net.zoom_factor, post=1, out=self.zoom_mask_gt)
-        ops.zoom_planes(batch["flow"], net.zoom_factor, scale_mode=1, out=self.zoom_flow_lab)          # ZoomFlow :689-698
-        ops.zoom_planes(batch["flow_weights"], net.zoom_factor, post=2, out=self.zoom_flow_w)
+        if self.pred_mask:
+            ops.zoom_planes(batch["mask_gt_observed"], net.zoom_factor, post=1, out=self.zoom_mask_gt)
+        if self.pred_flow:
+            ops.zoom_planes(batch["flow"], net.zoom_factor, scale_mode=1, out=self.zoom_flow_lab)          # ZoomFlow :689-698
+            ops.zoom_planes(batch["flow_weights"], net.zoom_factor, post=2, out=self.zoom_flow_w)
         net.encoder()
         net.head()                                               # se3 = [rot (raw), inverse-zoomed trans]; fc7
         ops.quat_normalize(net.se3[:, :4].contiguous(), out=self.rot_norm)   # L2Normalization :375
-        net.decoder()
         p = self.w
-        ops.conv_small_cout_fwd(net.concat3, 770, net.packed["Convolution3"], p["Convolution3_bias"], 2, out=net.flow4)
-        ops.upsample16_fwd(net.flow4, p["upsampling_weight"], H, W, crop=8, out=self.flow_est_crop)
-        ops.conv_small_cout_fwd(net.concat3, 770, net.packed["mask_conv3"], p["mask_conv3_bias"], 1, out=net.mask4)
-        ops.upsample16_fwd(net.mask4, p["mask_upsampling_weight"], H, W, crop=8, out=self.mask_logit)
+        if self.has_decoder:
+            net.decoder()
+        if self.pred_flow:
+            ops.conv_small_cout_fwd(net.concat3, 770, net.packed["Convolution3"], p["Convolution3_bias"], 2, out=net.flow4)
+            ops.upsample16_fwd(net.flow4, p["upsampling_weight"], H, W, crop=8, out=self.flow_est_crop)
+        if self.pred_mask:
+            ops.conv_small_cout_fwd(net.concat3, 770, net.packed["mask_conv3"], p["mask_conv3_bias"], 1, out=net.mask4)
+            ops.upsample16_fwd(net.mask4, p["mask_upsampling_weight"], H, W, crop=8, out=self.mask_logit)
         self.trans_est = net.se3[:, 4:].contiguous()
         pts = batch["point_cloud_model"]
         self.pts_est = ops.transform3d_fwd(pts, self.rot_norm, self.trans_est, batch["src_pose"], cfg.network.ROT_COORD, self.T_means,
                                            self.T_stds, out=self.pts_est)
-        return {"rot_est_norm": self.rot_norm, "trans_est": self.trans_est, "flow_est_crop": self.flow_est_crop,
-                "mask_logit": self.mask_logit, "point_cloud_observed_est": self.pts_est, "zoom_factor": net.zoom_factor}
+        out = {"rot_est_norm": self.rot_norm, "trans_est": self.trans_est, "point_cloud_observed_est": self.pts_est, "zoom_factor": net.zoom_factor}
+        if self.pred_flow:
+            out["flow_est_crop"] = self.flow_est_crop
+        if self.pred_mask:
+            out["mask_logit"] = self.mask_logit
+        return out
 
     def backward(self, batch):
         cfg, net, w, g = self.cfg, self.net, self.w, self.g
@@ -274,9 +291,11 @@ class MutableModule(object):
         self._pending, self._next_bucket = [], 0
         self.loss_sums.zero_()
         # ---------------- loss gradients (get_loss :344-357, :446-499, :531-536)
-        ops.flow_loss_grad(self.flow_est_crop, self.zoom_flow_lab, self.zoom_flow_w, self.dflow_full, cfg.dataset.NORMALIZE_FLOW,
-                           ti.LW_FLOW / (480.0 * 640.0), loss_sum=self.loss_sums[0:1])
-        ops.logistic_grad(self.mask_logit, self.zoom_mask_gt, self.dlogit, ti.LW_MASK / (480.0 * 640.0), prob=self.mask_prob)
+        if self.pred_flow:
+            ops.flow_loss_grad(self.flow_est_crop, self.zoom_flow_lab, self.zoom_flow_w, self.dflow_full, cfg.dataset.NORMALIZE_FLOW,
+                               ti.LW_FLOW / (480.0 * 640.0), loss_sum=self.loss_sums[0:1])
+        if self.pred_mask:
+            ops.logistic_grad(self.mask_logit, self.zoom_mask_gt, self.dlogit, ti.LW_MASK / (480.0 * 640.0), prob=self.mask_prob)
         if ti.SE3_PM_LOSS:   # point matching (:440-499): L1 / L2 / smooth_L1 on (Transform3D(model points) - observed points) / norm
             if self.dpts is None:
                 self.dpts = torch.empty_like(self.pts_est)
@@ -292,30 +311,9 @@ class MutableModule(object):
             zt_gt = ops.zoom_trans(net.zoom_factor, batch["trans"].contiguous(), 1)   # ZoomTrans, b_inv_zoom False (:659-665)
             ops.se3_dist_loss_grad(self.rot_norm, batch["rot"].contiguous(), net.fc7, w, zt_gt, d_rn, d_t, ti.LW_ROT, ti.LW_TRANS,
                                    ti.TRANS_LOSS_TYPE, ti.TRANS_SMOOTH_L1_SCALAR, loss_sums2=self.loss_sums[3:5])
-        # ---------------- flow / mask heads
-        ops.upsample16_bwd(self.dflow_full, w["upsampling_weight"], self.dflow4)
-        ops.conv_small_cout_bwd(net.concat3, 770, self.dflow4, w["Convolution3_weight"], self.dconcat3, g["Convolution3_weight"],
-                                g["Convolution3_bias"], accumulate_dx=False, workspace=self.ws)
-        ops.upsample16_bwd(self.dlogit, w["mask_upsampling_weight"], self.dmask4)
-        ops.conv_small_cout_bwd(net.concat3, 770, self.dmask4, w["mask_conv3_weight"], self.dconcat3, g["mask_conv3_weight"],
-                                g["mask_conv3_bias"], accumulate_dx=True, workspace=self.ws)
-        g["upsampling_weight"].zero_()
-        g["mask_upsampling_weight"].zero_()
-        # ---------------- decoder level 4: Concat3 = [ReLU6 | ReLU12 (deconv4) | upsample_flow5to4]
-        ops.deconv4x4s2_tiny_bwd(net.flow5, self.dconcat3, 768, w["upsample_flow5to4_weight"], self.dflow5, g["upsample_flow5to4_weight"],
-                                 g["upsample_flow5to4_bias"])
-        ops.lrelu_bwd(net.concat3, self.dconcat3, 256, y_coff=512, dy_coff=512)
-        self._deconv_bwd("deconv4", x=net.concat2, x_c=1026, x_cpad=ops.pad64(1026), dz=self.dconcat3, dz_coff=512, cout=256, dx=self.dconcat2)
-        ops.conv_small_cout_bwd(net.concat2, 1026, self.dflow5, w["Convolution2_weight"], self.dconcat2, g["Convolution2_weight"],
-                                g["Convolution2_bias"], accumulate_dx=True, workspace=self.ws)
-        # ---------------- decoder level 5: Concat2 = [ReLU8 | ReLU11 (deconv5) | upsample_flow6to5]
-        ops.deconv4x4s2_tiny_bwd(net.flow6, self.dconcat2, 1024, w["upsample_flow6to5_weight"], self.dflow6, g["upsample_flow6to5_weight"],
-                                 g["upsample_flow6to5_bias"])
-        ops.lrelu_bwd(net.concat2, self.dconcat2, 512, y_coff=512, dy_coff=512)
         d10 = self.dacts["conv6_1"]
-        self._deconv_bwd("deconv5", x=net.acts["conv6_1"], x_c=1024, x_cpad=1024, dz=self.dconcat2, dz_coff=512, cout=512, dx=d10)
-        ops.conv_small_cout_bwd(net.acts["conv6_1"], 1024, self.dflow6, w["Convolution1_weight"], d10, g["Convolution1_weight"],
-                                g["Convolution1_bias"], accumulate_dx=True, workspace=self.ws)
+        if self.has_decoder:
+            self._decoder_backward()
         # ---------------- pose head (fc7, rot, trans, fc6)
         fc6a = net.fc6.view(B, 256)
         ops.pose_head_bwd(fc6a, net.fc7, net.se3[:, :4].contiguous(), d_rn, d_t, w, self.d_rot, self.dz7, self.dz6)
@@ -328,7 +326,8 @@ class MutableModule(object):
         self._bucket_ready("fc6_weight")
         ops.bias_grad(dz6, 256, g["fc6_bias"], workspace=self.bias_ws)
         # d(ReLU10) += dz6 * W6  (fc6 dgrad as a 1x1 convolution to 81920 "channels" = the NHWC feature map)
-        ops.conv2d_fwd_ex(dz6, 0, 256, self.dgrad_packed["fc6"], None, d10.view(B, 1, 1, 81920), 0, 81920, 1, 1, 1, 0, accumulate=True)  # M = B rows: tile 3
+        ops.conv2d_fwd_ex(dz6, 0, 256, self.dgrad_packed["fc6"], None, d10.view(B, 1, 1, 81920), 0, 81920, 1, 1, 1, 0,
+                          accumulate=self.has_decoder)  # M = B rows: tile 3; without a decoder this is d10's only term
         # ---------------- encoder, top down
         prev = {ENCODER[i][0]: (ENCODER[i - 1][0] if i else None) for i in range(len(ENCODER))}
         cin = {}
@@ -338,9 +337,9 @@ class MutableModule(object):
             c = cout
         for name, cout, k, s, p in reversed(ENCODER):
             dy = self.dacts[name]
-            if name == "conv5_1":
+            if name == "conv5_1" and self.has_decoder:
                 dy.add_(self.dconcat2[..., :512])   # skip connection into Concat2
-            if name == "conv4_1":
+            if name == "conv4_1" and self.has_decoder:
                 dy.add_(self.dconcat3[..., :512])   # skip connection into Concat3
             ops.lrelu_bwd_bias_grad(net.acts[name], dy, cout, g[name + "_bias"], workspace=self.bias_ws)   # dz in place + bias gradient
             x = net.acts[prev[name]] if prev[name] else net.X
@@ -429,6 +428,37 @@ class MutableModule(object):
                 ops.from_bf16(self.flat_g16[a:b], out=self.flat_g[a:b])
         self._pending = []
         self._next_bucket = 0
+
+    def _decoder_backward(self):
+        """heads and decoder (deepIM_flownet.py:213-299), top down: leaves d(ReLU10) in dacts["conv6_1"] (overwritten), the skip
+        terms of ReLU8 / ReLU6 in dconcat2[..., :512] / dconcat3[..., :512]"""
+        net, w, g = self.net, self.w, self.g
+        d10 = self.dacts["conv6_1"]
+        # ---------------- flow / mask heads (whichever exist; the first one overwrites d(Concat3), the second adds)
+        if self.pred_flow:
+            ops.upsample16_bwd(self.dflow_full, w["upsampling_weight"], self.dflow4)
+            ops.conv_small_cout_bwd(net.concat3, 770, self.dflow4, w["Convolution3_weight"], self.dconcat3, g["Convolution3_weight"],
+                                    g["Convolution3_bias"], accumulate_dx=False, workspace=self.ws)
+            g["upsampling_weight"].zero_()
+        if self.pred_mask:
+            ops.upsample16_bwd(self.dlogit, w["mask_upsampling_weight"], self.dmask4)
+            ops.conv_small_cout_bwd(net.concat3, 770, self.dmask4, w["mask_conv3_weight"], self.dconcat3, g["mask_conv3_weight"],
+                                    g["mask_conv3_bias"], accumulate_dx=self.pred_flow, workspace=self.ws)
+            g["mask_upsampling_weight"].zero_()
+        # ---------------- decoder level 4: Concat3 = [ReLU6 | ReLU12 (deconv4) | upsample_flow5to4]
+        ops.deconv4x4s2_tiny_bwd(net.flow5, self.dconcat3, 768, w["upsample_flow5to4_weight"], self.dflow5, g["upsample_flow5to4_weight"],
+                                 g["upsample_flow5to4_bias"])
+        ops.lrelu_bwd(net.concat3, self.dconcat3, 256, y_coff=512, dy_coff=512)
+        self._deconv_bwd("deconv4", x=net.concat2, x_c=1026, x_cpad=ops.pad64(1026), dz=self.dconcat3, dz_coff=512, cout=256, dx=self.dconcat2)
+        ops.conv_small_cout_bwd(net.concat2, 1026, self.dflow5, w["Convolution2_weight"], self.dconcat2, g["Convolution2_weight"],
+                                g["Convolution2_bias"], accumulate_dx=True, workspace=self.ws)
+        # ---------------- decoder level 5: Concat2 = [ReLU8 | ReLU11 (deconv5) | upsample_flow6to5]
+        ops.deconv4x4s2_tiny_bwd(net.flow6, self.dconcat2, 1024, w["upsample_flow6to5_weight"], self.dflow6, g["upsample_flow6to5_weight"],
+                                 g["upsample_flow6to5_bias"])
+        ops.lrelu_bwd(net.concat2, self.dconcat2, 512, y_coff=512, dy_coff=512)
+        self._deconv_bwd("deconv5", x=net.acts["conv6_1"], x_c=1024, x_cpad=1024, dz=self.dconcat2, dz_coff=512, cout=512, dx=d10)
+        ops.conv_small_cout_bwd(net.acts["conv6_1"], 1024, self.dflow6, w["Convolution1_weight"], d10, g["Convolution1_weight"],
+                                g["Convolution1_bias"], accumulate_dx=True, workspace=self.ws)
 
     def _deconv_bwd(self, name, x, x_c, x_cpad, dz, dz_coff, cout, dx):
         """Deconvolution(k4,s2)+Crop(1,1) backward.  x: deconv input (N,h,w,stride>=x_cpad), dz: gradient w.r.t. the pre-activation

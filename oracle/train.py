@@ -60,9 +60,15 @@ def loss_and_grads(params, batch, cfg, K, dtype=torch.float64):
     """-> (outputs dict, grads dict name -> numpy in MXNet layouts).  batch: numpy blobs with the reference names."""
     H, W = 480, 640
     ti = cfg.train_iter
-    zmo, zmg, zmr, zf = ozoom.zoom_mask(batch["mask_observed"], batch["mask_gt_observed"], batch["mask_rendered"], batch["src_pose"], K, H, W)
-    zio, zir = ozoom.zoom_image_with_factor(zf, batch["image_observed"], batch["image_rendered"], cfg.network.PIXEL_MEANS, H, W)
-    zflow, zfw = ozoom.zoom_flow(zf, batch["flow"], batch["flow_weights"], b_inv_zoom=False, H=H, W=W)
+    pred_flow, pred_mask = bool(cfg.network.PRED_FLOW), bool(cfg.network.PRED_MASK)
+    zmo = zmg = zmr = None
+    if cfg.network.INPUT_MASK or pred_mask:   # :589-623 ZoomMask + ZoomImageWithFactor; else :625-640 ZoomImage
+        zmo, zmg, zmr, zf = ozoom.zoom_mask(batch["mask_observed"], batch["mask_gt_observed"], batch["mask_rendered"], batch["src_pose"], K, H, W)
+        zio, zir = ozoom.zoom_image_with_factor(zf, batch["image_observed"], batch["image_rendered"], cfg.network.PIXEL_MEANS, H, W)
+    else:
+        zio, zir, zf = ozoom.zoom_image(batch["image_observed"], batch["image_rendered"], batch["src_pose"], K, cfg.network.PIXEL_MEANS, H, W)
+    if pred_flow:
+        zflow, zfw = ozoom.zoom_flow(zf, batch["flow"], batch["flow_weights"], b_inv_zoom=False, H=H, W=W)
     # the Concat of get_convs (deepIM_flownet.py:33-66) for this configuration: the zoom window always comes from the masks in
     # training (:589-612, PRED_MASK), the masks are network inputs only with INPUT_MASK, the zoomed depth planes with INPUT_DEPTH (:670-683)
     with_masks = bool(cfg.network.INPUT_MASK and cfg.network.PRED_MASK)
@@ -84,30 +90,37 @@ def loss_and_grads(params, batch, cfg, K, dtype=torch.float64):
     tz = F.linear(fc7, P["trans_weight"], P["trans_bias"])
     rot_norm = rot / torch.sqrt((rot * rot).sum(dim=1, keepdim=True) + 1e-10)  # L2Normalization(instance)
     trans_est = _InvZoomTrans.apply(tz, torch.from_numpy(zf[:, 0].astype(np.float64)).to(dtype))
-    # decoder
+    # decoder (:213-299: built when either head is predicted) and the heads that exist
     r10, r8, r6 = feats["conv6_1"], feats["conv5_1"], feats["conv4_1"]
-    c1 = F.conv2d(r10, P["Convolution1_weight"], P["Convolution1_bias"], padding=1)
-    d5 = F.leaky_relu(crop_like(F.conv_transpose2d(r10, P["deconv5_weight"], P["deconv5_bias"], stride=2), r8.shape[2:], (1, 1)), 0.1)
-    u65 = crop_like(F.conv_transpose2d(c1, P["upsample_flow6to5_weight"], P["upsample_flow6to5_bias"], stride=2), r8.shape[2:], (1, 1))
-    cat2 = torch.cat([r8, d5, u65], dim=1)
-    c2 = F.conv2d(cat2, P["Convolution2_weight"], P["Convolution2_bias"], padding=1)
-    d4 = F.leaky_relu(crop_like(F.conv_transpose2d(cat2, P["deconv4_weight"], P["deconv4_bias"], stride=2), r6.shape[2:], (1, 1)), 0.1)
-    u54 = crop_like(F.conv_transpose2d(c2, P["upsample_flow5to4_weight"], P["upsample_flow5to4_bias"], stride=2), r6.shape[2:], (1, 1))
-    cat3 = torch.cat([r6, d4, u54], dim=1)
-    f4 = F.conv2d(cat3, P["Convolution3_weight"], P["Convolution3_bias"], padding=1)
-    flow_est = crop_like(F.conv_transpose2d(f4, P["upsampling_weight"], None, stride=16, groups=2), (H, W), (8, 8))
-    m4 = F.conv2d(cat3, P["mask_conv3_weight"], P["mask_conv3_bias"], padding=1)
-    logit = crop_like(F.conv_transpose2d(m4, P["mask_upsampling_weight"], None, stride=16), (H, W), (8, 8))
-    # losses -> one scalar whose autograd gradient equals MXNet's head gradients
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dtype)  # noqa: E731
-    flow_loss_ = t(zfw) * (flow_est - t(zflow) / cfg.dataset.NORMALIZE_FLOW) ** 2
+    cat2 = cat3 = flow_est = logit = None
+    flow_loss_ = torch.zeros(1, dtype=dtype)
+    L = torch.zeros((), dtype=dtype)
+    if pred_flow or pred_mask:
+        c1 = F.conv2d(r10, P["Convolution1_weight"], P["Convolution1_bias"], padding=1)
+        d5 = F.leaky_relu(crop_like(F.conv_transpose2d(r10, P["deconv5_weight"], P["deconv5_bias"], stride=2), r8.shape[2:], (1, 1)), 0.1)
+        u65 = crop_like(F.conv_transpose2d(c1, P["upsample_flow6to5_weight"], P["upsample_flow6to5_bias"], stride=2), r8.shape[2:], (1, 1))
+        cat2 = torch.cat([r8, d5, u65], dim=1)
+        c2 = F.conv2d(cat2, P["Convolution2_weight"], P["Convolution2_bias"], padding=1)
+        d4 = F.leaky_relu(crop_like(F.conv_transpose2d(cat2, P["deconv4_weight"], P["deconv4_bias"], stride=2), r6.shape[2:], (1, 1)), 0.1)
+        u54 = crop_like(F.conv_transpose2d(c2, P["upsample_flow5to4_weight"], P["upsample_flow5to4_bias"], stride=2), r6.shape[2:], (1, 1))
+        cat3 = torch.cat([r6, d4, u54], dim=1)
+    if pred_flow:
+        f4 = F.conv2d(cat3, P["Convolution3_weight"], P["Convolution3_bias"], padding=1)
+        flow_est = crop_like(F.conv_transpose2d(f4, P["upsampling_weight"], None, stride=16, groups=2), (H, W), (8, 8))
+        flow_loss_ = t(zfw) * (flow_est - t(zflow) / cfg.dataset.NORMALIZE_FLOW) ** 2
+        L = L + (ti.LW_FLOW / (480.0 * 640.0)) * flow_loss_.sum()
+    if pred_mask:
+        m4 = F.conv2d(cat3, P["mask_conv3_weight"], P["mask_conv3_bias"], padding=1)
+        logit = crop_like(F.conv_transpose2d(m4, P["mask_upsampling_weight"], None, stride=16), (H, W), (8, 8))
+        bce = F.binary_cross_entropy_with_logits(logit, t(zmg), reduction="sum")  # d/dx = sigmoid(x) - y
+        L = L + (ti.LW_MASK / (480.0 * 640.0)) * bce
+    # losses -> one scalar whose autograd gradient equals MXNet's head gradients
     pts_est = _Transform3D.apply(t(batch["point_cloud_model"]), rot_norm, trans_est, batch["src_pose"], np.asarray(cfg.dataset.trans_means, np.float32),
                                  np.asarray(cfg.dataset.trans_stds, np.float32), cfg.network.ROT_COORD)
     # point matching: SE3_PM_LOSS_TYPE 'L1' | 'L2' | 'smooth_L1' (deepIM_flownet.py:458-499)
     pm_loss_ = t(batch["point_cloud_weights"]) * _elem_loss((pts_est - t(batch["point_cloud_observed"])) / cfg.dataset.NORMALIZE_3D_POINT,
                                                              ti.SE3_PM_LOSS_TYPE, ti.SE3_PM_SL1_SCALAR)
-    bce = F.binary_cross_entropy_with_logits(logit, t(zmg), reduction="sum")  # d/dx = sigmoid(x) - y
-    L = (ti.LW_FLOW / (480.0 * 640.0)) * flow_loss_.sum() + (ti.LW_MASK / (480.0 * 640.0)) * bce
     if ti.SE3_PM_LOSS:
         L = L + (ti.LW_PM / float(ti.NUM_3D_SAMPLE)) * pm_loss_.sum()
     rot_loss_ = trans_loss_ = torch.zeros(1, dtype=dtype)
@@ -120,15 +133,22 @@ def loss_and_grads(params, batch, cfg, K, dtype=torch.float64):
         trans_loss_ = _elem_loss(tz - zt_gt, ti.TRANS_LOSS_TYPE, ti.TRANS_SMOOTH_L1_SCALAR)
         L = L + ti.LW_ROT * rot_loss_.sum() + ti.LW_TRANS * trans_loss_.sum()
     for tnsr in (cat2, cat3, r10, r8, r6):
-        tnsr.retain_grad()
+        if tnsr is not None:
+            tnsr.retain_grad()
     L.backward()
     grads = {k: (v.grad.numpy().astype(np.float64) if v.grad is not None else np.zeros(v.shape)) for k, v in P.items()}
     for k in ("upsampling_weight", "mask_upsampling_weight"):  # lr_mult 0: frozen
-        grads[k] = np.zeros_like(grads[k])
-    out = {"rot_est_norm": rot_norm.detach().numpy(), "trans_est": trans_est.detach().numpy(), "flow_est_crop": flow_est.detach().numpy(),
-           "mask_logit": logit.detach().numpy(), "zoom_factor": zf, "cat2": cat2.detach().numpy(), "cat3": cat3.detach().numpy(), "r10": r10.detach().numpy(), "d_cat2": cat2.grad.numpy(), "d_cat3": cat3.grad.numpy(),
+        if k in grads:
+            grads[k] = np.zeros_like(grads[k])
+    out = {"rot_est_norm": rot_norm.detach().numpy(), "trans_est": trans_est.detach().numpy(), "zoom_factor": zf, "r10": r10.detach().numpy(),
            "d_r10": r10.grad.numpy(), "d_r8": r8.grad.numpy(), "d_r6": r6.grad.numpy(), "flow_loss_sum": float(flow_loss_.sum()), "pm_loss_sum": float(pm_loss_.sum()),
            "rot_loss_sum": float(rot_loss_.sum()), "trans_loss_sum": float(trans_loss_.sum())}
+    if flow_est is not None:
+        out["flow_est_crop"] = flow_est.detach().numpy()
+    if logit is not None:
+        out["mask_logit"] = logit.detach().numpy()
+    if cat2 is not None:
+        out.update({"cat2": cat2.detach().numpy(), "cat3": cat3.detach().numpy(), "d_cat2": cat2.grad.numpy(), "d_cat3": cat3.grad.numpy()})
     return out, grads
 
 

@@ -309,3 +309,55 @@ def test_train_input_arities(setup, input_mask, input_depth):
     out3 = MutableModule(cfg, new, B).forward(batch)
     np.testing.assert_array_equal(out2["rot_est_norm"].cpu().numpy(), out3["rot_est_norm"].cpu().numpy())
     np.testing.assert_allclose(out2["flow_est_crop"].cpu().numpy(), out3["flow_est_crop"].cpu().numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize("pred_flow,pred_mask,input_mask", [(True, False, True), (False, True, True), (False, False, True), (False, False, False)])
+def test_train_optional_heads(setup, pred_flow, pred_mask, input_mask):
+    """Training graphs without the flow and / or the mask head (reference: the decoder exists when either is predicted,
+    deepIM_flownet.py:213; flow loss :315-357, mask loss :502-536; the zoom window comes from the masks when INPUT_MASK or PRED_MASK,
+    else from the images, :589-640).  Outputs and every gradient of the parameters that configuration has, vs the oracle."""
+    from deepim.core.module import MutableModule
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+
+    _, _, scene = setup
+    cfg = make_train_config()
+    cfg.network.PRED_FLOW, cfg.network.PRED_MASK, cfg.network.INPUT_MASK = pred_flow, pred_mask, input_mask
+    sym = deepIM_flownet()
+    sym.get_symbol(cfg, is_train=True)
+    params = sym.init_weights(cfg, {}, {}, seed=0)
+    rng = np.random.RandomState(1)
+    params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
+    params["rot_weight"][1:] = (rng.randn(3, 256) * 0.01).astype(np.float32)
+    has_dec = pred_flow or pred_mask
+    assert ("deconv5_weight" in params) == has_dec and ("Convolution3_weight" in params) == pred_flow and ("mask_conv3_weight" in params) == pred_mask
+    B = 2
+    blobs = scene["blobs"]
+    mod = MutableModule(cfg, params, B)
+    batch = {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in blobs.items()}
+    out = mod.forward_backward(batch)
+    ref_out, ref_g = otrain.loss_and_grads(params, blobs, cfg, scene["K"])
+    np.testing.assert_allclose(out["zoom_factor"].cpu().numpy(), ref_out["zoom_factor"], atol=1e-5)
+    np.testing.assert_allclose(out["rot_est_norm"].cpu().numpy(), ref_out["rot_est_norm"], atol=1e-5)
+    np.testing.assert_allclose(out["trans_est"].cpu().numpy(), ref_out["trans_est"], atol=1e-5)
+    assert ("flow_est_crop" in out) == pred_flow and ("mask_logit" in out) == pred_mask
+    if pred_flow:
+        fe = ref_out["flow_est_crop"]
+        np.testing.assert_allclose(out["flow_est_crop"].cpu().numpy(), fe, atol=1e-4 * max(1.0, np.abs(fe).max()))
+    if pred_mask:
+        np.testing.assert_allclose(out["mask_logit"].cpu().numpy(), ref_out["mask_logit"], atol=1e-4)
+    got = mod.get_grads()
+    assert sorted(got) == sorted(ref_g)
+    for k, rg in ref_g.items():
+        scale = np.abs(rg).max()
+        err = np.abs(got[k] - rg).max()
+        l2 = np.linalg.norm((got[k] - rg).ravel()) / (np.linalg.norm(rg.ravel()) + 1e-30)
+        print("grad {:28s} max|g| {:.3e}  max err {:.3e}  l2 {:.2e}".format(k, scale, err, l2))
+        # no LeakyReLU' below these: the pose head (fc6 / fc7 activations aside) and the two heads that sit on Concat3; every other
+        # gradient passes the decoder / encoder activations, where pre-activations within f32 noise of zero flip between f32 and f64
+        exact_path = k.startswith(("fc", "rot", "trans", "Convolution3", "mask_conv3"))
+        assert err <= (1e-4 if exact_path else 5e-2) * scale + 1e-9, (k, float(err), float(scale))
+        assert l2 <= (1e-4 if exact_path else 1e-2), (k, l2)
+    mod.update(cfg.TRAIN.lr)
+    out2 = mod.forward(batch)
+    out3 = MutableModule(cfg, mod.get_params(), B).forward(batch)
+    np.testing.assert_array_equal(out2["rot_est_norm"].cpu().numpy(), out3["rot_est_norm"].cpu().numpy())
