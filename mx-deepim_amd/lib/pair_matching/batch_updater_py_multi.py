@@ -29,8 +29,10 @@ class batchUpdaterPyMulti(object):
         self.K = np.asarray(big_cfg.dataset.INTRINSIC_MATRIX, dtype=np.float32).reshape(3, 3)
         self.Kinv = np.linalg.inv(np.matrix(self.K))  # same call as the reference (:41)
         self.plane_means = np.asarray(big_cfg.network.PIXEL_MEANS, dtype=np.float32).reshape(3)[::-1].copy()  # pixel_means[[2,1,0]] (:24-25)
-        if big_cfg.dataset.dataset.startswith("ModelNet"):
-            raise NotImplementedError("the lit ModelNet renderer variant is not on the HIP path yet")
+        # ModelNet (:232-270): the render machine is the lit one (Render_Py_Light_ModelNet_Multi) and forward() draws its intensities
+        if big_cfg.dataset.dataset.startswith("ModelNet") and render_machine is not None and not hasattr(render_machine, "normals"):
+            raise Exception("ModelNet batches re-render with the lit renderer (Render_Py_Light_ModelNet_Multi); got {}".format(
+                type(render_machine).__name__))
         self.render_machine = render_machine
         self._bufs = None
 

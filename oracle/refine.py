@@ -74,9 +74,11 @@ def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord=
     return poses, se3s
 
 
-def update_train_batch(blobs, preds, meshes, K, pixel_means, T_means, T_stds, rot_coord="CAMERA", znear=0.25, zfar=6.0):
+def update_train_batch(blobs, preds, meshes, K, pixel_means, T_means, T_stds, rot_coord="CAMERA", znear=0.25, zfar=6.0, lit=None):
     """batchUpdaterPyMulti.forward restated (lib/pair_matching/batch_updater_py_multi.py:205-365) for one GPU's blobs (numpy).
-    preds: rot_est (B,4) [= rot_est_norm], trans_est (B,3).  Returns the dict of updated blobs."""
+    preds: rot_est (B,4) [= rot_est_norm], trans_est (B,3).  Returns the dict of updated blobs.
+    lit: None, or dict(normals=[(V,3) per mesh], ratio=0.7) for the ModelNet branch (:232-270): light index 2 moved by the refined
+    translation, one np.random.uniform(0.9, 1.1, 3) intensity per sample in batch order."""
     B = blobs["src_pose"].shape[0]
     H, W = blobs["image_rendered"].shape[2:]
     K = np.asarray(K, dtype=np.float32)
@@ -89,7 +91,13 @@ def update_train_batch(blobs, preds, meshes, K, pixel_means, T_means, T_stds, ro
         refined = ose3.RT_transform(np.squeeze(blobs["src_pose"][b]), np.squeeze(preds["rot_est"][b]), np.squeeze(preds["trans_est"][b]),
                                     T_means, T_stds, rot_coord)
         v, t, f, tex = meshes[int(blobs["class_index"][b])]
-        bgr, depth = native.render(v, t, f, tex, refined[:3, :3], refined[:3, 3], K, znear=znear, zfar=zfar)
+        if lit is None:
+            bgr, depth = native.render(v, t, f, tex, refined[:3, :3], refined[:3, 3], K, znear=znear, zfar=zfar)
+        else:
+            light_position = native.modelnet_light_position(refined, idx=2)
+            light_intensity = np.array([1, 1, 1])[0] * np.random.uniform(0.9, 1.1, size=(3,))
+            bgr, depth = native.render_lit(v, lit["normals"][int(blobs["class_index"][b])], t, f, tex, refined[:3, :3], refined[:3, 3], K,
+                                           light_position, light_intensity, lit.get("ratio", 0.7), znear=znear, zfar=zfar)
         im = bgr[:, :, [2, 1, 0]].transpose([2, 0, 1]).astype(np.float32)
         im -= pm
         r, tr = ose3.calc_RT_delta(refined, np.squeeze(blobs["tgt_pose"][b]), T_means, T_stds, rot_coord, "QUAT")

@@ -361,3 +361,47 @@ def test_train_optional_heads(setup, pred_flow, pred_mask, input_mask):
     out2 = mod.forward(batch)
     out3 = MutableModule(cfg, mod.get_params(), B).forward(batch)
     np.testing.assert_array_equal(out2["rot_est_norm"].cpu().numpy(), out3["rot_est_norm"].cpu().numpy())
+
+
+def test_batch_updater_modelnet_lit(setup):
+    """The ModelNet branch of batchUpdaterPyMulti.forward (reference batch_updater_py_multi.py:232-270): the re-render between training
+    iterations goes through the lit renderer, light index 2 moved by the refined translation, one host-drawn intensity per sample in
+    batch order (numpy's global stream, like the reference)."""
+    from lib.pair_matching.batch_updater_py_multi import batchUpdaterPyMulti
+    from lib.render_hip.render_py_light_modelnet_multi import Render_Py_Light_ModelNet_Multi, vertex_normals
+    from lib.render_hip.render_py_multi import Render_Py
+    from oracle import refine as orefine
+
+    cfg = make_train_config()
+    cfg.dataset.dataset = "ModelNet_v1"
+    cfg.dataset.class_name = ["m0", "m1"]
+    B = 2
+    scene = make_train_scene(B=B, seed=4242, subdiv=3, n_models=2)
+    bl = scene["blobs"]
+    gray = np.full((32, 32, 3), 180, np.uint8)
+    meshes = [(v, vertex_normals(v, f).astype(np.float32), t, f) for v, t, f, _ in scene["models"]]
+    rm = Render_Py_Light_ModelNet_Multi(None, gray, scene["K"], 640, 480, 0.25, 6.0, brightness_ratios=[0.7], meshes=meshes)
+    with pytest.raises(Exception):   # a ModelNet batch must not be re-rendered unlit
+        batchUpdaterPyMulti(cfg, 480, 640, render_machine=Render_Py(None, cfg.dataset.class_name, scene["K"], meshes=scene["models"]))
+    upd = batchUpdaterPyMulti(cfg, 480, 640, render_machine=rm)
+    batch = {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in bl.items()}
+    preds = {"rot_est_norm": torch.tensor([[0.999, 0.02, -0.03, 0.01], [0.98, -0.1, 0.05, 0.12]], device=DEV),
+             "trans_est": torch.tensor([[0.01, -0.02, 0.03], [-0.015, 0.01, -0.05]], device=DEV)}
+    preds["rot_est_norm"] = preds["rot_est_norm"] / preds["rot_est_norm"].norm(dim=1, keepdim=True)
+    np.random.seed(5)
+    new = upd.forward(batch, preds)
+    np.random.seed(5)
+    z3, o3 = np.zeros(3), np.ones(3)
+    ref = orefine.update_train_batch(bl, {"rot_est": preds["rot_est_norm"].cpu().numpy(), "trans_est": preds["trans_est"].cpu().numpy()},
+                                     [(v, t, f, gray) for v, n, t, f in meshes], scene["K"], cfg.network.PIXEL_MEANS, z3, o3,
+                                     lit={"normals": [n for v, n, t, f in meshes], "ratio": 0.7})
+    np.testing.assert_allclose(new["src_pose"].cpu().numpy(), ref["src_pose"], atol=2e-6)
+    np.testing.assert_allclose(new["rot"].cpu().numpy(), ref["rot"], atol=5e-6)
+    assert (new["mask_rendered"].cpu().numpy() != ref["mask_rendered"]).sum() <= 8
+    img, rimg = new["image_rendered"].cpu().numpy(), ref["image_rendered"]
+    # lit shading: integral grey levels, a rounding tie may land one level apart; silhouette pixels may differ by the fill rule
+    assert (np.abs(img - rimg).max(axis=1) > 1.0).sum() <= 32
+    on = ref["mask_rendered"][:, 0] > 0
+    assert rimg[:, 0][on].std() > 2.0 and np.abs(img - rimg)[:, :, :, :][np.broadcast_to(on[:, None], img.shape)].mean() < 0.2
+    fw, rfw = new["flow_weights"].cpu().numpy(), ref["flow_weights"]
+    assert (fw != rfw).sum() <= 200 and fw.sum() > 1000
