@@ -48,6 +48,11 @@ int dim_copy_words(void* dst, const void* src, long nwords, void* stream);
  * (O, I, kh, kw) weight is one run of (b - a) kh kw words per output channel (the training executor's first layer when the network
  * input has 6 or 10 channels: reference get_convs, deepim/symbols/deepIM_flownet.py:33-66). */
 int dim_copy_rows(void* dst, long dst_pitch_words, const void* src, long src_pitch_words, long rows, long width_words, void* stream);
+/* dst += src over the same geometry, as floats (the skip connections of the decoder add a channel range of a concat-gradient buffer to
+ * an encoder gradient: get_convs Concat2 / Concat3, deepim/symbols/deepIM_flownet.py:236-299), and a constant fill (loss sums) -- so
+ * that no vendor elementwise kernel sits on the training or test path. */
+int dim_add_rows(float* dst, long dst_pitch, const float* src, long src_pitch, long rows, long width, void* stream);
+int dim_fill_words(void* dst, long nwords, unsigned value, void* stream);
 
 /* ---------------------------------------------------------------- zoom ops
  * bbox of {x > thr} (mode 0, C==1) or {sum_c (x_c + means3[c]) > thr} (mode 1, C==3):

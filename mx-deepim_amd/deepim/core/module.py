@@ -118,6 +118,8 @@ class MutableModule(object):
         self.mask_logit = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
         self.mask_prob = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
         self.rot_norm = torch.empty((B, 4), dtype=torch.float32, device=d)
+        self.rot_raw = torch.empty((B, 4), dtype=torch.float32, device=d)     # se3[:, :4] / se3[:, 4:] as their own arrays
+        self.trans_est = torch.empty((B, 3), dtype=torch.float32, device=d)
         self.loss_sums = torch.zeros(5, dtype=torch.float32, device=d)  # flow, pm, -, rot, trans (un-scaled sums; metrics only)
         self.T_means = np.asarray(cfg.dataset.trans_means, dtype=np.float32)
         self.T_stds = np.asarray(cfg.dataset.trans_stds, dtype=np.float32)
@@ -263,7 +265,8 @@ class MutableModule(object):
             ops.zoom_planes(batch["flow_weights"], net.zoom_factor, post=2, out=self.zoom_flow_w)
         net.encoder()
         net.head()                                               # se3 = [rot (raw), inverse-zoomed trans]; fc7
-        ops.quat_normalize(net.se3[:, :4].contiguous(), out=self.rot_norm)   # L2Normalization :375
+        ops.copy_nhwc_channels(self.rot_raw, 0, net.se3, 0, 4)
+        ops.quat_normalize(self.rot_raw, out=self.rot_norm)   # L2Normalization :375
         p = self.w
         if self.has_decoder:
             net.decoder()
@@ -273,7 +276,7 @@ class MutableModule(object):
         if self.pred_mask:
             ops.conv_small_cout_fwd(net.concat3, 770, net.packed["mask_conv3"], p["mask_conv3_bias"], 1, out=net.mask4)
             ops.upsample16_fwd(net.mask4, p["mask_upsampling_weight"], H, W, crop=8, out=self.mask_logit)
-        self.trans_est = net.se3[:, 4:].contiguous()
+        ops.copy_nhwc_channels(self.trans_est, 0, net.se3, 4, 3)
         pts = batch["point_cloud_model"]
         self.pts_est = ops.transform3d_fwd(pts, self.rot_norm, self.trans_est, batch["src_pose"], cfg.network.ROT_COORD, self.T_means,
                                            self.T_stds, out=self.pts_est)
@@ -289,7 +292,7 @@ class MutableModule(object):
         ti = cfg.train_iter
         B = self.B
         self._pending, self._next_bucket = [], 0
-        self.loss_sums.zero_()
+        ops.fill(self.loss_sums, 0.0)
         # ---------------- loss gradients (get_loss :344-357, :446-499, :531-536)
         if self.pred_flow:
             ops.flow_loss_grad(self.flow_est_crop, self.zoom_flow_lab, self.zoom_flow_w, self.dflow_full, cfg.dataset.NORMALIZE_FLOW,
@@ -316,7 +319,7 @@ class MutableModule(object):
             self._decoder_backward()
         # ---------------- pose head (fc7, rot, trans, fc6)
         fc6a = net.fc6.view(B, 256)
-        ops.pose_head_bwd(fc6a, net.fc7, net.se3[:, :4].contiguous(), d_rn, d_t, w, self.d_rot, self.dz7, self.dz6)
+        ops.pose_head_bwd(fc6a, net.fc7, self.rot_raw, d_rn, d_t, w, self.d_rot, self.dz7, self.dz6)
         ops.fc_wgrad(self.d_rot, net.fc7, g["rot_weight"], g["rot_bias"])
         ops.fc_wgrad(d_t, net.fc7, g["trans_weight"], g["trans_bias"])
         ops.fc_wgrad(self.dz7, fc6a, g["fc7_weight"], g["fc7_bias"])
@@ -338,9 +341,9 @@ class MutableModule(object):
         for name, cout, k, s, p in reversed(ENCODER):
             dy = self.dacts[name]
             if name == "conv5_1" and self.has_decoder:
-                dy.add_(self.dconcat2[..., :512])   # skip connection into Concat2
+                ops.copy_nhwc_channels(dy, 0, self.dconcat2, 0, 512, add=True)   # skip connection into Concat2
             if name == "conv4_1" and self.has_decoder:
-                dy.add_(self.dconcat3[..., :512])   # skip connection into Concat3
+                ops.copy_nhwc_channels(dy, 0, self.dconcat3, 0, 512, add=True)   # skip connection into Concat3
             ops.lrelu_bwd_bias_grad(net.acts[name], dy, cout, g[name + "_bias"], workspace=self.bias_ws)   # dz in place + bias gradient
             x = net.acts[prev[name]] if prev[name] else net.X
             if name in self.wino_wgrad:
@@ -439,12 +442,10 @@ class MutableModule(object):
             ops.upsample16_bwd(self.dflow_full, w["upsampling_weight"], self.dflow4)
             ops.conv_small_cout_bwd(net.concat3, 770, self.dflow4, w["Convolution3_weight"], self.dconcat3, g["Convolution3_weight"],
                                     g["Convolution3_bias"], accumulate_dx=False, workspace=self.ws)
-            g["upsampling_weight"].zero_()
         if self.pred_mask:
             ops.upsample16_bwd(self.dlogit, w["mask_upsampling_weight"], self.dmask4)
             ops.conv_small_cout_bwd(net.concat3, 770, self.dmask4, w["mask_conv3_weight"], self.dconcat3, g["mask_conv3_weight"],
                                     g["mask_conv3_bias"], accumulate_dx=self.pred_flow, workspace=self.ws)
-            g["mask_upsampling_weight"].zero_()
         # ---------------- decoder level 4: Concat3 = [ReLU6 | ReLU12 (deconv4) | upsample_flow5to4]
         ops.deconv4x4s2_tiny_bwd(net.flow5, self.dconcat3, 768, w["upsample_flow5to4_weight"], self.dflow5, g["upsample_flow5to4_weight"],
                                  g["upsample_flow5to4_bias"])

@@ -462,13 +462,13 @@ class FlowNetHip(object):
         p = self.params
         r10, r8, r6 = self.acts["conv6_1"], self.acts["conv5_1"], self.acts["conv4_1"]
         ops.conv_small_cout_fwd(r10, 1024, self.packed["Convolution1"], p["Convolution1_bias"], 2, out=self.flow6)
-        self.concat2[..., :512].copy_(r8)  # strided: an elementwise kernel, not a memcpy node
+        ops.copy_nhwc_channels(self.concat2, 0, r8, 0, 512)   # Concat2[..., :512] = ReLU8 (a kernel, not a memcpy node)
         ops.deconv4x4s2_fwd(r10, 1024, self.packed["deconv5"], p["deconv5_bias"], self.concat2, 512, crop=1, slope=0.1, out_coff=512,
                             tile=bf16_tile(512) if self.bf16 else 3)
         ops.deconv4x4s2_tiny_fwd(self.flow6, 2, p["upsample_flow6to5_weight"], p["upsample_flow6to5_bias"], self.concat2, 2, crop=1,
                                  out_coff=1024)
         ops.conv_small_cout_fwd(self.concat2, 1026, self.packed["Convolution2"], p["Convolution2_bias"], 2, out=self.flow5)
-        self.concat3[..., :512].copy_(r6)
+        ops.copy_nhwc_channels(self.concat3, 0, r6, 0, 512)   # Concat3[..., :512] = ReLU6
         ops.deconv4x4s2_fwd(self.concat2, 1026, self.packed["deconv4"], p["deconv4_bias"], self.concat3, 256, crop=1, slope=0.1,
                             out_coff=512, tile=bf16_tile(256) if self.bf16 else 3)
         ops.deconv4x4s2_tiny_fwd(self.flow5, 2, p["upsample_flow5to4_weight"], p["upsample_flow5to4_bias"], self.concat3, 2, crop=1,

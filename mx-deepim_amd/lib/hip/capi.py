@@ -94,6 +94,8 @@ SIGNATURES = {
     "dim_conv2d_fwd_winograd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, P, P]),
     "dim_copy_words": (I, [P, P, L, P]),
     "dim_copy_rows": (I, [P, L, P, L, L, L, P]),
+    "dim_add_rows": (I, [P, L, P, L, L, L, P]),
+    "dim_fill_words": (I, [P, L, ctypes.c_uint, P]),
     "dim_sgd_momentum": (I, [P, P, P, L, F, F, F, F, P]),
     "dim_adam": (I, [P, P, P, P, L, F, F, F, F, F, F, P]),
     "dim_deconv4x4s2_packed_weight_floats": (L, [I, I]),

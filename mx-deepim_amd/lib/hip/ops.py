@@ -4,6 +4,8 @@ Every function only enqueues HIP kernels on torch's current stream; outputs are 
 caller-provided tensors when given, so the refinement loop can run allocation-free inside a
 hipGraph capture.  No CPU fallback: non-CUDA tensors raise DeepIMHipError.
 """
+import struct
+
 import torch
 
 from . import capi
@@ -234,6 +236,27 @@ def copy(dst, src):
     (hipMemcpyAsync nodes inside captured graphs are avoided, see include/deepim_hip.h dim_copy_words)."""
     assert dst.shape == src.shape and dst.dtype == src.dtype and dst.element_size() == 4, (dst.shape, src.shape, dst.dtype, src.dtype)
     check(lib().dim_copy_words(dptr(dst), dptr(src), dst.numel(), current_stream()))
+    return dst
+
+
+def copy_nhwc_channels(dst, dst_c0, src, src_c0, nch, add=False):
+    """dst[..., dst_c0:dst_c0+nch] (+)= src[..., src_c0:src_c0+nch] for two contiguous f32 tensors with the same leading dims and their own
+    channel counts (NHWC maps, or (B, C) matrices): dim_copy_rows / dim_add_rows with rows = pixels -- the strided copy / add a
+    Tensor.copy_ / add_ on a channel slice would hand to a vendor elementwise kernel"""
+    assert dst.is_contiguous() and src.is_contiguous() and dst.shape[:-1] == src.shape[:-1], (dst.shape, src.shape)
+    Cd, Cs = dst.shape[-1], src.shape[-1]
+    assert 0 <= dst_c0 and dst_c0 + nch <= Cd and 0 <= src_c0 and src_c0 + nch <= Cs
+    rows = dst.numel() // Cd
+    fn = lib().dim_add_rows if add else lib().dim_copy_rows
+    check(fn(dptr(dst, f32) + 4 * dst_c0, Cd, dptr(src, f32) + 4 * src_c0, Cs, rows, nch, current_stream()))
+    return dst
+
+
+def fill(dst, value=0.0):
+    """dst[...] = value (contiguous f32 / int32 tensor) as a kernel launch (dim_fill_words)"""
+    assert dst.is_contiguous() and dst.element_size() == 4
+    bits = struct.unpack("<I", struct.pack("<f", float(value)))[0] if dst.dtype == f32 else int(value) & 0xFFFFFFFF
+    check(lib().dim_fill_words(dptr(dst), dst.numel(), bits, current_stream()))
     return dst
 
 

@@ -49,8 +49,8 @@ class batchUpdaterPyMulti(object):
                           "valid": torch.empty((B, 1, self.height, self.width), device=d)}
             self.render_machine.reserve(B)
         b = self._bufs
-        b["se3"][:, :4].copy_(preds["rot_est_norm"])
-        b["se3"][:, 4:].copy_(preds["trans_est"])
+        ops.copy_nhwc_channels(b["se3"], 0, preds["rot_est_norm"].contiguous(), 0, 4)   # strided copies as kernels of this library
+        ops.copy_nhwc_channels(b["se3"], 4, preds["trans_est"].contiguous(), 0, 3)
         ops.se3_compose(data_batch["src_pose"], b["se3"], self.rot_coord, self.T_means, self.T_stds, out=b["pose"])
         depth = data_batch.get("depth_rendered", b["depth"])
         extra = {}
@@ -62,13 +62,14 @@ class batchUpdaterPyMulti(object):
                                          mask=data_batch["mask_rendered"] if cfg.network.INPUT_MASK else None, plane_means=self.plane_means,
                                          mask_thr=0.2, **extra)
         rot, trans = ops.se3_delta(b["pose"], data_batch["tgt_pose"], self.rot_coord, self.T_means, self.T_stds)
-        data_batch["rot"].copy_(rot)
-        data_batch["trans"].copy_(trans)
+        ops.copy(data_batch["rot"], rot)
+        ops.copy(data_batch["trans"], trans)
         if cfg.network.PRED_FLOW:
             ops.pose_to_KT(b["pose"], data_batch["tgt_pose"], self.K, out=b["KT"])
             ops.depth_to_flow(depth, data_batch["depth_gt_observed"], b["KT"], np.asarray(self.Kinv, dtype=np.float32), flow=data_batch["flow"],
                               valid=b["valid"])
-            data_batch["flow_weights"][:, 0:1].copy_(b["valid"])   # np.tile(valid, [1, 2, 1, 1]) (:352)
-            data_batch["flow_weights"][:, 1:2].copy_(b["valid"])
-        data_batch["src_pose"].copy_(b["pose"])
+            fw, va, hw = data_batch["flow_weights"].view(B, -1), b["valid"].view(B, -1), self.height * self.width
+            ops.copy_nhwc_channels(fw, 0, va, 0, hw)    # np.tile(valid, [1, 2, 1, 1]) (:352)
+            ops.copy_nhwc_channels(fw, hw, va, 0, hw)
+        ops.copy(data_batch["src_pose"], b["pose"])
         return data_batch

@@ -636,3 +636,24 @@ def test_conv_auto_split_tail_vs_f64(hip_lib, shape, tile):
     bm, bn = (128, 128) if tile == 4 else (64, 64)
     head = tb.value // (Cout // bn) * bm                           # rows of the un-split part: bit-identical to the single launch
     np.testing.assert_array_equal(y.reshape(-1, Cout)[:head], y1.reshape(-1, Cout)[:head])
+
+
+def test_copy_add_rows_and_fill(hip_lib):
+    """dim_copy_rows / dim_add_rows / dim_fill_words: channel-range copies and adds between NHWC maps with different channel counts
+    (vectorised and scalar paths), bit-exact against torch slicing."""
+    from lib.hip import ops
+
+    g = torch.Generator().manual_seed(3)
+    for cd, cs, d0, s0, n in ((1088, 512, 0, 0, 512), (832, 512, 0, 0, 512), (7, 4, 0, 0, 4), (7, 3, 4, 0, 3), (20, 9, 5, 2, 6)):
+        dst = torch.randn(2, 5, 6, cd, generator=g).to("cuda:0")
+        src = torch.randn(2, 5, 6, cs, generator=g).to("cuda:0")
+        want = dst.clone()
+        want[..., d0:d0 + n] = src[..., s0:s0 + n]
+        assert torch.equal(ops.copy_nhwc_channels(dst.clone(), d0, src, s0, n), want)
+        want = dst.clone()
+        want[..., d0:d0 + n] += src[..., s0:s0 + n]
+        assert torch.equal(ops.copy_nhwc_channels(dst.clone(), d0, src, s0, n, add=True), want)
+    t = torch.randn(1000, generator=g).to("cuda:0")
+    assert torch.equal(ops.fill(t, 0.0), torch.zeros_like(t)) and torch.equal(ops.fill(t, 2.5), torch.full_like(t, 2.5))
+    ti = torch.ones(17, dtype=torch.int32, device="cuda:0")
+    assert torch.equal(ops.fill(ti, -3), torch.full_like(ti, -3))
