@@ -198,6 +198,9 @@ int dim_conv2d_fwd_ex(const float* x, const float* w_packed, const float* bias, 
 long dim_winograd_packed_weight_floats(int Cout, int Cin, int m);
 long dim_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int m);
 int dim_winograd_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int m, void* stream);
+/* transformed weights of the INPUT gradient of the same layer (a Winograd convolution of dY with the flipped, transposed kernel: Cin
+ * output and Cout input channels), read straight from the forward (Cout, Cin, 3, 3) array; same size as dim_winograd_pack_weight's */
+int dim_winograd_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int m, void* stream);
 /* events4: NULL, or four hipEvent_t recorded on the stream before the input transform, before / after the batched GEMM and after
  * the output transform (how bench.py times the GEMM launch separately from the transforms). */
 int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,

@@ -2212,11 +2212,19 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 }
 
 // U_k = G g G^T per (co, ci), written in the 1x1 packed layout of each of the 16 GEMMs: [k][ci/32][co][ci%32]
+// DGRAD: the kernel of the input gradient, g'[ci -> co][kh][kw] = w[ci][co][2 - kh][2 - kw] read from the forward's (O, I, 3, 3) array
+// (Cout / Cin are the GEMM's: dX channels / dY channels), instead of a flipped + transposed copy made by the caller
+template <bool DGRAD>
 __global__ void wino_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)Cout * Cin) return;
   const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
-  const float* g = w + ((long)co * Cin + ci) * 9;
+  float g[9];
+  {
+    const float* gp = w + (DGRAD ? (long)ci * Cout + co : (long)co * Cin + ci) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g[i] = gp[DGRAD ? 8 - i : i];
+  }
   float Gg[4][3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -2407,14 +2415,15 @@ __device__ __forceinline__ void wino4_transform_weight(const float g[9], float* 
 }
 
 // (Cout,Cin,3,3) -> the 1x1 packed layout of each of the 36 GEMMs: [k][ci/32][co][ci%32]
+template <bool DGRAD>
 __global__ void wino4_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)Cout * Cin) return;
   const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
-  const float* gp = w + ((long)co * Cin + ci) * 9;
+  const float* gp = w + (DGRAD ? (long)ci * Cout + co : (long)co * Cin + ci) * 9;
   float g[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) g[i] = gp[i];
+  for (int i = 0; i < 9; ++i) g[i] = gp[DGRAD ? 8 - i : i];
   wino4_transform_weight(g, wp + ((long)(ci >> 5) * Cout + co) * 32 + (ci & 31), (long)Cin * Cout);
 }
 
@@ -2594,10 +2603,24 @@ int dim_winograd_pack_weight(const float* w_oihw, float* w_packed, int Cout, int
   DIM_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "Cin %% 32 == 0 and Cout %% 64 == 0 required");
   long total = (long)Cout * Cin;
   if (m == 2)
-    hipLaunchKernelGGL(wino_pack_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin);
+    hipLaunchKernelGGL(wino_pack_weight_kernel<false>, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin);
   else
-    hipLaunchKernelGGL(wino4_pack_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin);
+    hipLaunchKernelGGL(wino4_pack_weight_kernel<false>, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin);
   return check_launch("winograd_pack_weight");
+}
+
+// transformed weights of the INPUT gradient of a 3x3 / stride-1 / pad-1 layer, straight from its forward (Cout, Cin, 3, 3) array:
+// == dim_winograd_pack_weight of w.flip(2, 3).transpose(0, 1), i.e. a Winograd layer with Cin output and Cout input channels
+int dim_winograd_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int m, void* stream) {
+  DIM_REQUIRE(w_oihw && w_packed, "null weight pointer");
+  DIM_REQUIRE(m == 2 || m == 4, "output tile m must be 2 or 4");
+  DIM_REQUIRE(Cout % 32 == 0 && Cin % 64 == 0, "Cout %% 32 == 0 and Cin %% 64 == 0 required");
+  long total = (long)Cout * Cin;
+  if (m == 2)
+    hipLaunchKernelGGL(wino_pack_weight_kernel<true>, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cin, Cout);
+  else
+    hipLaunchKernelGGL(wino4_pack_weight_kernel<true>, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cin, Cout);
+  return check_launch("winograd_dgrad_pack_weight");
 }
 
 // one slice of the batch: T * planes * max(K, Cout) floats must stay below 2^32 bytes (32-bit buffer offsets in the GEMM)

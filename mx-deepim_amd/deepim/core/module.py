@@ -224,7 +224,7 @@ class MutableModule(object):
                 else:
                     net.packed[name] = net.pack_conv(w[name + "_weight"])
             if name in net.wino:
-                self.wino_dgrad[name] = ops.winograd_pack_weight(w[name + "_weight"].flip(2, 3).transpose(0, 1).contiguous(), m=net.wino_m[name])
+                self.wino_dgrad[name] = ops.winograd_dgrad_pack_weight(w[name + "_weight"], m=net.wino_m[name])
             elif name in net.wino5:  # 5x5 / stride-2 layers: input gradient through Winograd too (four phase images of dX)
                 self.wino5_dgrad[name] = ops.winograd5x5s2_dgrad_pack_weight(w[name + "_weight"])
             elif name != "flow_conv1":

@@ -81,6 +81,7 @@ SIGNATURES = {
     "dim_winograd_packed_weight_floats": (L, [I, I, I]),
     "dim_winograd_workspace_floats": (L, [I, I, I, I, I, I]),
     "dim_winograd_pack_weight": (I, [P, P, I, I, I, P]),
+    "dim_winograd_dgrad_pack_weight": (I, [P, P, I, I, I, P]),
     "dim_winograd5x5s2_packed_weight_floats": (L, [I, I]),
     "dim_winograd5x5s2_workspace_floats": (L, [I, I, I, I, I]),
     "dim_winograd5x5s2_pack_weight": (I, [P, P, I, I, P]),

@@ -282,6 +282,16 @@ def winograd_pack_weight(w_oihw, m=2):
     return out
 
 
+def winograd_dgrad_pack_weight(w_oihw, m=2):
+    """the transformed weights of the layer's INPUT gradient from its forward (Cout,Cin,3,3) array: the same array
+    winograd_pack_weight(w.flip(2, 3).transpose(0, 1)) gives, without the flipped copy"""
+    Cout, Cin, KH, KW = w_oihw.shape
+    assert KH == 3 and KW == 3 and w_oihw.is_contiguous()
+    out = _new((lib().dim_winograd_packed_weight_floats(Cin, Cout, m),), w_oihw)
+    check(lib().dim_winograd_dgrad_pack_weight(dptr(w_oihw, f32), dptr(out, f32), Cout, Cin, m, current_stream()))
+    return out
+
+
 def conv2d_fwd_winograd(x_nhwc, Cin, w_packed, bias, Cout, slope=0.1, tile=0, out=None, out_coff=0, workspace=None, events=None, m=2):
     """3x3 / stride 1 / pad 1 convolution through Winograd F(m x m, 3x3) (m = 2 or 4, the m the weights were packed with);
     x may carry padded channels (in_cstride = x.shape[-1]).

@@ -167,3 +167,15 @@ def test_deconv4x4s2_backward_via_conv_view(ops, shape):
     dw = torch.empty((Cin, Cout, 4, 4), device=DEV)
     ops.conv2d_unpack_weight(gp, dw, CoutPad=cpad)
     assert (dw.cpu().double() - w.grad).abs().max().item() <= 3e-5 * w.grad.abs().max().item() + 1e-6
+
+
+def test_winograd_dgrad_pack_weight_matches_flipped_copy(hip_lib):
+    """dim_winograd_dgrad_pack_weight == dim_winograd_pack_weight of the flipped, transposed kernel (bit for bit), m = 2 and 4"""
+    from lib.hip import ops
+
+    g = torch.Generator().manual_seed(5)
+    for cout, cin in ((64, 128), (256, 64), (512, 512)):
+        w = torch.randn(cout, cin, 3, 3, generator=g).to("cuda:0")
+        for m in (2, 4):
+            want = ops.winograd_pack_weight(w.flip(2, 3).transpose(0, 1).contiguous(), m=m)
+            assert torch.equal(ops.winograd_dgrad_pack_weight(w, m=m), want)
