@@ -2,7 +2,6 @@
 # usage: bash tools/pmc_train.sh [f32|bf16]
 set -e
 DT=${1:-bf16}
-export DIM_BF16_PATCH=${DIM_BF16_PATCH:-0}
 R=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 i=0
