@@ -31,7 +31,24 @@ struct WgradArgs {
   // whose dZ operand sits dz_plane_stride channels further in the row (0 / 0: plain convolution)
   int chunks_per_plane, dz_plane_stride;
   int bf16;  // products on v_mfma_f32_32x32x16_bf16 (conv_wgrad_bf16_kernel); the result is f32 in the same packed layout
+  int xcd;   // number the workgroups XCD-contiguously (wgrad_block below)
 };
+
+// (chunk tile, output-channel tile, pixel split) of this workgroup.  The hardware deals linear block ids round-robin to the 8 XCDs, so
+// with the chunk tile as the fastest grid index the workgroups that share one dZ tile landed on 8 different L2s; wg_xcd_contiguous
+// hands every XCD a contiguous run of the (x fastest) order instead: chunk tiles of one (channel tile, split) follow each other on
+// one XCD and find dZ -- and the next channel tile its X -- in that L2.
+__device__ __forceinline__ void wgrad_block(const WgradArgs& a, int& bx, int& by, int& bz) {
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  if (a.xcd) {
+    const int G = gridDim.x * gridDim.y * gridDim.z;
+    const int m = wg_xcd_contiguous(bx + gridDim.x * (by + gridDim.y * bz), G);
+    bx = m % gridDim.x;
+    const int t = m / gridDim.x;
+    by = t % gridDim.y;
+    bz = t / gridDim.y;
+  }
+}
 
 template <int NW, bool CIN8, int NCH>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
@@ -49,9 +66,10 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) float sX[2][BP * LDX];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kc0 = blockIdx.x * NCH;
-  const int co0 = blockIdx.y * BM;
-  const int split = blockIdx.z;
+  int bx, by, split;
+  wgrad_block(a, bx, by, split);
+  const int kc0 = bx * NCH;
+  const int co0 = by * BM;
   const int step_begin = split * a.steps_per_split;
   const int step_end = min(a.nsteps, step_begin + a.steps_per_split);
 
@@ -212,9 +230,10 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 sX[2][BP * LDX];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kc0 = blockIdx.x * NCH;
-  const int co0 = blockIdx.y * BM;
-  const int split = blockIdx.z;
+  int bx, by, split;
+  wgrad_block(a, bx, by, split);
+  const int kc0 = bx * NCH;
+  const int co0 = by * BM;
   const int step_begin = split * a.steps_per_split;
   const int step_end = min(a.nsteps, step_begin + a.steps_per_split);
 
@@ -560,6 +579,8 @@ int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, i
   DIM_REQUIRE(splits == 1 || workspace, "split wgrad needs a workspace (dim_conv2d_wgrad_workspace_floats)");
   a.dw = splits > 1 ? workspace : dw_packed;
   a.accumulate = accumulate;
+  static const int xcd_env = [] { const char* e = getenv("DIM_WGRAD_XCD"); return e ? atoi(e) : 1; }();
+  a.xcd = xcd_env;
   hipStream_t st = as_stream(stream);
   const bool nw4 = Cout % 128 == 0;
   if (a.bf16) {
