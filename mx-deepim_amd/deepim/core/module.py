@@ -152,9 +152,11 @@ class MutableModule(object):
             blocks = nchunks * (cout // 128 if cout % 128 == 0 else cout // 64)
             nsteps = -(-B * ho * wo // 32)
             sp = max(1, min(-(-4096 // blocks), max(1, nsteps // 4)))
-            if self.bf16:  # a workgroup covers four K chunks (128 packed columns); ~2048 workgroups, each at least 4 pixel steps long
+            if self.bf16:  # a workgroup covers four K chunks (128 packed columns); ~1024 workgroups, each at least 4 pixel steps long
+                # (iteration at B = 16 with the XCD-contiguous numbering, same box: target 512: 7.22 ms, 768: 7.42, 1024: 7.21, 1280: 7.22,
+                # 1536: 7.41, 2048: 7.29, 3072: 7.51, 4096: 7.71 -- 768 workgroups are resident at once)
                 blocks = -(-nchunks // 4) * (cout // 128 if cout % 128 == 0 else cout // 64)
-                sp = max(1, min(-(-2048 // blocks), max(1, nsteps // 4)))
+                sp = max(1, min(-(-1024 // blocks), max(1, nsteps // 4)))
             self.wgrad_splits[name] = sp
             max_ws = max(max_ws, ops.lib().dim_conv2d_wgrad_workspace_floats(cout, c, k, k, sp))
             max_pack = max(max_pack, ops.lib().dim_conv2d_packed_weight_floats(cout, c, k, k))
