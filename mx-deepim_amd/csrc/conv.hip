@@ -1221,7 +1221,9 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float* __res
                                                               int W, int CinPad, int in_cstride, int KH, int KW, int pad,
                                                               int out_cstride, int out_coff) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long pix = (long)blockIdx.x * 4 + wave;
+  // XCD-contiguous numbering: the four pixels of the neighbouring workgroups read the same 3x3 rows; in launch order they sit on
+  // eight different L2s
+  const long pix = (long)wg_xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * 4 + wave;
   if (pix >= (long)N * H * W) return;
   const int wo = (int)(pix % W);
   const int ho = (int)((pix / W) % H);
