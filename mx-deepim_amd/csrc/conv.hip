@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void conv1_halo_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_w = (a.Wo + TW - 1) / TW, tiles_h = (a.Ho + TH - 1) / TH;
-  int id = blockIdx.x;
+  int id = wg_xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // neighbouring tiles (shared halo) on one XCD
   const int twi = id % tiles_w;
   id /= tiles_w;
   const int thi = id % tiles_h;
@@ -2285,7 +2285,9 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     wino_gemm_zero_tile(plan, (int)(blockIdx.x - nblk) + 1);
     return;
   }
-  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  // XCD-contiguous numbering: neighbouring tiles share two of their six input rows / columns, and block ids go round-robin to the 8
+  // XCDs -- in launch order every overlap is fetched into a second L2 (PMC: 1.4x the algorithmic bytes on the fabric)
+  const unsigned idx = (unsigned)wg_xcd_contiguous((int)blockIdx.x, (int)nblk) * 256u + threadIdx.x;
   const unsigned CT = C * S * S;  // channels of V
   const unsigned CQ = CT / VEC;
   const unsigned T = (unsigned)N * th * tw;
