@@ -261,41 +261,74 @@ __global__ void small_cout_transpose_weight_kernel(const float* __restrict__ w, 
   wt[idx] = ci < Cin ? w[((long)co * Cin + ci) * taps + tap] : 0.f;
 }
 
+// Version 2: a thread keeps its 4 channels' K*K*COUT weights in registers and walks pixels.  Workgroup = a chunk of 64 consecutive
+// pixels x 64 channel quads (lane = quad, the 4 waves take every 4th pixel); the dY window of the chunk sits in LDS (broadcast
+// reads).  The first version -- one thread per (pixel, quad) -- re-loaded the 18 weight float4 per thread and was bound by the
+// vector L1 (61 us for a 120 MB read-modify-write at 16 x 30 x 40 x 770).
+template <int COUT, int K>
 __global__ __launch_bounds__(256) void conv_small_cout_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wt,
                                                                     float* __restrict__ dx, int N, int H, int W, int Cin, int CinPad,
-                                                                    int dx_cstride, int Cout, int KH, int KW, int pad, int accumulate) {
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c4n = CinPad / 4;
-  long total = (long)N * H * W * c4n;
-  if (idx >= total) return;
-  const int c0 = (int)(idx % c4n) * 4;
-  long pix = idx / c4n;
-  int x = (int)(pix % W);
-  int y = (int)((pix / W) % H);
-  int n = (int)(pix / ((long)W * H));
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int kh = 0; kh < KH; ++kh) {
-    int oy = y + pad - kh;
-    if ((unsigned)oy >= (unsigned)H) continue;
-    for (int kw = 0; kw < KW; ++kw) {
-      int ox = x + pad - kw;
-      if ((unsigned)ox >= (unsigned)W) continue;
-      const float* g = dy + ((long)(n * H + oy) * W + ox) * Cout;
-      const float* wrow = wt + ((long)(kh * KW + kw) * Cout) * CinPad + c0;
-      for (int co = 0; co < Cout; ++co) {
-        const float gv = g[co];
-        const float4 wv = *reinterpret_cast<const float4*>(wrow + (long)co * CinPad);
-        acc.x = fmaf(gv, wv.x, acc.x);
-        acc.y = fmaf(gv, wv.y, acc.y);
-        acc.z = fmaf(gv, wv.z, acc.z);
-        acc.w = fmaf(gv, wv.w, acc.w);
+                                                                    int dx_cstride, int pad, int accumulate, int chunk_px) {
+  extern __shared__ float s_dy[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long P = (long)N * H * W;
+  const long p0 = (long)blockIdx.x * chunk_px, p1 = min(P, p0 + chunk_px);
+  // dX[p] pairs with dY[p + (pad - kh) W + (pad - kw)]: window = pixels p0 - mlo .. p1 - 1 + mhi of dY
+  const int mhi = pad * W + pad, mlo = (K - 1 - pad) * W + (K - 1 - pad);
+  const int wn = (int)(p1 - p0) + mlo + mhi;
+  for (int i = threadIdx.x; i < wn * COUT; i += 256) {
+    const long pp = p0 - mlo + i / COUT;
+    s_dy[i] = (pp >= 0 && pp < P) ? dy[pp * COUT + i % COUT] : 0.f;
+  }
+  __syncthreads();
+  const int c0 = (blockIdx.y * 64 + lane) * 4;
+  if (c0 >= CinPad) return;
+  float4 wv[K * K][COUT];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) wv[t][co] = *reinterpret_cast<const float4*>(wt + ((long)t * COUT + co) * CinPad + c0);
+  const bool full = c0 + 3 < Cin;
+  for (long p = p0 + wave; p < p1; p += 4) {
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    float* o = dx + p * dx_cstride + c0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (accumulate) {
+      if (full) {
+        acc = *reinterpret_cast<const float4*>(o);
+      } else {
+        acc.x = o[0];
+        if (c0 + 1 < Cin) acc.y = o[1];
+        if (c0 + 2 < Cin) acc.z = o[2];
       }
     }
+    const int o0 = (int)(p - p0) + mlo;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+      const int kh = t / K, kw = t - kh * K;
+      const int oy = y + pad - kh, ox = x + pad - kw;
+      const bool ok = (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
+      const int oi = o0 + (pad - kh) * W + (pad - kw);
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) {
+        const float gl = s_dy[oi * COUT + co];
+        const float g = ok ? gl : 0.f;
+        s.x = fmaf(g, wv[t][co].x, s.x);
+        s.y = fmaf(g, wv[t][co].y, s.y);
+        s.z = fmaf(g, wv[t][co].z, s.z);
+        s.w = fmaf(g, wv[t][co].w, s.w);
+      }
+    }
+    acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+    if (full) {
+      *reinterpret_cast<float4*>(o) = acc;
+    } else {
+      o[0] = acc.x;
+      if (c0 + 1 < Cin) o[1] = acc.y;
+      if (c0 + 2 < Cin) o[2] = acc.z;
+    }
   }
-  float* o = dx + pix * dx_cstride + c0;
-  const float av[4] = {acc.x, acc.y, acc.z, acc.w};
-  for (int j = 0; j < 4; ++j)
-    if (c0 + j < Cin) o[j] = accumulate ? o[j] + av[j] : av[j];
 }
 
 // small-Cout conv backward, weights: dW[co][ci][kh][kw] = sum_pix dY[pix][co] * X[pix + tap][ci]; db[co] = sum_pix dY[pix][co]
@@ -660,7 +693,7 @@ int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw
                             int accumulate_dx, void* stream) {
   if (N == 0) return DIM_OK;
   DIM_REQUIRE(x && dy && w_oihw && dw_oihw && workspace, "null pointer");
-  DIM_REQUIRE(KH * KW == 9 && (Cout == 1 || Cout == 2), "small-Cout backward is built for 3x3 kernels with 1 or 2 output channels");
+  DIM_REQUIRE(KH == 3 && KW == 3 && (Cout == 1 || Cout == 2), "small-Cout backward is built for 3x3 kernels with 1 or 2 output channels");
   hipStream_t st = as_stream(stream);
   const int nchunk = ceil_div((long)N * H * W, kSmallCoutChunkPx);
   const int CinPad = (Cin + 3) / 4 * 4;
@@ -674,13 +707,19 @@ int dim_conv_small_cout_bwd(const float* x, const float* dy, const float* w_oihw
     DIM_REQUIRE(dx_cstride % 4 == 0, "dx_cstride must be a multiple of 4");
     long wtot = (long)KH * KW * Cout * CinPad;
     hipLaunchKernelGGL(small_cout_transpose_weight_kernel, dim3(ceil_div(wtot, 256)), dim3(256), 0, st, w_oihw, wt, Cout, Cin, CinPad, KH * KW);
-    long total = (long)N * H * W * (CinPad / 4);
-    hipLaunchKernelGGL(conv_small_cout_dgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, dy, wt, dx, N, H, W, Cin, CinPad,
-                       dx_cstride, Cout, KH, KW, pad, accumulate_dx);
   }
   dim3 grid(nchunk, ceil_div(CinPad, 256));
   const size_t dy_lds = (size_t)(kSmallCoutChunkPx + (KH - 1) * W + (KW - 1)) * Cout * 4;  // the chunk's dY window
   DIM_REQUIRE(dy_lds <= 65536, "small-Cout backward: image too wide for the dY window in LDS (W = %d)", W);
+  if (dx) {
+    DIM_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 15) == 0, "dx must be 16-byte aligned");
+    if (Cout == 2)
+      hipLaunchKernelGGL((conv_small_cout_dgrad_kernel<2, 3>), grid, dim3(256), dy_lds, st, dy, wt, dx, N, H, W, Cin, CinPad, dx_cstride, pad,
+                         accumulate_dx, kSmallCoutChunkPx);
+    else
+      hipLaunchKernelGGL((conv_small_cout_dgrad_kernel<1, 3>), grid, dim3(256), dy_lds, st, dy, wt, dx, N, H, W, Cin, CinPad, dx_cstride, pad,
+                         accumulate_dx, kSmallCoutChunkPx);
+  }
   if (Cout == 2)
     hipLaunchKernelGGL((conv_small_cout_wgrad_partial_kernel<2, 9>), grid, dim3(64), dy_lds, st, x, dy, partial, partial_b, N, H, W, Cin, CinPad,
                        in_cstride, KH, KW, pad, kSmallCoutChunkPx);
