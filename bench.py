@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-deadline", type=float, default=240.0, help="seconds the `train` object may take with several ranks before the line is printed without it")
     ap.add_argument("--no-fresh-batch", action="store_true", help="skip the (non-headline) `fresh_batch` object: a new batch uploaded every step")
+    ap.add_argument("--no-variants", action="store_true", help="skip the (non-headline) `full_graph` and `modelnet_lit` objects (BASELINE configs[3] / [4] per GPU)")
     ap.add_argument("--no-train", action="store_true", help="skip the (non-headline) `train` object: timed training iterations at 16 pairs per GPU")
     ap.add_argument("--train-steps", type=int, default=5, help="timed training iterations per phase for the `train` object")
     ap.add_argument("--autotune", action="store_true", help="time tile/split-K candidates per layer first (untimed); default: fixed plan")
@@ -97,6 +98,176 @@ def cpu_baseline(cfg, params, models, batch, n_pairs):
                 n_pairs, int(cfg.TEST.test_iter), dt)}
 
 
+def encoder_roofline(net, b, test_iter, profile_steps):
+    """roofline object of the dominant kernel of the network forward on the blobs `b`: HIP events on the launch stream around every
+    conv launch of `profile_steps` x `test_iter` eager forwards, grouped by kernel symbol"""
+    # ---- roofline of the dominant kernel: HIP events on the launch stream around every conv launch (eager)
+    events = {}
+    for _ in range(profile_steps):
+        for it in range(test_iter):
+            net.zoom(b)
+            net.encoder(events=events)
+            net.head()
+    torch.cuda.synchronize()
+    per_kernel = {}
+    TILE_SYM = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 128, 2, 4", 5: "128, 256, 2, 4"}
+    for name, evs in events.items():
+        info = net.layer_info[name]
+        for ev in evs:
+            tag, e0, e1 = ev[:3]
+            n_launch = ev[3] if len(ev) > 3 else 1  # auto mode: two conv launches (+ a reduce) inside one event pair
+            if tag == "conv":  # the symbol rocprofv3 --kernel-trace reports for this launch
+                if info.get("winograd"):  # batched GEMM of the Winograd path: the multiply-adds that launch really executes
+                    kname = "dim::wino_gemm_kernel<{}>".format(TILE_SYM[info["wino_tile"]])
+                    flops, nbytes = info["wino_flops"], info["wino_gemm_bytes"]
+                else:
+                    kname = "dim::conv1_halo_kernel<7, 7>" if info["tile"] == 6 else \
+                        "dim::conv_fwd_kernel<{}, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
+                    flops, nbytes = info["flops"], info["min_bytes"]
+            elif tag == "fc":  # fc6 weight stream (+ its partial-sum reduce inside the event pair)
+                kname, flops, nbytes = "dim::fc_stream_kernel", info["flops"], info["min_bytes"]
+            elif tag in ("wino_in", "wino_out"):
+                kname, flops = info["wino_in_kernel" if tag == "wino_in" else "wino_out_kernel"], 0.0
+                nbytes = info["wino_in_bytes" if tag == "wino_in" else "wino_out_bytes"]  # HBM-bound: read x + write V / read M + write y
+            else:
+                kname, flops, nbytes = "dim::splitk_reduce_kernel", 0.0, 0.0
+            k = per_kernel.setdefault(kname, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "layers": []})
+            k["ms"] += e0.elapsed_time(e1)
+            k["flops"] += flops
+            k["bytes"] += nbytes
+            k["launches"] += n_launch
+            if name not in k["layers"]:
+                k["layers"].append(name)
+    dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    nfwd = profile_steps * test_iter
+    # HBM-side bytes per launch of that kernel: cannot be read live (rocprofv3 --pmc is its own run), so the figure comes
+    # from the committed PMC passes over this same command (profiles/README.md; tools/pmc_traffic.py applies the guide's
+    # gfx950 correction 2*FETCH_SIZE + WRITE_SIZE); null when the summary is absent or is for another kernel
+    traffic, traffic_src = None, None
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        rec = json.load(open(cand)).get("kernels", {}).get(dom_name)
+        if rec:
+            traffic, traffic_src = rec["hbm_bytes_per_launch"], os.path.relpath(cand, ROOT)
+            break
+    roofline = {"bound": "mfma", "kernel": dom_name, "layers": dom["layers"], "achieved": round(achieved, 2),
+                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "bytes/launch (PMC, 2*FETCH_SIZE+WRITE_SIZE)", "traffic_source": traffic_src,
+                "min_bytes_per_launch_avg": round(dom["bytes"] / dom["launches"]),
+                "avg_launch_ms": round(dom["ms"] / dom["launches"], 4), "launches_timed": dom["launches"],
+                "gflop_per_launch_avg": round(dom["flops"] / dom["launches"] / 1e9, 3),
+                "all_kernels": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "algorithmic_GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                    "avg_launch_ms": round(v["ms"] / v["launches"], 4),
+                                    "ms_per_forward": round(v["ms"] / nfwd, 4)} for k, v in per_kernel.items()},
+                "conv_stack_ms_per_forward": round(sum(v["ms"] for v in per_kernel.values()) / nfwd, 3)}
+
+    return roofline
+
+
+def variant_bench(kind, cfg, dev, rank, steps, warmup, profile_steps, subdiv):
+    """Non-headline objects for BASELINE configs[3] / [4] at their per-GPU shape (the global sizes are 8 such ranks; ranks do not
+    interact at test time):
+      full_graph    FAST_TEST off: decoder + mask + flow heads produced every iteration (deepIM_flownet.py:840-954, read at
+                    tester.py:485-491), 8 Occlusion-LINEMOD-like classes of 20 480 triangles resident, 16 pairs, 4 iterations
+      modelnet_lit  256 gray-textured meshes resident in one HBM table, the lit renderer in the loop (tester.py:204-242,
+                    render_py_light_modelnet_multi.py:82-231), 32 pairs, 4 iterations
+    Same timing as the headline: hipGraph replays bracketed by device syncs; its own roofline entry from an eager event pass."""
+    from deepim.core.tester import Predictor, Refiner
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+    from lib.utils import synthetic as syn
+
+    keep = (cfg.TEST.FAST_TEST, list(cfg.dataset.class_name), cfg.dataset.dataset)
+    try:
+        test_iter = int(cfg.TEST.test_iter)
+        if kind == "full_graph":
+            from lib.render_hip.render_py_multi import Render_Py
+
+            n_cls, B = 8, 16
+            cfg.TEST.FAST_TEST = False
+            cfg.dataset.class_name = ["occ{:d}".format(i) for i in range(n_cls)]
+            models = syn.make_models(seed=77, n_models=n_cls, subdiv=subdiv)
+            rm = Render_Py(None, cfg.dataset.class_name, cfg.dataset.INTRINSIC_MATRIX, zNear=cfg.dataset.ZNEAR, zFar=cfg.dataset.ZFAR,
+                           device=dev, meshes=models)
+            tri = [int(m[2].shape[0]) for m in models]
+        else:
+            from lib.render_hip.render_py_light_modelnet_multi import Render_Py_Light_ModelNet_Multi, vertex_normals
+
+            n_cls, B = 256, 32
+            cfg.dataset.dataset = "ModelNet_v1"
+            cfg.dataset.class_name = ["m{:03d}".format(i) for i in range(n_cls)]
+            models = []
+            for i in range(n_cls):   # 1 280 / 5 120 triangles alternating: irregular mesh_table offsets
+                models += syn.make_models(seed=9000 + i, n_models=1, subdiv=3 + i % 2)
+            gray = np.full((32, 32, 3), 180, np.uint8)
+            meshes = [(v, vertex_normals(v, f).astype(np.float32), t, f) for v, t, f, _ in models]
+            rm = Render_Py_Light_ModelNet_Multi(None, gray, cfg.dataset.INTRINSIC_MATRIX, 640, 480, cfg.dataset.ZNEAR, cfg.dataset.ZFAR,
+                                                brightness_ratios=[0.7], meshes=meshes, device=dev)
+            tri = [int(m[3].shape[0]) for m in meshes]
+        sym = deepIM_flownet()
+        sym.get_symbol(cfg, is_train=False)
+        params = sym.init_weights(cfg, {}, {}, seed=0)
+        _rng = np.random.RandomState(1)
+        params["trans_weight"] = (_rng.randn(3, 256) * 0.02).astype(np.float32)
+        params["rot_weight"][1:] = (_rng.randn(3, 256) * 0.2).astype(np.float32)
+        if "mask_conv3_weight" in params:
+            params["mask_conv3_weight"] = (_rng.randn(1, 770, 3, 3) * 0.05).astype(np.float32)
+        pred = Predictor(cfg, params, B, device=dev)
+        batch = syn.build_device_batch(rm, B, seed=3000 + rank, n_classes=n_cls, pixel_means=cfg.network.PIXEL_MEANS, device=dev)
+        refiner = Refiner(cfg, pred, rm, B, capture_graph=True)
+        np.random.seed(99)
+        refiner.load(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"], batch["src_pose"],
+                     batch["class_index"])
+        for _ in range(warmup):
+            refiner.refine()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            refiner.refine()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        poses = refiner.poses_iter
+        res = {"value": round(B * steps / el, 2), "unit": "pose-refinements/sec", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+               "pairs_per_gpu": B, "test_iter": test_iter, "resident_classes": n_cls, "triangles_per_mesh": [min(tri), max(tri)],
+               "classes_in_batch": int(len(set(batch["class_index"].cpu().numpy().tolist()))),
+               "status_flags": int(refiner.status_iter.abs().sum().item()), "finite": bool(torch.isfinite(poses).all().item()),
+               "gflop_per_refinement": round(pred.net.flops_per_forward() * test_iter / B / 1e9, 2)}
+        # one render of the whole batch alone (HIP events on the launch stream): the rasteriser's share of a step
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        extra = {"light_intensity": refiner.light_int[0]} if refiner.lit else {}
+        kw = dict(image=refiner.batch["image_rendered"], mask=refiner.batch["mask_rendered"], bbox=refiner.bbox,
+                  plane_means=pred.net.plane_means, mask_thr=0.2, **extra)
+        rm.render_batch(batch["class_index"], poses[0], **kw)
+        e0.record()
+        for _ in range(10):
+            rm.render_batch(batch["class_index"], poses[0], **kw)
+        e1.record()
+        e1.synchronize()
+        res["render_batch_ms"] = round(e0.elapsed_time(e1) / 10.0, 4)
+        # bytes a render must move: z-buffer clear + read (2 x 8 B per pixel) + the 3 image planes and the mask plane written
+        rbytes = B * 480 * 640 * (16 + 16)
+        res["render_roofline"] = {"bound": "hbm", "achieved": round(rbytes / (res["render_batch_ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(rbytes / (res["render_batch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "bytes_per_render_batch": rbytes}
+        if kind == "full_graph":   # decoder + both heads of one forward, as one event pair
+            net = pred.net
+            net.forward_test(refiner.batch)
+            e0.record()
+            for _ in range(10):
+                net.decoder()
+                net.heads()
+            e1.record()
+            e1.synchronize()
+            res["decoder_heads_ms_per_forward"] = round(e0.elapsed_time(e1) / 10.0, 4)
+        res["roofline"] = encoder_roofline(pred.net, refiner.batch, test_iter, profile_steps)
+        for k in ("all_kernels", "traffic_unit"):
+            res["roofline"].pop(k, None)
+        del refiner, pred
+        torch.cuda.empty_cache()
+        return res
+    finally:
+        cfg.TEST.FAST_TEST, cfg.dataset.class_name, cfg.dataset.dataset = keep
+
+
 def fresh_batch_bench(cfg, rm, refiner, B, dev, steps, warmup):
     """Non-headline `fresh_batch` object: the same 4-iteration refinement, but every step takes a NEW batch from host memory through
     the data layer (deepim/core/loader.py): raw pixels as the image files hold them (8-bit BGR, 16-bit depth: 2.15 MB per pair) ->
@@ -139,7 +310,7 @@ def fresh_batch_bench(cfg, rm, refiner, B, dev, steps, warmup):
                         "dim_box_mask -> hipGraph replay; decode of image files not included"}
 
 
-def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps):
+def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps, progress=None):
     """Non-headline `train` object (BASELINE configs[2] per-GPU shape): one training iteration = train-graph forward (encoder +
     decoder + flow / mask / pose heads) + all losses + full backward + gradient all-reduce(SUM) over the ranks + SGD-momentum
     update + weight repack, 16 pairs per GPU, on a synthetic batch resident in HBM.  Phases are timed with HIP events on the
@@ -180,12 +351,22 @@ def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps):
                        "gradients, SGD momentum + repack; synthetic batch resident in HBM"}
     # f32 = the reference's precision; bf16 = BASELINE configs[2]: convolutions on the bf16 matrix pipe (f32 accumulate, f32 master
     # weights / momentum / losses / SE(3)), gradient bucket all-reduced as bf16 -- declared tolerance: tests/test_gpu_train_bf16.py
+    progress = {} if progress is None else progress
     for dtype in ("f32", "bf16"):
         mod = MutableModule(cfg, params, B, device=dev, compute_dtype=dtype)
-        r = {"forward_ms": phase_ms(lambda: mod.forward(batch)), "backward_ms": phase_ms(lambda: mod.backward(batch)),
+        progress.update(module=mod, dtype=dtype, phase="phases")
+
+        def backward_and_reduce():
+            # the phase figure includes the gradient sum: every bucket this backward hands to the collective is waited for before the
+            # next pass rewrites flat_g (the overlapped figure is the whole-iteration timing below)
+            mod.backward(batch)
+            mod._finish_allreduce()
+
+        r = {"forward_ms": phase_ms(lambda: mod.forward(batch)), "backward_ms": phase_ms(backward_and_reduce if world > 1 else (lambda: mod.backward(batch))),
              "allreduce_update_repack_ms": phase_ms(lambda: mod.update(0.0))}
         preds = mod.forward(batch)
         r["batch_updater_ms"] = phase_ms(lambda: upd.forward(batch, preds))
+        progress["phase"] = "iterations"
         mod.forward_backward(batch)
         mod.update(1e-4)
         sync()
@@ -223,6 +404,7 @@ def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps):
                                 "frac_of_bound": round(max(t_mfma, t_hbm) * 1e3 / ms, 3)}
             r["forward_conv_layers"] = layers
         res[dtype] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()}
+        progress.pop("module", None)
         del mod
     cfg.TEST.FAST_TEST = fast
     return res
@@ -230,25 +412,48 @@ def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps):
 
 def main():
     args = parse_args()
+    # `python bench.py --gpus N` is ONE command (the reference takes `--gpus 0,1,2,3` the same way, deepim/train.py:425-438): when this
+    # process is not already a rank of a torch.distributed.run job it starts the N ranks as a child job -- before anything here touches
+    # the GPU -- relays their output (rank 0 prints the JSON line) and leaves with the job's exit code.  Under an external launcher
+    # WORLD_SIZE must equal --gpus (also when it is 1): launch_ranks_if_needed raises otherwise.
+    from lib.utils.dist_utils import launch_ranks_if_needed
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    rc = launch_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus {} but WORLD_SIZE {}".format(args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the refinement path has no CPU fallback")
-    dev_index = int(os.environ.get("DIM_BENCH_DEVICE", local_rank))  # rehearsal only: several ranks on one card
-    torch.cuda.set_device(dev_index)
-    dev = "cuda:{}".format(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
-        else:
+        if args.dist_backend != "nccl":   # host-side backend: the ranks meet before anything touches a GPU
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+            dist.barrier()
+            sys.stderr.write("bench.py: rank {} of {} joined ({})\n".format(rank, world, args.dist_backend))
+            sys.stderr.flush()
+    # (torch.cuda.device_count() does not initialise the GPU on this image)
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a GPU: the refinement path has no CPU fallback")
+    if args.dist_backend == "nccl" and world > n_dev:
+        raise SystemExit("--gpus {} over RCCL needs {} GPUs, {} visible (rehearse several ranks on one card with --dist-backend gloo)".format(
+            args.gpus, world, n_dev))
+    # gloo rehearsal: more ranks than cards share the cards round-robin (DIM_BENCH_DEVICE pins all of them to one card)
+    dev_index = int(os.environ.get("DIM_BENCH_DEVICE", local_rank % n_dev))
+    torch.cuda.set_device(dev_index)
+    dev = "cuda:{}".format(dev_index)
+    if world > 1 and args.dist_backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        dist.barrier()
+        sys.stderr.write("bench.py: rank {} of {} joined (nccl = RCCL, {})\n".format(rank, world, dev))
+        sys.stderr.flush()
 
     from deepim.config.config import config as cfg, update_config
     from deepim.core.tester import Predictor, Refiner
@@ -265,7 +470,11 @@ def main():
     sym = deepIM_flownet()
     sym.get_symbol(cfg, is_train=False)
     params = sym.init_weights(cfg, {}, {}, seed=0)
-    params["trans_weight"] = (np.random.RandomState(1).randn(3, 256) * 0.002).astype(np.float32)  # non-zero head: poses move
+    # a pose head that moves the pose like a trained network (3-12 deg / 4-42 mm per iteration, tests/loop_parity.py): every re-render
+    # covers new pixels.  The reference initialisation (trans = 0, rot rows ~ U(0, 0.01)) would re-render nearly the same image.
+    _rng = np.random.RandomState(1)
+    params["trans_weight"] = (_rng.randn(3, 256) * 0.02).astype(np.float32)
+    params["rot_weight"][1:] = (_rng.randn(3, 256) * 0.2).astype(np.float32)
     models = syn.make_models(seed=2333, n_models=len(cfg.dataset.class_name), subdiv=args.subdiv)
     rm = Render_Py(None, cfg.dataset.class_name, cfg.dataset.INTRINSIC_MATRIX, zNear=cfg.dataset.ZNEAR, zFar=cfg.dataset.ZFAR,
                    device=dev, meshes=models)
@@ -298,67 +507,8 @@ def main():
         elapsed = float(t.item())
     status = int(refiner.status_iter.abs().sum().item())
 
-    # ---- roofline of the dominant kernel: HIP events on the launch stream around every conv launch (eager)
+    roofline = encoder_roofline(pred.net, refiner.batch, test_iter, args.profile_steps)
     net = pred.net
-    events = {}
-    b = refiner.batch
-    for _ in range(args.profile_steps):
-        for it in range(test_iter):
-            net.zoom(b)
-            net.encoder(events=events)
-            net.head()
-    torch.cuda.synchronize()
-    per_kernel = {}
-    TILE_SYM = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 128, 2, 4", 5: "128, 256, 2, 4"}
-    for name, evs in events.items():
-        info = net.layer_info[name]
-        for ev in evs:
-            tag, e0, e1 = ev[:3]
-            n_launch = ev[3] if len(ev) > 3 else 1  # auto mode: two conv launches (+ a reduce) inside one event pair
-            if tag == "conv":  # the symbol rocprofv3 --kernel-trace reports for this launch
-                if info.get("winograd"):  # batched GEMM of the Winograd path: the multiply-adds that launch really executes
-                    kname = "dim::wino_gemm_kernel<{}>".format(TILE_SYM[info["wino_tile"]])
-                    flops, nbytes = info["wino_flops"], info["wino_gemm_bytes"]
-                else:
-                    kname = "dim::conv1_halo_kernel<7, 7>" if info["tile"] == 6 else \
-                        "dim::conv_fwd_kernel<{}, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
-                    flops, nbytes = info["flops"], info["min_bytes"]
-            elif tag == "fc":  # fc6 weight stream (+ its partial-sum reduce inside the event pair)
-                kname, flops, nbytes = "dim::fc_stream_kernel", info["flops"], info["min_bytes"]
-            elif tag in ("wino_in", "wino_out"):
-                kname, flops = info["wino_in_kernel" if tag == "wino_in" else "wino_out_kernel"], 0.0
-                nbytes = info["wino_in_bytes" if tag == "wino_in" else "wino_out_bytes"]  # HBM-bound: read x + write V / read M + write y
-            else:
-                kname, flops, nbytes = "dim::splitk_reduce_kernel", 0.0, 0.0
-            k = per_kernel.setdefault(kname, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "layers": []})
-            k["ms"] += e0.elapsed_time(e1)
-            k["flops"] += flops
-            k["bytes"] += nbytes
-            k["launches"] += n_launch
-            if name not in k["layers"]:
-                k["layers"].append(name)
-    dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
-    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    nfwd = args.profile_steps * test_iter
-    # HBM-side bytes per launch of that kernel: cannot be read live (rocprofv3 --pmc is its own run), so the figure comes
-    # from the committed PMC passes over this same command (profiles/README.md; tools/pmc_traffic.py applies the guide's
-    # gfx950 correction 2*FETCH_SIZE + WRITE_SIZE); null when the summary is absent or is for another kernel
-    traffic, traffic_src = None, None
-    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-        rec = json.load(open(cand)).get("kernels", {}).get(dom_name)
-        if rec:
-            traffic, traffic_src = rec["hbm_bytes_per_launch"], os.path.relpath(cand, ROOT)
-            break
-    roofline = {"bound": "mfma", "kernel": dom_name, "layers": dom["layers"], "achieved": round(achieved, 2),
-                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "bytes/launch (PMC, 2*FETCH_SIZE+WRITE_SIZE)", "traffic_source": traffic_src,
-                "min_bytes_per_launch_avg": round(dom["bytes"] / dom["launches"]),
-                "avg_launch_ms": round(dom["ms"] / dom["launches"], 4), "launches_timed": dom["launches"],
-                "gflop_per_launch_avg": round(dom["flops"] / dom["launches"] / 1e9, 3),
-                "all_kernels": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "algorithmic_GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                    "avg_launch_ms": round(v["ms"] / v["launches"], 4),
-                                    "ms_per_forward": round(v["ms"] / nfwd, 4)} for k, v in per_kernel.items()},
-                "conv_stack_ms_per_forward": round(sum(v["ms"] for v in per_kernel.values()) / nfwd, 3)}
 
     total_pairs = B * world * args.steps
     value = total_pairs / elapsed
@@ -381,15 +531,23 @@ def main():
             out["fresh_batch"] = fresh_batch_bench(cfg, rm, refiner, B, dev, args.steps, args.warmup)
         except Exception as e:
             out["fresh_batch"] = {"error": "{}: {}".format(type(e).__name__, e)}
+    if world == 1 and not args.no_variants and not args.no_graph:
+        for kind in ("full_graph", "modelnet_lit"):
+            try:   # non-headline objects: a failure must not cost the headline line
+                out[kind] = variant_bench(kind, cfg, dev, rank, max(5, args.steps // 2), args.warmup, 1, args.subdiv)
+            except Exception as e:
+                out[kind] = {"error": "{}: {}".format(type(e).__name__, e)}
     if not args.no_train:
         del refiner, pred
         torch.cuda.empty_cache()
+
+        progress = {}
 
         def run_train():
             try:
                 torch.cuda.set_device(dev_index)
                 out["train"] = train_bench(cfg, models, rm, int(cfg.TRAIN.BATCH_PAIRS) if args.batch_pairs is None else B, dev, rank, world,
-                                           dist, args.train_steps)
+                                           dist, args.train_steps, progress=progress)
             except Exception as e:  # the non-headline object must never take the headline line down with it
                 out["train"] = {"error": "{}: {}".format(type(e).__name__, e)}
 
@@ -405,10 +563,22 @@ def main():
             th.start()
             th.join(args.train_deadline)
             if th.is_alive():
-                out["train"] = {"error": "no result within {} s (a collective of the training object did not complete)".format(args.train_deadline)}
+                # a hang, not a result: rank 0 still prints the headline line (measured before the training object started), every
+                # rank says what it was waiting for, and EVERY rank leaves with a non-zero code so that the launcher and the driver
+                # record the failure.  No retry, no restart in-process: kernels / RCCL work may still be in flight.
+                mod = progress.get("module")
+                pend = None
+                try:
+                    pend = [{"begin": a, "end": b, "completed": c} for a, b, c in mod.pending_buckets()] if mod is not None else None
+                except Exception as e:  # querying a wedged communicator may itself fail
+                    pend = "unavailable: {}".format(e)
+                out["train"] = {"error": "no result within {} s (a collective of the training object did not complete)".format(args.train_deadline),
+                                "rank": rank, "phase": progress.get("phase"), "dtype": progress.get("dtype"), "pending_buckets": pend}
+                sys.stderr.write("bench.py rank {}: train object hung: {}\n".format(rank, json.dumps(out["train"])))
+                sys.stderr.flush()
                 if rank == 0:
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, params, models, batch, args.cpu_pairs)
     if rank == 0:

@@ -30,7 +30,10 @@ extern "C" {
 #define DIM_OK 0
 #define DIM_ERR_ARG (-1)
 #define DIM_ERR_LAUNCH (-2)
-/* per-sample status words (device int32, OR-ed by the kernels, never cleared by them): */
+/* per-sample status words (device int32).  Contract: dim_zoom_factor OVERWRITES status[b] (0 or its two bits) -- it is the first
+ * kernel of an iteration, so a replayed loop (dim_refiner_run, Refiner._loop) starts every iteration's row clean without a fill;
+ * dim_raster_render* OR their bits into the word.  A caller of a standalone render zeroes the words first (dim_fill_words), and a
+ * caller that wants both kinds of bits in one word calls dim_zoom_factor BEFORE the render, as the loop does. */
 #define DIM_STATUS_OBS_BOX_EMPTY 1 /* dim_zoom_factor: observed box empty (the reference raises) */
 #define DIM_STATUS_REN_BOX_EMPTY 2 /* dim_zoom_factor: rendered box empty */
 #define DIM_STATUS_BAD_CLASS 4     /* dim_raster_render*: class_index outside [0, n_classes): sample rendered as background */
@@ -102,6 +105,12 @@ int dim_se3_delta(const float* pose_src, const float* pose_tgt, float* rot_quat,
 /* the same residual with the rotation as a 3x3 matrix (calc_RT_delta(..., rot_type="MATRIX"), RT_transform.py:16-48): rot_mat (B,3,3) */
 int dim_se3_delta_matrix(const float* pose_src, const float* pose_tgt, float* rot_mat, float* trans, int B, int rot_coord,
                          const float* T_means3, const float* T_stds3, void* stream);
+/* EULER deltas (RT_transform.py:139-140, :39-40: euler2mat / mat2euler with their default static-xyz axes): euler_trans6 (B,6) =
+ * [ai, aj, ak, tx, ty, tz]; rot_euler (B,3). */
+int dim_se3_compose_euler(const float* pose_src, const float* euler_trans6, float* pose_out, double* pose_out_f64, int B, int rot_coord,
+                          const float* T_means3, const float* T_stds3, void* stream);
+int dim_se3_delta_euler(const float* pose_src, const float* pose_tgt, float* rot_euler, float* trans, int B, int rot_coord,
+                        const float* T_means3, const float* T_stds3, void* stream);
 /* KT (B,3,4) = K * calc_se3(pose_src, pose_tgt): the per-sample matrix dim_depth_to_flow needs (batch_updater_py_multi.py:306-312) */
 int dim_pose_to_KT(const float* pose_src, const float* pose_tgt, const float* K9, float* KT, int B, void* stream);
 /* Transform3D custom op (transform3d.py:42-327); points/out/out_grad are (B,3,Npts). */

@@ -1756,6 +1756,8 @@ int dim_conv2d_fwd(const float* x, const float* w_packed, const float* bias, flo
 int dim_f32_to_bf16(const float* src, void* dst_bf16, long n, void* stream) {
   if (n == 0) return DIM_OK;
   DIM_REQUIRE(src && dst_bf16 && n > 0, "null pointer");
+  DIM_REQUIRE(reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst_bf16) % 8 == 0,
+              "dim_f32_to_bf16: src must be 16-byte and dst 8-byte aligned (vector accesses)");
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ceil_div((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), src,
                      reinterpret_cast<__bf16*>(dst_bf16), n);
   return check_launch("f32_to_bf16");
@@ -1764,6 +1766,8 @@ int dim_f32_to_bf16(const float* src, void* dst_bf16, long n, void* stream) {
 int dim_bf16_to_f32(const void* src_bf16, float* dst, long n, void* stream) {
   if (n == 0) return DIM_OK;
   DIM_REQUIRE(src_bf16 && dst && n > 0, "null pointer");
+  DIM_REQUIRE(reinterpret_cast<uintptr_t>(src_bf16) % 8 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0,
+              "dim_bf16_to_f32: src must be 8-byte and dst 16-byte aligned (vector accesses)");
   hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(ceil_div((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const __bf16*>(src_bf16), dst, n);
   return check_launch("bf16_to_f32");

@@ -10,6 +10,12 @@
 // Implementation-defined in GL and fixed here (same as oracle/raster.c): 8-bit sub-pixel
 // snapping, top-left fill rule, nearest or bilinear clamp-to-edge texel filter, z-fight ties
 // broken by the lower face index.
+// Near plane (GL clips primitives against zNear = 0.25, render_py_multi.py:152-169): a triangle with all vertices at Z >= zNear
+// takes the screen-space path (its fragments outside [znear, zfar] are discarded per pixel = what clipping gives for it); one wholly
+// in front of the plane is dropped; one that straddles it is clipped in CAMERA space (Sutherland-Hodgman, cut points computed from
+// the inside to the outside vertex so neighbours agree), rasterised as a fan, and shaded with camera-space barycentrics of the
+// original triangle -- its screen triangle does not exist when a vertex is behind the eye.  A refinement that diverges toward the
+// camera therefore renders what GL would, instead of losing every triangle that crosses Z = 0.
 //
 // Passes (all on one stream): clear z-buffer (u64 = depth bits << 32 | face id) -> project
 // vertices -> one thread per triangle, atomicMin per covered pixel -> resolve (textured RGB
@@ -105,10 +111,91 @@ __device__ inline float interp_z(const long long E[3], float inv_area, const flo
   return __fdiv_rn(1.0f, invz);
 }
 
+constexpr float kZClipMin = 1.0e-4f;
+constexpr float kCoordLim = 1.0e6f;
+
+// camera-space position of vertex p under pose P (3x4 row-major): the vertex pass's arithmetic, bit for bit
+__device__ inline void cam_point(const float* __restrict__ P, const float* __restrict__ p, float c[3]) {
+  c[0] = __fmaf_rn(P[0], p[0], __fmaf_rn(P[1], p[1], __fmaf_rn(P[2], p[2], P[3])));
+  c[1] = __fmaf_rn(P[4], p[0], __fmaf_rn(P[5], p[1], __fmaf_rn(P[6], p[2], P[7])));
+  c[2] = __fmaf_rn(P[8], p[0], __fmaf_rn(P[9], p[1], __fmaf_rn(P[10], p[2], P[11])));
+}
+
+// Sutherland-Hodgman against z >= zc: 0, 3 or 4 vertices in out
+__device__ inline int clip_near(const float cam[3][3], float zc, float out[4][3]) {
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float* a = cam[i];
+    const float* b = cam[(i + 1) % 3];
+    const bool ina = a[2] >= zc, inb = b[2] >= zc;
+    if (ina) { out[n][0] = a[0]; out[n][1] = a[1]; out[n][2] = a[2]; ++n; }
+    if (ina != inb) {
+      const float* pi = ina ? a : b;
+      const float* po = ina ? b : a;
+      const float tt = __fdiv_rn(__fsub_rn(zc, pi[2]), __fsub_rn(po[2], pi[2]));
+      out[n][0] = __fmaf_rn(tt, __fsub_rn(po[0], pi[0]), pi[0]);
+      out[n][1] = __fmaf_rn(tt, __fsub_rn(po[1], pi[1]), pi[1]);
+      out[n][2] = zc;
+      ++n;
+    }
+  }
+  return n;
+}
+
+// affine (camera-space) barycentrics of the point pixel (x, y) sees at depth z, w.r.t. the triangle cam; float64, un-fused
+// (-ffp-contract=off) like oracle/raster.c cam_bary
+__device__ inline void cam_bary(const float cam[3][3], int x, int y, float z, float fx, float fy, float cx, float cy, float w[3]) {
+  const double P[3] = {(double)z * (((double)x - (double)cx) / (double)fx), (double)z * (((double)y - (double)cy) / (double)fy), (double)z};
+  double e1[3], e2[3], d0[3], d1[3], d2[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    e1[k] = (double)cam[1][k] - (double)cam[0][k];
+    e2[k] = (double)cam[2][k] - (double)cam[0][k];
+    d0[k] = (double)cam[0][k] - P[k];
+    d1[k] = (double)cam[1][k] - P[k];
+    d2[k] = (double)cam[2][k] - P[k];
+  }
+  const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+  const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+  const double c0[3] = {d1[1] * d2[2] - d1[2] * d2[1], d1[2] * d2[0] - d1[0] * d2[2], d1[0] * d2[1] - d1[1] * d2[0]};
+  const double c1[3] = {d2[1] * d0[2] - d2[2] * d0[1], d2[2] * d0[0] - d2[0] * d0[2], d2[0] * d0[1] - d2[1] * d0[0]};
+  const double b0 = (c0[0] * n[0] + c0[1] * n[1] + c0[2] * n[2]) / nn;
+  const double b1 = (c1[0] * n[0] + c1[1] * n[1] + c1[2] * n[2]) / nn;
+  w[0] = (float)b0;
+  w[1] = (float)b1;
+  w[2] = (float)(1.0 - b0 - b1);
+}
+
+// one screen triangle into the z-buffer; clamp_near: a fragment of a clipped piece may round below the plane it was cut at
+__device__ inline void raster_one(const int X[3], const int Y[3], const float iz[3], int f, int H, int W, float znear, float zfar,
+                                  bool clamp_near, float zc, unsigned long long* __restrict__ zb) {
+  Edges e;
+  if (!setup_edges(X, Y, e)) return;
+  int minX = min(X[0], min(X[1], X[2])), maxX = max(X[0], max(X[1], X[2]));
+  int minY = min(Y[0], min(Y[1], Y[2])), maxY = max(Y[0], max(Y[1], Y[2]));
+  int x0 = max((minX + 255) >> 8, 0), x1 = min(maxX >> 8, W - 1);
+  int y0 = max((minY + 255) >> 8, 0), y1 = min(maxY >> 8, H - 1);
+  if (x0 > x1 || y0 > y1) return;
+  const float inv_area = __fdiv_rn(1.0f, (float)e.area);
+  for (int y = y0; y <= y1; ++y)
+    for (int x = x0; x <= x1; ++x) {
+      long long E[3];
+      if (!inside_tri(e, (long long)x * 256, (long long)y * 256, E)) continue;
+      float bw[3];
+      float z = interp_z(E, inv_area, iz, bw);
+      if (clamp_near && z < zc) z = zc;
+      if (!(z >= znear && z <= zfar)) continue;
+      unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned)f;
+      atomicMin(zb + (long)y * W + x, key);
+    }
+}
+
 __global__ __launch_bounds__(256) void raster_tri_kernel(const int* __restrict__ faces, const int* __restrict__ mesh_table,
                                                          const int* __restrict__ class_index, const float* __restrict__ scr,
-                                                         int vmax, int H, int W, float znear, float zfar, int n_classes,
-                                                         unsigned long long* __restrict__ zbuf) {
+                                                         const float* __restrict__ verts, const float* __restrict__ poses, float fx,
+                                                         float fy, float cx, float cy, int vmax, int H, int W, float znear, float zfar,
+                                                         int n_classes, unsigned long long* __restrict__ zbuf) {
   const int b = blockIdx.y;
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   const int cls = class_index[b];
@@ -119,26 +206,37 @@ __global__ __launch_bounds__(256) void raster_tri_kernel(const int* __restrict__
   const float* scr_b = scr + (long)b * vmax * 3;
   int X[3], Y[3];
   float iz[3];
-  if (!load_tri(scr_b, face, X, Y, iz)) return;
-  Edges e;
-  if (!setup_edges(X, Y, e)) return;
-  int minX = min(X[0], min(X[1], X[2])), maxX = max(X[0], max(X[1], X[2]));
-  int minY = min(Y[0], min(Y[1], Y[2])), maxY = max(Y[0], max(Y[1], Y[2]));
-  int x0 = max((minX + 255) >> 8, 0), x1 = min(maxX >> 8, W - 1);
-  int y0 = max((minY + 255) >> 8, 0), y1 = min(maxY >> 8, H - 1);
-  if (x0 > x1 || y0 > y1) return;
-  const float inv_area = __fdiv_rn(1.0f, (float)e.area);
   unsigned long long* zb = zbuf + (long)b * H * W;
-  for (int y = y0; y <= y1; ++y)
-    for (int x = x0; x <= x1; ++x) {
-      long long E[3];
-      if (!inside_tri(e, (long long)x * 256, (long long)y * 256, E)) continue;
-      float bw[3];
-      float z = interp_z(E, inv_area, iz, bw);
-      if (!(z >= znear && z <= zfar)) continue;
-      unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned)f;
-      atomicMin(zb + (long)y * W + x, key);
+  const float zc = fmaxf(znear, kZClipMin);
+  const float vz0 = scr_b[3 * (long)face[0] + 2], vz1 = scr_b[3 * (long)face[1] + 2], vz2 = scr_b[3 * (long)face[2] + 2];
+  const int nin = (int)(vz0 >= zc) + (int)(vz1 >= zc) + (int)(vz2 >= zc);
+  if (nin == 0) return;  // wholly in front of the near plane (or NaN): clipped away
+  if (nin < 3) {         // straddles the near plane: clip in camera space, rasterise the pieces (rare: a few triangles of a close object)
+    float cam[3][3], poly[4][3], su[4], sv[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cam_point(poses + 12 * b, verts + 3 * (long)(mt[0] + face[k]), cam[k]);
+    const int np = clip_near(cam, zc, poly);
+    bool ok = np >= 3;
+    for (int k = 0; k < np; ++k) {
+      su[k] = __fmaf_rn(fx, __fdiv_rn(poly[k][0], poly[k][2]), cx);
+      sv[k] = __fmaf_rn(fy, __fdiv_rn(poly[k][1], poly[k][2]), cy);
+      ok = ok && (fabsf(su[k]) < kCoordLim) && (fabsf(sv[k]) < kCoordLim);
     }
+    if (!ok) return;
+    for (int piece = 0; piece + 2 < np; ++piece) {
+      const int idx[3] = {0, piece + 1, piece + 2};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        X[k] = snap_px(su[idx[k]]);
+        Y[k] = snap_px(sv[idx[k]]);
+        iz[k] = __fdiv_rn(1.0f, poly[idx[k]][2]);
+      }
+      raster_one(X, Y, iz, f, H, W, znear, zfar, true, zc, zb);
+    }
+    return;
+  }
+  if (!load_tri(scr_b, face, X, Y, iz)) return;
+  raster_one(X, Y, iz, f, H, W, znear, zfar, false, zc, zb);
 }
 
 __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -150,12 +248,14 @@ __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > 
 //   bbox   (B,4) {min_x,max_x,min_y,max_y} of mask (pre-initialised to {W,-1,H,-1})
 // Lit (ModelNet) shading inputs, render_py_light_modelnet_multi.py:36-77: all null / unused when LIT is false
 struct LitArgs {
-  const float* verts;      // model-frame positions (same table as the vertex pass)
+  const float* verts;      // model-frame positions (same table as the vertex pass); also read for near-clipped faces
   const float* normals;    // per-vertex normals, same indexing as verts
   const float* poses;      // (B,3,4)
   const float* light_pos;  // (B,3) GL camera coordinates
   const float* light_int;  // (B,3)
   float ratio;             // brightness_ratio
+  float fx, fy, cx, cy;    // pinhole (near-clipped faces: pixel -> camera-space point)
+  float zclip;             // max(znear, kZClipMin): a face with a vertex in front of it was clipped by the triangle pass
 };
 
 // Colour of pixel (x, y) of sample b whose z-buffer key names face f (the heavy path: exact edge functions again, perspective-correct
@@ -164,28 +264,39 @@ template <bool LIT>
 __device__ __forceinline__ bool shade_pixel(const LitArgs& lit, const float* __restrict__ uvs, const int* __restrict__ faces,
                                             const int* __restrict__ mesh_table, const unsigned char* __restrict__ tex,
                                             const int* __restrict__ tex_table, int cls, const float* __restrict__ scr_b, int b, int x, int y,
-                                            unsigned f_id, float z, int tex_bilinear, float& r, float& g, float& bl) {
+                                            unsigned f_id, float z_key, int tex_bilinear, float& r, float& g, float& bl) {
   const int* mt = mesh_table + 4 * cls;
   if (f_id >= (unsigned)mt[3]) return false;
   const int f = (int)f_id;
   const int* face = faces + 3 * (long)(mt[2] + f);
   int X[3], Y[3];
   float iz[3], tu[3], tv[3];
-  load_tri(scr_b, face, X, Y, iz);
+  bool clipped = false;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float* uv = uvs + 2 * (long)(mt[0] + face[k]);
     tu[k] = uv[0];
     tv[k] = uv[1];
+    clipped = clipped || !(scr_b[3 * (long)face[k] + 2] >= lit.zclip);
   }
-  Edges e;
-  long long E[3];
-  setup_edges(X, Y, e);
-  inside_tri(e, (long long)x * 256, (long long)y * 256, E);
-  const float inv_area = __fdiv_rn(1.0f, (float)e.area);
-  float bw[3];
-  interp_z(E, inv_area, iz, bw);
-  float w0 = __fmul_rn(bw[0], iz[0]), w1 = __fmul_rn(bw[1], iz[1]), w2 = __fmul_rn(bw[2], iz[2]);
+  float w0, w1, w2, z;  // attribute = (w2 a2 + (w1 a1 + w0 a0)) * z
+  if (clipped) {        // a piece of a near-clipped triangle: camera-space barycentrics of the ORIGINAL triangle
+    float cam[3][3], wb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cam_point(lit.poses + 12 * b, lit.verts + 3 * (long)(mt[0] + face[k]), cam[k]);
+    cam_bary(cam, x, y, z_key, lit.fx, lit.fy, lit.cx, lit.cy, wb);
+    w0 = wb[0]; w1 = wb[1]; w2 = wb[2]; z = 1.0f;
+  } else {
+    load_tri(scr_b, face, X, Y, iz);
+    Edges e;
+    long long E[3];
+    setup_edges(X, Y, e);
+    inside_tri(e, (long long)x * 256, (long long)y * 256, E);
+    const float inv_area = __fdiv_rn(1.0f, (float)e.area);
+    float bw[3];
+    interp_z(E, inv_area, iz, bw);
+    w0 = __fmul_rn(bw[0], iz[0]); w1 = __fmul_rn(bw[1], iz[1]); w2 = __fmul_rn(bw[2], iz[2]); z = z_key;
+  }
   float u = __fmul_rn(__fmaf_rn(w2, tu[2], __fmaf_rn(w1, tu[1], __fmul_rn(w0, tu[0]))), z);
   float v = __fmul_rn(__fmaf_rn(w2, tv[2], __fmaf_rn(w1, tv[1], __fmul_rn(w0, tv[0]))), z);
   const int* tt = tex_table + 3 * cls;
@@ -576,11 +687,11 @@ static int raster_render_impl(const float* verts, const float* normals, const fl
                      (int)((reinterpret_cast<uintptr_t>(workspace) & 15) == 0));
   hipLaunchKernelGGL(raster_vertex_kernel, dim3(ceil_div(vmax, 256), B), dim3(256), 0, st, verts, mesh_table, class_index, poses,
                      K9[0], K9[4], K9[2], K9[5], vmax, n_classes, status, scr);
-  hipLaunchKernelGGL(raster_tri_kernel, dim3(ceil_div(fmax, 256), B), dim3(256), 0, st, faces, mesh_table, class_index, scr, vmax, H,
-                     W, znear, zfar, n_classes, zbuf);
+  hipLaunchKernelGGL(raster_tri_kernel, dim3(ceil_div(fmax, 256), B), dim3(256), 0, st, faces, mesh_table, class_index, scr, verts, poses,
+                     K9[0], K9[4], K9[2], K9[5], vmax, H, W, znear, zfar, n_classes, zbuf);
   hipLaunchKernelGGL(raster_init_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, bbox, B, H, W, hdr);
   float p0 = plane_means3 ? plane_means3[0] : 0.f, p1 = plane_means3 ? plane_means3[1] : 0.f, p2 = plane_means3 ? plane_means3[2] : 0.f;
-  LitArgs lit = {verts, normals, poses, light_pos, light_int, ratio};
+  LitArgs lit = {verts, normals, poses, light_pos, light_int, ratio, K9[0], K9[4], K9[2], K9[5], fmaxf(znear, kZClipMin)};
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   // the two-pass resolve moves float4 / 2 x u64: every plane pointer (and the workspace) must be 16-byte aligned; anything else
   // takes the one-thread-per-pixel kernel

@@ -165,7 +165,10 @@ int dim_refiner_create(dim_refiner** out, const dim_refiner_desc* desc, const ch
     }
     h = P.ho; w = P.wo; c = ly.cout;
   }
-  DIM_REQUIRE(h == 8 && w == 10 && c == 1024, "encoder geometry");
+  if (!(h == 8 && w == 10 && c == 1024)) {
+    dim_refiner_destroy(r);
+    return set_err(DIM_ERR_ARG, "encoder geometry");
+  }
   // ---- heads
   const float* fc6w = need("fc6_weight");
   r->fc6_b = const_cast<float*>(need("fc6_bias"));

@@ -51,23 +51,53 @@ __device__ inline void mat2quat_d(const double M[9], double q[4]) {
   q[0] = w / n; q[1] = x / n; q[2] = y / n; q[3] = z / n;
 }
 
-// pose_out[b] = RT_transform(pose_src[b], se3[b,0:4], se3[b,4:7])
+// Euler angles of the reference's EULER deltas: euler2mat / mat2euler with their default axes "sxyz" (RT_transform.py:250-383; the only
+// convention RT_transform :139-140 and calc_RT_delta :39-40 use): rotations about the STATIC x, y, z axes in that order,
+// M = Rz(ak) Ry(aj) Rx(ai).
+__device__ inline void euler2mat_d(double ai, double aj, double ak, double M[9]) {
+  double si = sin(ai), ci = cos(ai), sj = sin(aj), cj = cos(aj), sk = sin(ak), ck = cos(ak);
+  M[0] = cj * ck; M[1] = sj * si * ck - ci * sk; M[2] = sj * ci * ck + si * sk;
+  M[3] = cj * sk; M[4] = sj * si * sk + ci * ck; M[5] = sj * ci * sk - si * ck;
+  M[6] = -sj;     M[7] = cj * si;                M[8] = cj * ci;
+}
+
+// inverse; at the gimbal lock (cos(aj) < 4 eps) the third angle is set to zero like the reference does (:370-377)
+__device__ inline void mat2euler_d(const double M[9], double e[3]) {
+  double cy = sqrt(M[0] * M[0] + M[3] * M[3]);
+  if (cy > 4.0 * 2.220446049250313e-16) {
+    e[0] = atan2(M[7], M[8]);
+    e[1] = atan2(-M[6], cy);
+    e[2] = atan2(M[3], M[0]);
+  } else {
+    e[0] = atan2(-M[5], M[4]);
+    e[1] = atan2(-M[6], cy);
+    e[2] = 0.0;
+  }
+}
+
+// pose_out[b] = RT_transform(pose_src[b], se3[b,0:4], se3[b,4:7]); EULER: se3 rows are [ai, aj, ak, t] (6 floats)
+template <bool EULER>
 __global__ void se3_compose_kernel(const float* __restrict__ pose_src, const float* __restrict__ se3, float* __restrict__ pose_out,
                                    double* __restrict__ pose_out_f64, int B, int rot_coord, double m0, double m1, double m2,
                                    double s0, double s1, double s2) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float* ps = pose_src + 12 * b;
-  const float* d = se3 + 7 * b;
-  double q[4] = {d[0], d[1], d[2], d[3]};
-  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);  // LA.norm
-  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+  const float* d = se3 + (EULER ? 6 : 7) * b;
   double Rd[9], Rs[9], Ro[9], To[3];
-  quat2mat_d(q, Rd);
+  if (EULER) {
+    euler2mat_d(d[0], d[1], d[2], Rd);
+  } else {
+    double q[4] = {d[0], d[1], d[2], d[3]};
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);  // LA.norm
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+    quat2mat_d(q, Rd);
+  }
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) Rs[3 * i + j] = ps[4 * i + j];
   double Ts[3] = {ps[3], ps[7], ps[11]};
-  double td[3] = {(double)d[4], (double)d[5], (double)d[6]};
+  const float* dt = d + (EULER ? 3 : 4);
+  double td[3] = {(double)dt[0], (double)dt[1], (double)dt[2]};
   if (rot_coord == ROT_NAIVE) {
     // se3_mul(se3_mx, pose_src): R = Rd*Rs, T = Rd*Ts + t   (float32 result in the reference)
     mat3_mul(Rd, Rs, Ro);
@@ -99,9 +129,10 @@ __global__ void se3_compose_kernel(const float* __restrict__ pose_src, const flo
 
 // (rot_delta quat (B,4), trans_delta (B,3)) = calc_RT_delta(pose_src, pose_tgt, rot_type="QUAT")
 // rot_mat (B,3,3), optional: the same delta as a rotation matrix (rot_type="MATRIX"); rot (quaternion) may then be null
+// rot_euler (B,3), optional: the same delta as static-xyz Euler angles (rot_type="EULER")
 __global__ void se3_delta_kernel(const float* __restrict__ pose_src, const float* __restrict__ pose_tgt, float* __restrict__ rot,
-                                 float* __restrict__ rot_mat, float* __restrict__ trans, int B, int rot_coord, double m0, double m1, double m2, double s0,
-                                 double s1, double s2) {
+                                 float* __restrict__ rot_mat, float* __restrict__ rot_euler, float* __restrict__ trans, int B, int rot_coord,
+                                 double m0, double m1, double m2, double s0, double s1, double s2) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float* ps = pose_src + 12 * b;
@@ -146,6 +177,11 @@ __global__ void se3_delta_kernel(const float* __restrict__ pose_src, const float
   }
   if (rot_mat)
     for (int i = 0; i < 9; ++i) rot_mat[9 * b + i] = (float)Rd[i];
+  if (rot_euler) {
+    double e[3];
+    mat2euler_d(Rd, e);
+    for (int i = 0; i < 3; ++i) rot_euler[3 * b + i] = (float)e[i];
+  }
   for (int i = 0; i < 3; ++i) trans[3 * b + i] = (float)dT[i];
 }
 
@@ -361,10 +397,32 @@ int dim_se3_compose(const float* pose_src, const float* se3, float* pose_out, do
   if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(pose_src && se3 && pose_out && T_means3 && T_stds3, "null pointer");
   DIM_REQUIRE(parse_rot(rot_coord) >= 0, "unknown rot_coord %d", rot_coord);
-  hipLaunchKernelGGL(se3_compose_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, se3, pose_out,
+  hipLaunchKernelGGL(se3_compose_kernel<false>, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, se3, pose_out,
                      pose_out_f64, B, rot_coord, (double)T_means3[0], (double)T_means3[1], (double)T_means3[2], (double)T_stds3[0],
                      (double)T_stds3[1], (double)T_stds3[2]);
   return check_launch("se3_compose");
+}
+
+int dim_se3_compose_euler(const float* pose_src, const float* euler_trans6, float* pose_out, double* pose_out_f64, int B, int rot_coord,
+                          const float* T_means3, const float* T_stds3, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(pose_src && euler_trans6 && pose_out && T_means3 && T_stds3, "null pointer");
+  DIM_REQUIRE(parse_rot(rot_coord) >= 0, "unknown rot_coord %d", rot_coord);
+  hipLaunchKernelGGL(se3_compose_kernel<true>, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, euler_trans6, pose_out,
+                     pose_out_f64, B, rot_coord, (double)T_means3[0], (double)T_means3[1], (double)T_means3[2], (double)T_stds3[0],
+                     (double)T_stds3[1], (double)T_stds3[2]);
+  return check_launch("se3_compose_euler");
+}
+
+int dim_se3_delta_euler(const float* pose_src, const float* pose_tgt, float* rot_euler, float* trans, int B, int rot_coord,
+                        const float* T_means3, const float* T_stds3, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(pose_src && pose_tgt && rot_euler && trans && T_means3 && T_stds3, "null pointer");
+  DIM_REQUIRE(parse_rot(rot_coord) >= 0, "unknown rot_coord %d", rot_coord);
+  hipLaunchKernelGGL(se3_delta_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, pose_tgt, nullptr, nullptr, rot_euler,
+                     trans, B, rot_coord, (double)T_means3[0], (double)T_means3[1], (double)T_means3[2], (double)T_stds3[0],
+                     (double)T_stds3[1], (double)T_stds3[2]);
+  return check_launch("se3_delta_euler");
 }
 
 int dim_se3_delta(const float* pose_src, const float* pose_tgt, float* rot_quat, float* trans, int B, int rot_coord,
@@ -372,7 +430,7 @@ int dim_se3_delta(const float* pose_src, const float* pose_tgt, float* rot_quat,
   if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(pose_src && pose_tgt && rot_quat && trans && T_means3 && T_stds3, "null pointer");
   DIM_REQUIRE(parse_rot(rot_coord) >= 0, "unknown rot_coord %d", rot_coord);
-  hipLaunchKernelGGL(se3_delta_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, pose_tgt, rot_quat, nullptr, trans,
+  hipLaunchKernelGGL(se3_delta_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, pose_tgt, rot_quat, nullptr, nullptr, trans,
                      B, rot_coord, (double)T_means3[0], (double)T_means3[1], (double)T_means3[2], (double)T_stds3[0],
                      (double)T_stds3[1], (double)T_stds3[2]);
   return check_launch("se3_delta");
@@ -383,7 +441,7 @@ int dim_se3_delta_matrix(const float* pose_src, const float* pose_tgt, float* ro
   if (B == 0) return DIM_OK;
   DIM_REQUIRE(pose_src && pose_tgt && rot_mat && trans && T_means3 && T_stds3, "null pointer");
   DIM_REQUIRE(parse_rot(rot_coord) >= 0, "unknown rot_coord %d", rot_coord);
-  hipLaunchKernelGGL(se3_delta_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, pose_tgt, nullptr, rot_mat, trans,
+  hipLaunchKernelGGL(se3_delta_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), pose_src, pose_tgt, nullptr, rot_mat, nullptr, trans,
                      B, rot_coord, (double)T_means3[0], (double)T_means3[1], (double)T_means3[2], (double)T_stds3[0],
                      (double)T_stds3[1], (double)T_stds3[2]);
   return check_launch("se3_delta_matrix");

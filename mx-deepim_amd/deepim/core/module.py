@@ -71,31 +71,36 @@ class MutableModule(object):
         self.names = wnames + [n for n in keys if n not in FROZEN and not n.endswith("_weight")] + [n for n in keys if n in FROZEN]
         self.shapes = shapes
         sizes = [int(np.prod(shapes[n])) for n in self.names]
-        total = sum(sizes)
-        self.flat_w = torch.empty(total, dtype=torch.float32, device=d)
+        # every tensor starts on a 128-byte boundary of the flat vectors (32 floats; 64 B in the bf16 bucket image): the vector kernels
+        # (f32 <-> bf16, SGD / Adam: 16-byte accesses) and RCCL's aligned path need it for bucket and segment starts, and the sum of
+        # the head + decoder + fc6 sizes is 2 mod 4.  The gaps hold zeros in all three vectors and stay zero under SGD and Adam.
+        ALIGN = 32
+        padded = [-(-sz // ALIGN) * ALIGN for sz in sizes]
+        total = sum(padded)
+        self.flat_w = torch.zeros(total, dtype=torch.float32, device=d)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=d)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=d)
         self.flat_v = None  # second Adam state, allocated on first use
         self.flat_g16 = None  # bf16 image of the gradient bucket (bf16 mode, more than one rank)
         self.force_bf16_bucket = False  # tests: round the bucket through bf16 in a single process too
         self.w, self.g, self.m = {}, {}, {}
-        self.n_weight = sum(sz for n, sz in zip(self.names, sizes) if n not in FROZEN and n.endswith("_weight"))
-        self.n_bias = sum(sz for n, sz in zip(self.names, sizes) if n not in FROZEN and not n.endswith("_weight"))
+        self.n_weight = sum(sz for n, sz in zip(self.names, padded) if n not in FROZEN and n.endswith("_weight"))
+        self.n_bias = sum(sz for n, sz in zip(self.names, padded) if n not in FROZEN and not n.endswith("_weight"))
         off = 0
         off_of = {}
-        for n, sz in zip(self.names, sizes):
+        for n, sz, psz in zip(self.names, sizes, padded):
             off_of[n] = off
             self.w[n] = self.flat_w[off:off + sz].view(shapes[n])
             self.g[n] = self.flat_g[off:off + sz].view(shapes[n])
             self.m[n] = self.flat_m[off:off + sz].view(shapes[n])
             self.w[n].copy_(torch.as_tensor(np.ascontiguousarray(arg_params[n]), dtype=torch.float32))
-            off += sz
+            off += psz
         # ---- forward executor shares the master tensors (params dict = views of flat_w)
         self.net = FlowNetHip.__new__(FlowNetHip)
         # gradient buckets [begin, end) of the flat vector, in backward order; the last one also carries the biases; frozen tensors
         # (zero gradient, never updated) are not sent at all
         self.overlap_allreduce = bool(overlap_allreduce)
-        ends = [off_of[n] + int(np.prod(shapes[n])) for n in BUCKET_ENDS if n in off_of] + [self.n_weight + self.n_bias]
+        ends = [-(-(off_of[n] + int(np.prod(shapes[n]))) // ALIGN) * ALIGN for n in BUCKET_ENDS if n in off_of] + [self.n_weight + self.n_bias]
         self.buckets = [(a, b) for a, b in zip([0] + ends[:-1], ends) if b > a]
         self._pending = []      # (work handle or None, begin, end) of the buckets already handed to the collective
         self._next_bucket = 0
@@ -293,6 +298,11 @@ class MutableModule(object):
         cfg, net, w, g = self.cfg, self.net, self.w, self.g
         ti = cfg.train_iter
         B = self.B
+        # collectives of a previous backward() that no update() consumed still read / write flat_g (flat_g16) in place on the
+        # communicator's stream: wait for them before this pass rewrites the gradients
+        for work, _, _ in self._pending:
+            if work is not None:
+                work.wait()
         self._pending, self._next_bucket = [], 0
         ops.fill(self.loss_sums, 0.0)
         # ---------------- loss gradients (get_loss :344-357, :446-499, :531-536)
@@ -417,6 +427,11 @@ class MutableModule(object):
         if self.world_size() == 1:
             return None
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def pending_buckets(self):
+        """[(begin, end, completed)] of the buckets handed to the collective and not yet consumed by update() -- for a watchdog
+        that has to say WHICH transfer never finished"""
+        return [(a, b, True if w is None else bool(w.is_completed())) for w, a, b in self._pending]
 
     def _finish_allreduce(self):
         """every bucket summed over the ranks and back in flat_g as fp32 (buckets not started yet -- overlap off, or update() without

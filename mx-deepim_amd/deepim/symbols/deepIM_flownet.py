@@ -516,4 +516,6 @@ class FlowNetHip(object):
             total += h * w * cout * c * k * k
             c = cout
         total += 81920 * 256 + 256 * 256 + 256 * 7
+        if self.has_decoder and not self.cfg.TEST.FAST_TEST and (self.cfg.network.PRED_MASK or self.cfg.network.PRED_FLOW):
+            total += 1967511120   # decoder + flow / mask heads (SURVEY.md 8a layer table: 3.94 GFLOP per pair and forward)
         return 2 * total * self.B

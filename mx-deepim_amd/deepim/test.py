@@ -4,8 +4,9 @@ Flow of test_deepim (:58-215): update_config -> logger -> symbol -> load_param(p
 pred_eval (4-iteration refinement, result cache, evaluate_pose / _add / _arp_2d).
 Differences, all forced by the environment: the LINEMOD / ModelNet dataset classes are out of scope and no data is present, so the
 pairs come from lib/dataset/synthetic_pairs.py (`--num_pairs`); if `<prefix>-<epoch>.params` does not exist the network runs with
-the seeded initialisation (stated in the log); one process drives ONE GPU (`--gpus` names it) -- for several GPUs launch the script
-under `python -m torch.distributed.run --nproc-per-node N` and every rank refines its shard of the pairs."""
+the seeded initialisation (stated in the log); one process drives ONE GPU: `--gpus 0,1,2,3` starts one rank per named GPU as a
+child torch.distributed.run job (or launch the script under `python -m torch.distributed.run --nproc-per-node N` yourself) and every
+rank refines its shard of the pairs."""
 from __future__ import print_function, division
 
 import _init_paths  # noqa: F401
@@ -13,6 +14,7 @@ import _init_paths  # noqa: F401
 import argparse
 import os
 import pprint
+import sys
 
 from deepim.config.config import config, update_config
 
@@ -93,6 +95,13 @@ def test_deepim(args):
 def main():
     args = parse_args()
     print(args)
+    # `--gpus 0,1,2,3` in ONE command, as the reference takes it (train.py:425-438): this process starts one rank per named GPU as a
+    # child torch.distributed.run job (before anything touches the GPU) and leaves with its exit code
+    from lib.utils.dist_utils import launch_ranks_if_needed
+
+    rc = launch_ranks_if_needed(len(args.gpus.split(",")), os.path.abspath(__file__), sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
     test_deepim(args)
 
 

@@ -3,8 +3,9 @@
 Flow of train_net (:60-420): update_config -> logger -> symbol + init_weights (pretrained FlowNet checkpoint if present) ->
 MutableModule -> metrics + Speedometer -> WarmupMultiFactorScheduler (with the resume rule) -> epochs of `fit_batch` (forward,
 batch updater, backward, gradient sum over ranks, optimizer) -> epoch-end checkpoint `prefix-%04d.params` + optimizer states.
-As in deepim/test.py the pairs are synthetic (`--num_pairs` per epoch), one process drives one GPU and several GPUs run under
-torch.distributed.run (gradients are summed with one RCCL all-reduce per update, the kvstore='device' semantics)."""
+As in deepim/test.py the pairs are synthetic (`--num_pairs` per epoch); one process drives one GPU: `--gpus 0,1,2,3` starts one rank
+per named GPU as a child torch.distributed.run job (gradients are summed with RCCL all-reduces per update, the kvstore='device'
+semantics)."""
 from __future__ import print_function, division
 
 import _init_paths  # noqa: F401
@@ -12,6 +13,7 @@ import _init_paths  # noqa: F401
 import argparse
 import os
 import pprint
+import sys
 
 from deepim.config.config import config, update_config
 
@@ -141,6 +143,13 @@ def train_net(args):
 def main():
     args = parse_args()
     print("Called with argument:", args)
+    # `--gpus 0,1,2,3` in ONE command, as the reference takes it (train.py:425-438): this process starts one rank per named GPU as a
+    # child torch.distributed.run job (before anything touches the GPU) and leaves with its exit code
+    from lib.utils.dist_utils import launch_ranks_if_needed
+
+    rc = launch_ranks_if_needed(len(args.gpus.split(",")), os.path.abspath(__file__), sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
     train_net(args)
 
 

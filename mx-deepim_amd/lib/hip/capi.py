@@ -30,6 +30,8 @@ SIGNATURES = {
     "dim_se3_compose": (I, [P, P, P, P, I, I, P, P, P]),
     "dim_se3_delta": (I, [P, P, P, P, I, I, P, P, P]),
     "dim_se3_delta_matrix": (I, [P, P, P, P, I, I, P, P, P]),
+    "dim_se3_compose_euler": (I, [P, P, P, P, I, I, P, P, P]),
+    "dim_se3_delta_euler": (I, [P, P, P, P, I, I, P, P, P]),
     "dim_pose_to_KT": (I, [P, P, P, P, I, P]),
     "dim_transform3d_fwd": (I, [P, P, P, P, P, I, I, I, P, P, P]),
     "dim_transform3d_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P, P]),

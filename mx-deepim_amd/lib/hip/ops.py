@@ -130,6 +130,29 @@ def se3_delta_matrix(pose_src, pose_tgt, rot_coord, T_means, T_stds):
     return rot, trans
 
 
+def se3_compose_euler(pose_src, euler_trans6, rot_coord, T_means, T_stds, out=None, out_f64=None):
+    """RT_transform with a 3-number EULER rotation delta: euler_trans6 (B,6) = [ai, aj, ak, t]"""
+    B = pose_src.shape[0]
+    out = out if out is not None else torch.empty_like(pose_src)
+    k1, mp = host_f32(T_means, 3)
+    k2, sp = host_f32(T_stds, 3)
+    check(lib().dim_se3_compose_euler(dptr(pose_src, f32), dptr(euler_trans6, f32), dptr(out, f32), dptr(out_f64, torch.float64), B,
+                                      capi.rot_coord_id(rot_coord), mp, sp, current_stream()))
+    return out
+
+
+def se3_delta_euler(pose_src, pose_tgt, rot_coord, T_means, T_stds):
+    """-> (static-xyz Euler angles (B,3), translation residual (B,3)): calc_RT_delta(..., rot_type="EULER")"""
+    B = pose_src.shape[0]
+    rot = _new((B, 3), pose_src)
+    trans = _new((B, 3), pose_src)
+    k1, mp = host_f32(T_means, 3)
+    k2, sp = host_f32(T_stds, 3)
+    check(lib().dim_se3_delta_euler(dptr(pose_src, f32), dptr(pose_tgt, f32), dptr(rot, f32), dptr(trans, f32), B,
+                                    capi.rot_coord_id(rot_coord), mp, sp, current_stream()))
+    return rot, trans
+
+
 def transform3d_fwd(points, rot, trans, pose_src, rot_coord, T_means, T_stds, out=None):
     B = points.shape[0]
     npts = points.numel() // (B * 3) if B else 0

@@ -26,17 +26,18 @@ def _dev(a, device):
 
 def RT_transform(pose_src, r, t, T_means, T_stds, rot_coord="MODEL", device="cuda:0"):
     r = np.squeeze(r)
-    if r.shape[0] != 4:
-        raise Exception("Unknown r shape: {}".format(r.shape)) if r.shape[0] != 3 else Exception("EULER deltas are not on the HIP path")
-    se3 = np.concatenate([r, np.squeeze(t)]).reshape(1, 7)
+    if r.shape[0] not in (3, 4):   # 4 numbers: quaternion, 3: Euler angles (reference :138-146)
+        raise Exception("Unknown r shape: {}".format(r.shape))
+    se3 = np.concatenate([r, np.squeeze(t)]).reshape(1, r.shape[0] + 3)
     out64 = torch.empty((1, 3, 4), dtype=torch.float64, device=device)
-    RT_transform_batch(_dev(np.asarray(pose_src).reshape(1, 3, 4), device), _dev(se3, device), T_means, T_stds, rot_coord, out_f64=out64)
+    compose = ops.se3_compose if r.shape[0] == 4 else ops.se3_compose_euler
+    compose(_dev(np.asarray(pose_src).reshape(1, 3, 4), device), _dev(se3, device), rot_coord, T_means, T_stds, out_f64=out64)
     return out64[0].cpu().numpy()
 
 
 def calc_RT_delta(pose_src, pose_tgt, T_means, T_stds, rot_coord="MODEL", rot_type="MATRIX", device="cuda:0"):
-    """reference :16-48.  rot_type "quat" -> (w,x,y,z) with w >= 0, "matrix" -> the 3x3 residual rotation (the default there);
-    "euler" is not built (no shipped configuration uses it)."""
+    """reference :16-48.  rot_type "quat" -> (w,x,y,z) with w >= 0, "matrix" -> the 3x3 residual rotation (the default there),
+    "euler" -> the three static-xyz angles of mat2euler (:320-383)."""
     kind = rot_type.lower()
     ps, pt = _dev(np.asarray(pose_src).reshape(1, 3, 4), device), _dev(np.asarray(pose_tgt).reshape(1, 3, 4), device)
     if kind == "quat":
@@ -44,7 +45,7 @@ def calc_RT_delta(pose_src, pose_tgt, T_means, T_stds, rot_coord="MODEL", rot_ty
     elif kind == "matrix":
         r, t = ops.se3_delta_matrix(ps, pt, rot_coord, T_means, T_stds)
     elif kind == "euler":
-        raise Exception("rot_type 'EULER' is not on the HIP path (QUAT and MATRIX are)")
+        r, t = ops.se3_delta_euler(ps, pt, rot_coord, T_means, T_stds)
     else:
         raise Exception("Unknown rot_type: {}".format(rot_type))
     return r[0].cpu().numpy(), t[0].cpu().numpy()

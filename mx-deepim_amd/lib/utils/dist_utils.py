@@ -5,8 +5,48 @@ experiments/deepim/deepim_train_test.py:12) with ONE all-reduce(SUM) of the flat
 mean, because the reference sums gradients over GPUs and samples (rescale_grad = 1.0, deepim/train.py:383).
 Inference shards the independent (observed, rendered) pairs across ranks with no data-path collective.
 """
+import os
+import socket
+import subprocess
+import sys
+
 import torch
 import torch.distributed as dist
+
+
+def _free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks_if_needed(n_ranks, script, argv, extra_env=None):
+    """One command drives several GPUs, like the reference's `--gpus 0,1,2,3` (deepim/train.py:425-438 builds one executor per
+    context inside one process, DataParallelExecutorGroup.py:303-319).  Here it is one PROCESS per GPU: when `n_ranks` > 1 and this
+    process is not already a rank of a torch.distributed.run job (WORLD_SIZE unset), start that job -- `python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node n_ranks --master-addr 127.0.0.1 --master-port <free> script argv` -- as a
+    CHILD process, relay its output and return its exit code; the caller exits with it.  Returns None when there is nothing to launch.
+    Must be called before anything initialises the GPU (a process that touched the GPU must never exec or fork workers on this pool);
+    counting devices does not initialise it."""
+    if n_ranks <= 1:
+        return None
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != n_ranks:
+            raise SystemExit("{} GPUs / ranks requested but WORLD_SIZE is {}: launch with --nproc-per-node {} (or unset WORLD_SIZE and "
+                             "let this script start its own ranks)".format(n_ranks, world, n_ranks))
+        return None
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_ranks) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script] + list(argv)
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
 
 
 def is_distributed():

@@ -20,8 +20,13 @@
  * length(normal) again so the vec4 normalisation cancels).  The 8-bit framebuffer quantises the clamped colour
  * with round-to-nearest (:211-214 reads it back as float and rounds again, a no-op).
  *
- * Geometric near-plane clipping is not implemented: triangles with a vertex at Z<=1e-6 are
- * dropped; fragments outside [znear,zfar] are discarded per pixel.
+ * Near plane (GL clips primitives against zNear, render_py_multi.py:152-169): a triangle whose three vertices lie at
+ * Z >= zNear is rasterised as it is (fragments outside [znear, zfar] are discarded per pixel, which for such a triangle is
+ * what geometric clipping gives); one with all three in front of the plane is dropped; one that STRADDLES the plane is
+ * clipped in camera space (Sutherland-Hodgman against Z = zNear, intersection always computed from the inside to the outside
+ * vertex so that two triangles sharing the edge cut it in the same point), the 3- or 4-gon is rasterised as a fan, and its
+ * fragments are shaded with barycentrics of the ORIGINAL triangle taken in camera space (its screen-space triangle does not
+ * exist when a vertex is behind the eye).
  */
 #include <math.h>
 #include <stdint.h>
@@ -82,6 +87,76 @@ typedef struct {
   float ratio;            /* brightness_ratio (0.7 in tester.py:190) */
 } lit_t;
 
+#define ZCLIP_MIN 1.0e-4f
+
+/* Sutherland-Hodgman against z >= zc; cam = the triangle in camera space; returns 0, 3 or 4 vertices in out */
+static int clip_near(float cam[3][3], float zc, float out[4][3]) {
+  int n = 0;
+  for (int i = 0; i < 3; ++i) {
+    const float *a = cam[i], *b = cam[(i + 1) % 3];
+    const int ina = a[2] >= zc, inb = b[2] >= zc;
+    if (ina) { out[n][0] = a[0]; out[n][1] = a[1]; out[n][2] = a[2]; ++n; }
+    if (ina != inb) {
+      const float *pi = ina ? a : b, *po = ina ? b : a;
+      const float tt = (zc - pi[2]) / (po[2] - pi[2]);
+      out[n][0] = fmaf(tt, po[0] - pi[0], pi[0]);
+      out[n][1] = fmaf(tt, po[1] - pi[1], pi[1]);
+      out[n][2] = zc;
+      ++n;
+    }
+  }
+  return n;
+}
+
+/* barycentrics (affine, camera space) of the point that pixel (x, y) sees at depth z, w.r.t. the triangle cam; float64 */
+static void cam_bary(float cam[3][3], int x, int y, float z, float fx, float fy, float cx, float cy, float w[3]) {
+  const double P[3] = {(double)z * (((double)x - (double)cx) / (double)fx), (double)z * (((double)y - (double)cy) / (double)fy), (double)z};
+  double e1[3], e2[3], d0[3], d1[3], d2[3];
+  for (int k = 0; k < 3; ++k) {
+    e1[k] = (double)cam[1][k] - (double)cam[0][k];
+    e2[k] = (double)cam[2][k] - (double)cam[0][k];
+    d0[k] = (double)cam[0][k] - P[k];
+    d1[k] = (double)cam[1][k] - P[k];
+    d2[k] = (double)cam[2][k] - P[k];
+  }
+  const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+  const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+  const double c0[3] = {d1[1] * d2[2] - d1[2] * d2[1], d1[2] * d2[0] - d1[0] * d2[2], d1[0] * d2[1] - d1[1] * d2[0]};
+  const double c1[3] = {d2[1] * d0[2] - d2[2] * d0[1], d2[2] * d0[0] - d2[0] * d0[2], d2[0] * d0[1] - d2[1] * d0[0]};
+  const double b0 = (c0[0] * n[0] + c0[1] * n[1] + c0[2] * n[2]) / nn;
+  const double b1 = (c1[0] * n[0] + c1[1] * n[1] + c1[2] * n[2]) / nn;
+  w[0] = (float)b0;
+  w[1] = (float)b1;
+  w[2] = (float)(1.0 - b0 - b1);
+}
+
+/* one screen triangle into the z-buffer; clamp_near: fragments of a clipped piece may round below the plane they were cut at */
+static void raster_one(const int32_t X[3], const int32_t Y[3], const float iz[3], int f, int H, int W, float znear, float zfar,
+                       int clamp_near, float zc, uint64_t *zbuf) {
+  edges_t e;
+  if (!setup_edges(X, Y, &e)) return;
+  int32_t minX = X[0] < X[1] ? X[0] : X[1]; if (X[2] < minX) minX = X[2];
+  int32_t maxX = X[0] > X[1] ? X[0] : X[1]; if (X[2] > maxX) maxX = X[2];
+  int32_t minY = Y[0] < Y[1] ? Y[0] : Y[1]; if (Y[2] < minY) minY = Y[2];
+  int32_t maxY = Y[0] > Y[1] ? Y[0] : Y[1]; if (Y[2] > maxY) maxY = Y[2];
+  int x0 = (minX + 255) >> 8, x1 = maxX >> 8, y0 = (minY + 255) >> 8, y1 = maxY >> 8; /* arithmetic shifts = floor */
+  if (x0 < 0) x0 = 0; if (y0 < 0) y0 = 0; if (x1 > W - 1) x1 = W - 1; if (y1 > H - 1) y1 = H - 1;
+  const float inv_area = 1.0f / (float)e.area;
+  for (int y = y0; y <= y1; ++y)
+    for (int x = x0; x <= x1; ++x) {
+      int64_t E[3];
+      if (!inside(&e, (int64_t)x * 256, (int64_t)y * 256, E)) continue;
+      float b0 = (float)E[0] * inv_area, b1 = (float)E[1] * inv_area, b2 = (float)E[2] * inv_area;
+      float invz = fmaf(b2, iz[2], fmaf(b1, iz[1], b0 * iz[0]));
+      float z = 1.0f / invz;
+      if (clamp_near && z < zc) z = zc;
+      if (!(z >= znear && z <= zfar)) continue;
+      uint64_t key = ((uint64_t)f2u(z) << 32) | (uint32_t)f;
+      uint64_t *zp = zbuf + (size_t)y * W + x;
+      if (key < *zp) *zp = key;
+    }
+}
+
 static void render_impl(const float *verts, const float *uvs, const int32_t *faces, int V, int F,
                         const uint8_t *tex, int Ht, int Wt, const float *R, const float *t, const float *K,
                         int H, int W, float znear, float zfar, int tex_bilinear, const lit_t *lit, float *bgr, float *depth) {
@@ -98,37 +173,45 @@ static void render_impl(const float *verts, const float *uvs, const int32_t *fac
     scr[3 * i + 1] = fmaf(fy, yc / zc, cy);
     scr[3 * i + 2] = zc;
   }
+  const float zc = znear > ZCLIP_MIN ? znear : ZCLIP_MIN;
   for (int f = 0; f < F; ++f) {
     int32_t X[3], Y[3];
     float iz[3];
+    const float z0 = scr[3 * faces[3 * f] + 2], z1 = scr[3 * faces[3 * f + 1] + 2], z2 = scr[3 * faces[3 * f + 2] + 2];
+    const int nin = (z0 >= zc) + (z1 >= zc) + (z2 >= zc);
+    if (nin == 0) continue; /* wholly in front of the near plane (or NaN): clipped away */
+    if (nin < 3) {          /* straddles the near plane: clip in camera space, rasterise the pieces */
+      float cam[3][3], poly[4][3];
+      for (int k = 0; k < 3; ++k) {
+        const float *p = verts + 3 * faces[3 * f + k];
+        cam[k][0] = fmaf(R[0], p[0], fmaf(R[1], p[1], fmaf(R[2], p[2], t[0])));
+        cam[k][1] = fmaf(R[3], p[0], fmaf(R[4], p[1], fmaf(R[5], p[2], t[1])));
+        cam[k][2] = fmaf(R[6], p[0], fmaf(R[7], p[1], fmaf(R[8], p[2], t[2])));
+      }
+      const int np = clip_near(cam, zc, poly);
+      float su[4], sv[4];
+      int ok = np >= 3;
+      for (int k = 0; k < np; ++k) {
+        su[k] = fmaf(fx, poly[k][0] / poly[k][2], cx);
+        sv[k] = fmaf(fy, poly[k][1] / poly[k][2], cy);
+        if (!(fabsf(su[k]) < COORD_LIM) || !(fabsf(sv[k]) < COORD_LIM)) ok = 0;
+      }
+      if (!ok) continue;
+      for (int piece = 0; piece + 2 < np; ++piece) {
+        const int idx[3] = {0, piece + 1, piece + 2};
+        for (int k = 0; k < 3; ++k) { X[k] = snap(su[idx[k]]); Y[k] = snap(sv[idx[k]]); iz[k] = 1.0f / poly[idx[k]][2]; }
+        raster_one(X, Y, iz, f, H, W, znear, zfar, 1, zc, zbuf);
+      }
+      continue;
+    }
     int ok = 1;
     for (int k = 0; k < 3; ++k) {
       const float *s = scr + 3 * faces[3 * f + k];
-      if (!(s[2] > 1e-6f) || !(fabsf(s[0]) < COORD_LIM) || !(fabsf(s[1]) < COORD_LIM)) { ok = 0; break; }
+      if (!(fabsf(s[0]) < COORD_LIM) || !(fabsf(s[1]) < COORD_LIM)) { ok = 0; break; }
       X[k] = snap(s[0]); Y[k] = snap(s[1]); iz[k] = 1.0f / s[2];
     }
     if (!ok) continue;
-    edges_t e;
-    if (!setup_edges(X, Y, &e)) continue;
-    int32_t minX = X[0] < X[1] ? X[0] : X[1]; if (X[2] < minX) minX = X[2];
-    int32_t maxX = X[0] > X[1] ? X[0] : X[1]; if (X[2] > maxX) maxX = X[2];
-    int32_t minY = Y[0] < Y[1] ? Y[0] : Y[1]; if (Y[2] < minY) minY = Y[2];
-    int32_t maxY = Y[0] > Y[1] ? Y[0] : Y[1]; if (Y[2] > maxY) maxY = Y[2];
-    int x0 = (minX + 255) >> 8, x1 = maxX >> 8, y0 = (minY + 255) >> 8, y1 = maxY >> 8; /* arithmetic shifts = floor */
-    if (x0 < 0) x0 = 0; if (y0 < 0) y0 = 0; if (x1 > W - 1) x1 = W - 1; if (y1 > H - 1) y1 = H - 1;
-    const float inv_area = 1.0f / (float)e.area;
-    for (int y = y0; y <= y1; ++y)
-      for (int x = x0; x <= x1; ++x) {
-        int64_t E[3];
-        if (!inside(&e, (int64_t)x * 256, (int64_t)y * 256, E)) continue;
-        float b0 = (float)E[0] * inv_area, b1 = (float)E[1] * inv_area, b2 = (float)E[2] * inv_area;
-        float invz = fmaf(b2, iz[2], fmaf(b1, iz[1], b0 * iz[0]));
-        float z = 1.0f / invz;
-        if (!(z >= znear && z <= zfar)) continue;
-        uint64_t key = ((uint64_t)f2u(z) << 32) | (uint32_t)f;
-        uint64_t *zp = zbuf + (size_t)y * W + x;
-        if (key < *zp) *zp = key;
-      }
+    raster_one(X, Y, iz, f, H, W, znear, zfar, 0, zc, zbuf);
   }
   for (int y = 0; y < H; ++y)
     for (int x = 0; x < W; ++x) {
@@ -139,20 +222,37 @@ static void render_impl(const float *verts, const float *uvs, const int32_t *fac
       float z = u2f((uint32_t)(key >> 32));
       int32_t X[3], Y[3];
       float iz[3], tu[3], tv[3];
+      int clipped = 0;
       for (int k = 0; k < 3; ++k) {
         int vi = faces[3 * f + k];
-        const float *s = scr + 3 * vi;
-        X[k] = snap(s[0]); Y[k] = snap(s[1]); iz[k] = 1.0f / s[2];
         tu[k] = uvs[2 * vi]; tv[k] = uvs[2 * vi + 1];
+        if (!(scr[3 * vi + 2] >= zc)) clipped = 1;
       }
-      edges_t e; int64_t E[3];
-      setup_edges(X, Y, &e);
-      inside(&e, (int64_t)x * 256, (int64_t)y * 256, E);
-      const float inv_area = 1.0f / (float)e.area;
-      float b0 = (float)E[0] * inv_area, b1 = (float)E[1] * inv_area, b2 = (float)E[2] * inv_area;
-      float w0 = b0 * iz[0], w1 = b1 * iz[1], w2 = b2 * iz[2];
-      float u = fmaf(w2, tu[2], fmaf(w1, tu[1], w0 * tu[0])) * z;
-      float v = fmaf(w2, tv[2], fmaf(w1, tv[1], w0 * tv[0])) * z;
+      float w0, w1, w2, zs; /* attribute = (w2 a2 + w1 a1 + w0 a0) * zs */
+      if (clipped) {        /* a piece of a near-clipped triangle: camera-space barycentrics of the original */
+        float cam[3][3], wb[3];
+        for (int k = 0; k < 3; ++k) {
+          const float *p = verts + 3 * faces[3 * f + k];
+          cam[k][0] = fmaf(R[0], p[0], fmaf(R[1], p[1], fmaf(R[2], p[2], t[0])));
+          cam[k][1] = fmaf(R[3], p[0], fmaf(R[4], p[1], fmaf(R[5], p[2], t[1])));
+          cam[k][2] = fmaf(R[6], p[0], fmaf(R[7], p[1], fmaf(R[8], p[2], t[2])));
+        }
+        cam_bary(cam, x, y, z, fx, fy, cx, cy, wb);
+        w0 = wb[0]; w1 = wb[1]; w2 = wb[2]; zs = 1.0f;
+      } else {
+        for (int k = 0; k < 3; ++k) {
+          const float *s = scr + 3 * faces[3 * f + k];
+          X[k] = snap(s[0]); Y[k] = snap(s[1]); iz[k] = 1.0f / s[2];
+        }
+        edges_t e; int64_t E[3];
+        setup_edges(X, Y, &e);
+        inside(&e, (int64_t)x * 256, (int64_t)y * 256, E);
+        const float inv_area = 1.0f / (float)e.area;
+        float b0 = (float)E[0] * inv_area, b1 = (float)E[1] * inv_area, b2 = (float)E[2] * inv_area;
+        w0 = b0 * iz[0]; w1 = b1 * iz[1]; w2 = b2 * iz[2]; zs = z;
+      }
+      float u = fmaf(w2, tu[2], fmaf(w1, tu[1], w0 * tu[0])) * zs;
+      float v = fmaf(w2, tv[2], fmaf(w1, tv[1], w0 * tv[0])) * zs;
       float rgb[3];
       if (!tex_bilinear) {
         int tx = clampi((int)floorf(u * (float)Wt), 0, Wt - 1);
@@ -179,8 +279,8 @@ static void render_impl(const float *verts, const float *uvs, const int32_t *fac
         for (int c = 0; c < 3; ++c) {
           const float *N0 = lit->normals + 3 * faces[3 * f], *N1 = lit->normals + 3 * faces[3 * f + 1], *N2 = lit->normals + 3 * faces[3 * f + 2];
           const float *P0 = verts + 3 * faces[3 * f], *P1 = verts + 3 * faces[3 * f + 1], *P2 = verts + 3 * faces[3 * f + 2];
-          n[c] = fmaf(w2, N2[c], fmaf(w1, N1[c], w0 * N0[c])) * z; /* perspective-correct varyings v_normal, v_position */
-          p[c] = fmaf(w2, P2[c], fmaf(w1, P1[c], w0 * P0[c])) * z;
+          n[c] = fmaf(w2, N2[c], fmaf(w1, N1[c], w0 * N0[c])) * zs; /* perspective-correct varyings v_normal, v_position */
+          p[c] = fmaf(w2, P2[c], fmaf(w1, P1[c], w0 * P0[c])) * zs;
         }
         float Ng[3], Pg[3];
         for (int r = 0; r < 3; ++r) {

@@ -30,8 +30,12 @@ def update_mask_observed_box_rendered(mask_rendered):
 
 
 def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord="CAMERA", test_iter=4, znear=0.25, zfar=6.0,
-                tex_bilinear=False, fast_test=True, return_outputs=False, lit=None, **graph):
+                tex_bilinear=False, fast_test=True, return_outputs=False, lit=None, forced_poses=None, **graph):
     """One (observed, rendered) pair, batch 1 like the reference.
+    forced_poses: None, or (test_iter, 3, 4): "teacher forcing" for loop-parity tests -- the pose this loop computes in iteration k
+    is returned as usual, but the re-render, src_pose and the next compose continue from forced_poses[k] (the pose the loop under
+    test produced), so every iteration is compared on identical inputs and a silhouette pixel that flips in iteration k cannot
+    masquerade as (or hide) a feedback error in iteration k+1.
     lit: None, or dict(normals=(V,3), ratio=0.7) for the ModelNet branch of `render` (tester.py:204-243): light index 2,
     one np.random.uniform(0.9, 1.1, 3) intensity per re-render drawn from numpy's global RNG like the reference.
     graph: keyword arguments of flownet.forward_test selecting the graph variant (input_mask, pred_mask, input_depth).
@@ -48,6 +52,8 @@ def refine_pair(params, mesh, blobs, K, pixel_means, T_means, T_stds, rot_coord=
         outs.append({k: out[k] for k in ("mask_observed_pred", "zoom_mask_prob", "flow_est_crop", "zoom_factor") if k in out})
         pose_new = ose3.RT_transform(pose_rendered, se3[:-3], se3[-3:], T_means, T_stds, rot_coord)
         poses.append(pose_new)
+        if forced_poses is not None:
+            pose_new = np.array(forced_poses[it], dtype=np.float64)
         if it < test_iter - 1:
             if lit is None:
                 bgr, depth = native.render(verts, uvs, faces, tex, pose_new[:3, :3], pose_new[:, 3], K, znear=znear, zfar=zfar,

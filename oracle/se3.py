@@ -125,11 +125,38 @@ def T_inv_transform(T_src, T_tgt, T_means, T_stds, rot_coord):
     return (d - T_means) / T_stds
 
 
+def _axis_rot(axis, a):
+    c, s = np.cos(a), np.sin(a)
+    M = np.eye(3)
+    i, j = [(1, 2), (2, 0), (0, 1)][axis]
+    M[i, i], M[i, j], M[j, i], M[j, j] = c, -s, s, c
+    return M
+
+
+def euler2mat(ai, aj, ak):
+    """RT_transform.py:250-317 with its default axes 'sxyz' (the only ones the EULER branches :139-140 / :39-40 use):
+    rotations about the static x, y, z axes in that order = Rz(ak) Ry(aj) Rx(ai)."""
+    return _axis_rot(2, ak) @ _axis_rot(1, aj) @ _axis_rot(0, ai)
+
+
+def mat2euler(M):
+    """RT_transform.py:320-383, axes 'sxyz' (gimbal lock: third angle := 0, :370-377)."""
+    M = np.asarray(M, dtype=np.float64)[:3, :3]
+    cy = np.hypot(M[0, 0], M[1, 0])
+    if cy > np.finfo(float).eps * 4.0:
+        return np.arctan2(M[2, 1], M[2, 2]), np.arctan2(-M[2, 0], cy), np.arctan2(M[1, 0], M[0, 0])
+    return np.arctan2(-M[1, 2], M[1, 1]), np.arctan2(-M[2, 0], cy), 0.0
+
+
 def RT_transform(pose_src, r, t, T_means, T_stds, rot_coord="MODEL"):
-    """Compose a predicted (quat, trans) delta onto pose_src. RT_transform.py:135-161."""
+    """Compose a predicted (quat | euler, trans) delta onto pose_src. RT_transform.py:135-161."""
     r = np.squeeze(np.asarray(r, dtype=np.float64))
-    assert r.shape[0] == 4, "only QUAT is on the shipped path"
-    Rm_delta = quat2mat(r / np.linalg.norm(r))
+    if r.shape[0] == 3:
+        Rm_delta = euler2mat(r[0], r[1], r[2])
+    elif r.shape[0] == 4:
+        Rm_delta = quat2mat(r / np.linalg.norm(r))
+    else:
+        raise Exception("Unknown r shape: {}".format(r.shape))
     t_delta = np.squeeze(t)
     if rot_coord.lower() == "naive":
         se3_mx = np.zeros((3, 4))
@@ -153,6 +180,8 @@ def calc_RT_delta(pose_src, pose_tgt, T_means, T_stds, rot_coord="MODEL", rot_ty
     rt = rot_type.lower()
     if rt == "quat":
         r = mat2quat(Rm_delta)
+    elif rt == "euler":
+        r = mat2euler(Rm_delta)
     elif rt == "matrix":
         r = Rm_delta
     else:

@@ -87,6 +87,33 @@ def se3_vectors():
     np.savez_compressed(os.path.join(HERE, "se3_golden.npz"), **save)
 
 
+def se3_euler_vectors():
+    """EULER deltas (RT_transform.py:39-40, :139-140): calc_RT_delta(..., "EULER") and RT_transform with a 3-number rotation, on the
+    poses of se3_golden.npz plus exact gimbal-lock cases (aj = +-pi/2) for mat2euler's second branch."""
+    g = np.load(os.path.join(HERE, "se3_golden.npz"))
+    rng = np.random.default_rng(99)
+    coords = ["MODEL", "CAMERA", "CAMERA_NEW", "NAIVE"]
+    z3, o3 = np.zeros(3), np.ones(3)
+    n = g["pose_src"].shape[0]
+    eul = rng.uniform(-np.pi, np.pi, size=(n, 3)) * np.array([1.0, 0.5, 1.0])
+    save = {"euler": eul}
+    for c in coords:
+        save[c + "_compose"] = np.array([RT.RT_transform(g["pose_src"][i], eul[i], g["trans_delta"][i], z3, o3, c) for i in range(n)])
+        # calc_RT_delta(..., "EULER") = mat2euler of the MATRIX residual (:39-40).  Under numpy 2 the reference's mat2euler raises
+        # whenever np.array(mat, float64, copy=False) would have to copy (:357; numpy 1 copied silently) -- the float32 residual of
+        # NAIVE always, views sometimes -- so the residual is taken in MATRIX mode and handed over as the float64 array numpy 1
+        # would have made of it.
+        rt = [RT.calc_RT_delta(g["pose_src"][i], g["pose_tgt"][i], z3, o3, c, "MATRIX") for i in range(n)]
+        save[c + "_delta_e"] = np.array([np.array(RT.mat2euler(np.ascontiguousarray(r, dtype=np.float64))) for r, _ in rt])
+        save[c + "_delta_t"] = np.array([t for _, t in rt])
+    lock = np.array([[0.3, np.pi / 2, -0.7], [1.1, -np.pi / 2, 0.4], [0.0, np.pi / 2, 0.0]])
+    Rl = np.array([RT.euler2mat(*e) for e in lock])
+    save["lock_R"] = Rl
+    save["lock_e"] = np.array([np.array(RT.mat2euler(R)) for R in Rl])
+    save["e2m_R"] = np.array([RT.euler2mat(*e) for e in eul])
+    np.savez_compressed(os.path.join(HERE, "se3_euler_golden.npz"), **save)
+
+
 def synth_depth(rng, pose, H=120, W=160, Ks=None):
     """depth of a sphere of radius .08 m at pose translation (analytic ray cast), small image for fixture size"""
     c = pose[:, 3]
@@ -248,10 +275,14 @@ if __name__ == "__main__":
     if "--data-only" in sys.argv:
         data_layer_vectors()
         sys.exit(0)
+    if "--euler-only" in sys.argv:
+        se3_euler_vectors()
+        sys.exit(0)
     if "--callback-only" in sys.argv:
         callback_vectors()
         sys.exit(0)
     se3_vectors()
+    se3_euler_vectors()
     flow_vectors()
     pose_error_vectors()
     min_rect_vectors()

@@ -101,3 +101,24 @@ def test_training_shards_are_equal_when_batches_do_not_divide_world3(tmp_path):
     for a in accs:
         np.testing.assert_array_equal(a, accs[0])
     assert accs[0][4] == 5 and accs[0][0] == sum(range(15))
+
+
+def test_bench_gpus_2_starts_its_own_two_ranks():
+    """`python bench.py --gpus 2` is ONE command (reference: `--gpus 0,1,2,3`, deepim/train.py:425-438): with WORLD_SIZE unset it starts a
+    torch.distributed.run job of 2 ranks as a child process.  No GPU here, so the ranks meet over gloo, say so, and then every rank
+    stops at the GPU check -- the job, and with it the parent, must leave with a non-zero code (never a silent 1-GPU run)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert "rank 0 of 2 joined (gloo)" in r.stdout and "rank 1 of 2 joined (gloo)" in r.stdout, r.stdout[-3000:]
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs a GPU" in r.stdout, r.stdout[-3000:]
+    # an external launcher whose world size contradicts --gpus is an error, also when that world size is 1
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env1, stdout=subprocess.PIPE,
+                        stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+    assert r1.returncode != 0 and "WORLD_SIZE is 1" in r1.stdout, r1.stdout[-2000:]

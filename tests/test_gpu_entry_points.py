@@ -66,18 +66,37 @@ def test_two_rank_training_replicas_stay_identical(hip_lib, tmp_path):
 
 
 def test_two_rank_test_run_scores_the_union_of_the_shards(hip_lib, tmp_path):
-    """deepim/test.py under torch.distributed.run, 2 ranks on one card: each rank refines its own 32 of the 64 pairs (no collective on
+    """deepim/test.py --gpus 0,0 (the script launches its own torch.distributed.run job), 2 ranks on one card: each rank refines its own 32 of the 64 pairs (no collective on
     the data path), the per-class pose lists are merged once (all_gather_object) and every metric is over all 64 pairs; ONE result
     cache is written."""
     import pickle
 
-    env = dict(os.environ)
-    env.update(MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29523", os.path.join(PKG, "deepim", "test.py"), "--cfg", CFG, "--gpus", "0,0", "--num_pairs", "64"],
+    # ONE command, like the reference's `--gpus 0,1,2,3`: the script starts its own rank per named GPU (here twice card 0)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(PKG, "deepim", "test.py"), "--cfg", CFG, "--gpus", "0,0", "--num_pairs", "64"],
                        cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     files = glob.glob(os.path.join(str(tmp_path), "output", "deepim_hip", "*", "synthetic_val_ape", "*_results.pkl"))
     assert len(files) == 1, files
     rot_err, trans_err, poses_est, poses_gt = pickle.load(open(files[0], "rb"))
     assert len(poses_est[0][3]) == 64 and len(poses_gt[0][0]) == 64
+
+
+def test_bench_gpus_2_one_command_two_ranks_on_one_card(hip_lib):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its own 2 ranks (child torch.distributed.run job) and rank 0 prints
+    ONE line with "n_gpus": 2 -- rehearsed here with both ranks on this box's single card (gloo carries the barrier, the MAX over
+    ranks and the gradient sums of the `train` object; on a multi-GPU node the same command runs over RCCL)."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--train-steps", "1", "--profile-steps", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "rank 0 of 2 joined" in r.stderr and "rank 1 of 2 joined" in r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_pairs"] == 32 and out["value"] > 0
+    assert "error" not in out["train"], out["train"]
+    assert out["train"]["global_pairs"] == 2 * out["train"]["pairs_per_gpu"] and out["train"]["f32"]["finite"] and out["train"]["bf16"]["finite"]

@@ -54,8 +54,26 @@ def test_se3_compose_and_delta_vs_reference_golden(ops, golden_dir, coord):
     assert r1.shape == (3, 3)
     np.testing.assert_allclose(r1, g[coord + "_delta_R"][3], atol=2e-6)
     np.testing.assert_allclose(t1, g[coord + "_delta_t"][3], atol=2e-6)
-    with pytest.raises(Exception, match="EULER"):
-        calc_RT_delta(g["pose_src"][3], g["pose_tgt"][3], z3, o3, coord, "EULER")
+    # rot_type "EULER" and 3-number rotation deltas (RT_transform.py:39-40, :139-140), against the reference's outputs
+    from lib.pair_matching.RT_transform import RT_transform
+
+    e = np.load(os.path.join(golden_dir, "se3_euler_golden.npz"))
+    se3e = cu(np.concatenate([e["euler"], g["trans_delta"]], axis=1))
+    oute = ops.se3_compose_euler(ps, se3e, coord, z3, o3, out_f64=out64)
+    np.testing.assert_allclose(oute.cpu().numpy(), e[coord + "_compose"], atol=2e-6)
+    for i in (0, 7):   # on the f32-rounded inputs the float64 path agrees with the oracle to 1e-12
+        ref = ose3.RT_transform(g["pose_src"][i].astype(np.float32).astype(np.float64), se3e[i, :3].cpu().numpy().astype(np.float64),
+                                se3e[i, 3:].cpu().numpy().astype(np.float64), z3, o3, coord)
+        np.testing.assert_allclose(out64[i].cpu().numpy(), ref, atol=1e-6 if coord == "NAIVE" else 1e-12)
+    reul, trans_e = ops.se3_delta_euler(ps, pt, coord, z3, o3)
+    np.testing.assert_allclose(reul.cpu().numpy(), e[coord + "_delta_e"], atol=4e-6)
+    np.testing.assert_array_equal(trans_e.cpu().numpy(), trans.cpu().numpy())
+    r3, t3 = calc_RT_delta(g["pose_src"][3], g["pose_tgt"][3], z3, o3, coord, "EULER")
+    np.testing.assert_allclose(r3, e[coord + "_delta_e"][3], atol=4e-6)
+    np.testing.assert_allclose(RT_transform(g["pose_src"][3], e["euler"][3], g["trans_delta"][3], z3, o3, coord), e[coord + "_compose"][3],
+                               atol=2e-6)
+    with pytest.raises(Exception, match="Unknown rot_type"):
+        calc_RT_delta(g["pose_src"][3], g["pose_tgt"][3], z3, o3, coord, "AXIS_ANGLE")
 
 
 def test_se3_means_stds(ops, golden_dir):
@@ -313,6 +331,68 @@ def test_rasteriser_offscreen_and_clipping(ops):
     m = torch.ones((3, 1, 480, 640), device=DEV)
     ops.box_mask(bbox, m)
     assert m.sum() == 0
+
+
+def test_rasteriser_near_plane_clipping_vs_oracle(ops):
+    """GL clips against zNear = 0.25 (render_py_multi.py:152-169): meshes that straddle the plane -- and one with vertices BEHIND the
+    eye -- against oracle/raster.c (itself checked against ray casting: tests/test_oracle_crosscheck.py), unlit and lit.  Nothing
+    in front of the plane, no hole where a cut triangle's remainder shows, colours from camera-space barycentrics of the original
+    triangle."""
+    from lib.render_hip.render_py_light_modelnet_multi import Render_Py_Light_ModelNet_Multi, vertex_normals
+    from lib.render_hip.render_py_multi import Render_Py
+    from lib.utils import synthetic as syn
+
+    models = syn.make_models(seed=11, n_models=2, subdiv=3)
+    K = syn.LINEMOD_K
+    rng = np.random.default_rng(8)
+    B = 4
+    cls = np.array([0, 1, 0, 1], np.int32)
+    poses = np.zeros((B, 3, 4), np.float32)
+    for b, tz in enumerate((0.30, 0.26, 0.12, 0.05)):   # diameters 0.1-0.3 m: straddling; the last two reach behind the eye
+        q = rng.normal(size=4)
+        poses[b, :, :3] = ose3.quat2mat(q / np.linalg.norm(q))
+        poses[b, :, 3] = [0.01 * b, -0.01, tz]
+    big = []   # make sure the meshes are large enough to straddle at every distance above
+    for v, t, f, tex in models:
+        v = v * (0.3 / (v.max(0) - v.min(0)).max())
+        big.append((v.astype(np.float32), t, f, tex))
+    for b in range(B):
+        zc = (big[cls[b]][0] @ poses[b, :, :3].T + poses[b, :, 3])[:, 2]
+        assert zc.min() < 0.25 < zc.max(), (b, zc.min(), zc.max())
+    assert (big[0][0] @ poses[2, :, :3].T + poses[2, :, 3])[:, 2].min() < 0
+    for bil in (False, True):
+        rm = Render_Py(None, ["a", "b"], K, meshes=big, tex_bilinear=bil)
+        depth = torch.empty((B, 1, 480, 640), device=DEV)
+        bgr = torch.empty((B, 480, 640, 3), device=DEV)
+        status = torch.zeros(B, dtype=torch.int32, device=DEV)
+        rm.render_batch(cu(cls, torch.int32), cu(poses), depth=depth, bgr=bgr, status=status)
+        assert status.tolist() == [0] * B
+        for b in range(B):
+            v, t, f, tex = big[cls[b]]
+            rb, rd = native.render(v, t, f, tex, poses[b][:, :3], poses[b][:, 3], K, tex_bilinear=bil)
+            gd, gb = depth[b, 0].cpu().numpy(), bgr[b].cpu().numpy()
+            assert (rd > 0).sum() > 3000 and rd[rd > 0].min() >= 0.25 and gd[gd > 0].min() >= 0.25
+            assert ((gd > 0) != (rd > 0)).sum() <= 4
+            both = (gd > 0) & (rd > 0)
+            np.testing.assert_allclose(gd[both], rd[both], rtol=2e-6)
+            bad = (np.abs(gb - rb).max(axis=-1) > (1.0 if bil else 0.0)) & both
+            assert bad.sum() <= (20 if bil else 8), (b, bil, bad.sum())
+    # lit variant: normals / positions of a clipped face come from the same camera-space barycentrics
+    gray = np.full((32, 32, 3), 180, np.uint8)
+    meshes = [(v, vertex_normals(v, f).astype(np.float32), t, f) for v, t, f, _ in big]
+    rml = Render_Py_Light_ModelNet_Multi(None, gray, K, 640, 480, 0.25, 6.0, brightness_ratios=[0.7], meshes=meshes)
+    depth = torch.empty((B, 1, 480, 640), device=DEV)
+    bgr = torch.empty((B, 480, 640, 3), device=DEV)
+    li = np.tile(np.array([1.0, 0.95, 1.05], np.float32), (B, 1))
+    lp = np.stack([native.modelnet_light_position(poses[b].astype(np.float64), idx=2) for b in range(B)]).astype(np.float32)
+    rml.render_batch(cu(cls, torch.int32), cu(poses), depth=depth, bgr=bgr, light_position=cu(lp), light_intensity=cu(li))
+    for b in range(B):
+        v, n, t, f = meshes[cls[b]]
+        rb, rd = native.render_lit(v, n, t, f, gray, poses[b][:, :3], poses[b][:, 3], K, lp[b], li[b], 0.7)
+        gd, gb = depth[b, 0].cpu().numpy(), bgr[b].cpu().numpy()
+        assert ((gd > 0) != (rd > 0)).sum() <= 4
+        both = (gd > 0) & (rd > 0)
+        assert (np.abs(gb - rb).max(axis=-1)[both] > 1.0).sum() <= 8
 
 
 def test_rasteriser_reports_a_class_index_outside_the_mesh_table(ops):

@@ -7,6 +7,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import flownet as oflow, pose_error, refine as orefine  # noqa: E402
 from scene import make_scene, make_test_config  # noqa: E402
+from loop_parity import StaleRenderPose, check_loop, moving_head, oracle_free_and_forced, skip_box_mask  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -20,12 +21,19 @@ def setup(hip_lib):
     sym = deepIM_flownet()
     sym.get_symbol(cfg, is_train=False)
     params = sym.init_weights(cfg, {}, {}, seed=0)
-    # make the pose head non-trivial (the reference init has trans = 0): parity must cover it
-    rng = np.random.RandomState(1)
-    params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
-    params["rot_weight"][1:] = (rng.randn(3, 256) * 0.01).astype(np.float32)
+    # a pose head that moves the pose like a trained network does (3-12 deg, 4-42 mm per iteration: loop_parity.py); the
+    # reference init (trans = 0, rot rows ~ U(0, 0.01)) moves it by 0.4 deg / 1-4 mm, below any bar that could guard the loop
+    moving_head(params, seed=1)
     scene = make_scene(B=2, seed=2333, subdiv=3)
     return cfg, params, scene
+
+
+def _pair_oracles(cfg, params, scene, b, poses_hip_b, test_iter=4, mesh=None, blobs=None, **kw):
+    bl = scene["blobs"] if blobs is None else blobs
+    keys = ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose") + tuple(k for k in ("depth_observed", "depth_rendered") if k in bl)
+    blobs_b = {k: bl[k][b:b + 1] for k in keys}
+    mesh = scene["models"][int(bl["class_index"][b])] if mesh is None else mesh
+    return oracle_free_and_forced(params, mesh, blobs_b, scene["K"], cfg.network.PIXEL_MEANS, poses_hip_b, test_iter=test_iter, **kw)
 
 
 def test_forward_test_vs_oracle(setup):
@@ -70,25 +78,52 @@ def test_refine_4iter_vs_oracle(setup, graph):
     poses2 = ref.refine().cpu().numpy()  # replay on the same batch must be idempotent
     np.testing.assert_array_equal(poses, poses2)
     assert int(ref.status_iter.abs().sum()) == 0
-    z3, o3 = np.zeros(3), np.ones(3)
     pts = scene["models"][0][0].astype(np.float64)
     diam = np.linalg.norm(pts.max(0) - pts.min(0))
+    se3 = ref.se3_iter.cpu().numpy()
     for b in range(B):
-        blobs_b = {k: bl[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
-        o_poses, o_se3 = orefine.refine_pair(params, scene["models"][int(bl["class_index"][b])], blobs_b, scene["K"],
-                                             cfg.network.PIXEL_MEANS, z3, o3, "CAMERA", test_iter=4)
-        for it in range(4):
-            # the test graph emits the UN-normalised quaternion (|q| ~ 12 with this initialisation; RT_transform.py:143 normalises
-            # on use): compare the rotation it encodes and the translation at the north_star bar, not the raw scale
-            got = ref.se3_iter[it, b].cpu().numpy()
-            np.testing.assert_allclose(got[:4] / np.linalg.norm(got[:4]), o_se3[it][:4] / np.linalg.norm(o_se3[it][:4]), atol=1e-3)
-            np.testing.assert_allclose(got[4:], o_se3[it][4:], atol=1e-3)
-            np.testing.assert_allclose(got, o_se3[it], rtol=2e-3, atol=1e-3)
-            np.testing.assert_allclose(poses[it, b], o_poses[it], atol=1e-3)
-            # ADD of our final pose vs the oracle's final pose ("ADD(-S) vs reference" clause): far below 0.02*d
-            e = pose_error.add(poses[it, b][:, :3].astype(np.float64), poses[it, b][:, 3].astype(np.float64), o_poses[it][:, :3],
-                               o_poses[it][:, 3], pts)
-            assert e < 1e-3 * diam, (b, it, e)
+        free, forced = _pair_oracles(cfg, params, scene, b, poses[:, b])
+        # the STEP of every iteration (3-12 deg, 4-42 mm here) against the oracle's step from the same state, at 1e-4 of
+        # max(1, |step|); the free-running loops within 0.02 d of each other in ADD ("ADD(-S) vs reference" clause)
+        check_loop(bl["src_pose"][b], poses[:, b], se3[:, b], free, forced, pts, diam, tag="graph={} pair {}".format(graph, b))
+
+
+@pytest.mark.parametrize("fault", ["stale_render_pose", "skip_box_mask"])
+def test_refine_loop_negative_controls(setup, fault, monkeypatch):
+    """The bars of test_refine_4iter_vs_oracle must go RED when the loop is wrong: (1) iteration k rendered with the pose of
+    iteration k-1, (2) mask_observed not rebuilt from the new rendered mask (data_pair.py:103-114 skipped).  Same scene, same
+    checks; the faults are injected from outside (a wrapper around the render machine, a replaced ops.box_mask), eager mode."""
+    from deepim.core.tester import Predictor, Refiner
+    from lib.hip import ops
+    from lib.render_hip.render_py_multi import Render_Py
+
+    cfg, params, scene = setup
+    B = 2
+    bl = scene["blobs"]
+    pred = Predictor(cfg, params, B)
+    rm = Render_Py(None, cfg.dataset.class_name, scene["K"], meshes=scene["models"])
+    if fault == "stale_render_pose":
+        rm = StaleRenderPose(rm, torch.as_tensor(bl["src_pose"]).to(DEV))
+    else:
+        monkeypatch.setattr(ops, "box_mask", skip_box_mask(ops))
+    ref = Refiner(cfg, pred, rm, B, capture_graph=False)
+    ref.load(bl["image_observed"], bl["image_rendered"], bl["mask_observed"], bl["mask_rendered"], bl["src_pose"], bl["class_index"])
+    poses = ref.refine().cpu().numpy().copy()
+    se3 = ref.se3_iter.cpu().numpy()
+    pts = scene["models"][0][0].astype(np.float64)
+    diam = np.linalg.norm(pts.max(0) - pts.min(0))
+    red = 0
+    monkeypatch.undo()
+    for b in range(B):
+        free, forced = _pair_oracles(cfg, params, scene, b, poses[:, b])
+        # iteration 0 sees the loaded blobs only: it must still agree (the fault is in the feedback, nothing else)
+        np.testing.assert_allclose(poses[0, b], forced[0][0], atol=1e-5)
+        try:
+            check_loop(bl["src_pose"][b], poses[:, b], se3[:, b], free, forced, pts, diam, tag="{} pair {}".format(fault, b))
+        except AssertionError as e:
+            red += 1
+            print("{} pair {}: red as required: {}".format(fault, b, str(e)[:200]))
+    assert red == B, "the loop checks did not notice '{}'".format(fault)
 
 
 def test_refine_full_graph_multiclass_vs_oracle(hip_lib):
@@ -105,8 +140,7 @@ def test_refine_full_graph_multiclass_vs_oracle(hip_lib):
     sym.get_symbol(cfg, is_train=False)
     params = sym.init_weights(cfg, {}, {}, seed=3)
     rng = np.random.RandomState(4)
-    params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
-    params["rot_weight"][1:] = (rng.randn(3, 256) * 0.01).astype(np.float32)
+    moving_head(params, seed=4)
     params["mask_conv3_weight"] = (rng.randn(1, 770, 3, 3) * 0.05).astype(np.float32)
     params["mask_conv3_bias"] = np.array([0.1], np.float32)
     B = 3
@@ -144,18 +178,12 @@ def test_refine_full_graph_multiclass_vs_oracle(hip_lib):
         np.testing.assert_allclose(flows[it], rfl, atol=1e-3 * max(1.0, np.abs(rfl).max()))
     # (2) the loop as a whole vs the oracle's loop (north_star bar 1e-3; random weights amplify pose differences
     #     through re-rendering, so later iterations of the dense heads are only compared in (1))
-    z3, o3 = np.zeros(3), np.ones(3)
     for b in range(B):
-        blobs_b = {k: bl[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
-        o_poses, o_se3, o_out = orefine.refine_pair(params, scene["models"][int(bl["class_index"][b])], blobs_b, scene["K"],
-                                                    cfg.network.PIXEL_MEANS, z3, o3, "CAMERA", test_iter=4, fast_test=False,
-                                                    return_outputs=True)
-        for it in range(4):
-            # the test graph emits the un-normalised quaternion (RT_transform.py:143 normalises on use)
-            np.testing.assert_allclose(se3s[it, b, :4] / np.linalg.norm(se3s[it, b, :4]), o_se3[it][:4] / np.linalg.norm(o_se3[it][:4]),
-                                       atol=1e-3)
-            np.testing.assert_allclose(se3s[it, b, 4:], o_se3[it][4:], atol=1e-3)
-            np.testing.assert_allclose(poses[it, b], o_poses[it], atol=1e-3)
+        free, forced = _pair_oracles(cfg, params, scene, b, poses[:, b], fast_test=False, return_outputs=True)
+        o_out = free[2]
+        pts = scene["models"][int(bl["class_index"][b])][0].astype(np.float64)
+        check_loop(bl["src_pose"][b], poses[:, b], se3s[:, b], free, forced, pts, np.linalg.norm(pts.max(0) - pts.min(0)),
+                   tag="full graph pair {}".format(b))
         rfl = o_out[0]["flow_est_crop"][0]
         np.testing.assert_allclose(flows[0, b], rfl, atol=1e-3 * max(1.0, np.abs(rfl).max()))
         assert (masks[0, b] != o_out[0]["mask_observed_pred"][0]).sum() <= 100
@@ -180,9 +208,7 @@ def test_refine_modelnet_lit_vs_oracle(hip_lib):
     sym = deepIM_flownet()
     sym.get_symbol(cfg, is_train=False)
     params = sym.init_weights(cfg, {}, {}, seed=0)
-    rng = np.random.RandomState(1)
-    params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
-    params["rot_weight"][1:] = (rng.randn(3, 256) * 0.01).astype(np.float32)
+    moving_head(params, seed=1)
     B = 2
     scene = make_scene(B=B, seed=4242, subdiv=3, n_models=2)
     bl = scene["blobs"]
@@ -196,15 +222,13 @@ def test_refine_modelnet_lit_vs_oracle(hip_lib):
     poses = ref.refine().cpu().numpy().copy()
     assert int(ref.status_iter.abs().sum()) == 0
     np.random.seed(99)  # the oracle consumes the same stream: sample by sample, one draw per re-render
-    z3, o3 = np.zeros(3), np.ones(3)
     for b in range(B):
         c = int(bl["class_index"][b])
         v, n, t, f = meshes[c]
-        blobs_b = {k: bl[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
-        o_poses, o_se3 = orefine.refine_pair(params, (v, t, f, gray), blobs_b, scene["K"], cfg.network.PIXEL_MEANS, z3, o3, "CAMERA",
-                                             test_iter=4, lit={"normals": n, "ratio": 0.7})
-        for it in range(4):
-            np.testing.assert_allclose(poses[it, b], o_poses[it], atol=1e-3)
+        free, forced = _pair_oracles(cfg, params, scene, b, poses[:, b], mesh=(v, t, f, gray), lit={"normals": n, "ratio": 0.7})
+        pts = v.astype(np.float64)
+        check_loop(bl["src_pose"][b], poses[:, b], ref.se3_iter[:, b].cpu().numpy(), free, forced, pts,
+                   np.linalg.norm(pts.max(0) - pts.min(0)), tag="modelnet lit pair {}".format(b))
     # the lit image really is what the loop fed back: shading varies over the object
     img = ref.batch["image_rendered"].cpu().numpy()
     on = ref.batch["mask_rendered"].cpu().numpy()[:, 0] > 0
@@ -221,6 +245,12 @@ def test_pred_eval_collects_and_scores(setup, tmp_path):
     from lib.render_hip.render_py_multi import Render_Py
 
     _, params, scene = setup
+    # this test is about the outer loop's bookkeeping, and it scores our poses against the FREE-RUNNING oracle as ground truth at
+    # 0.1 deg / 1 mm: it keeps a head that moves the pose gently (the large steps are what test_refine_4iter_vs_oracle is for)
+    params = dict(params)
+    params["trans_weight"] = params["trans_weight"] * 0.1
+    params["rot_weight"] = params["rot_weight"].copy()
+    params["rot_weight"][1:] *= 0.05
     cfg = make_test_config(test_iter=4)  # the config object is a process-wide singleton that other tests re-shape
     B = 2
     pred = Predictor(cfg, params, B)
@@ -284,7 +314,7 @@ def test_graph_variants_images_only_and_depth_input(hip_lib):
         sym.get_symbol(cfg, is_train=False)
         params = sym.init_weights(cfg, {}, {}, seed=4)
         assert params["flow_conv1_weight"].shape == (64, cin, 7, 7)
-        params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
+        moving_head(params, seed=5)
         if cin > 6:
             params["flow_conv1_weight"][:, 6:] = (rng.randn(64, cin - 6, 7, 7) * 0.05).astype(np.float32)   # the depth lanes must matter
         pred = Predictor(cfg, params, B)
@@ -309,11 +339,11 @@ def test_graph_variants_images_only_and_depth_input(hip_lib):
             refiner.load(bl["image_observed"], bl["image_rendered"], bl["mask_observed"], bl["mask_rendered"], bl["src_pose"], bl["class_index"],
                          **dkw)
             poses = refiner.refine().cpu().numpy()
+            se3 = refiner.se3_iter.cpu().numpy()
+            pts = scene["models"][0][0].astype(np.float64)
             for b in range(B):
-                blobs_b = {k: host[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")
-                           + (("depth_observed", "depth_rendered") if input_depth else ())}
-                o_poses, _ = orefine.refine_pair(params, scene["models"][int(bl["class_index"][b])], blobs_b, scene["K"], cfg.network.PIXEL_MEANS,
-                                                 z3, o3, "CAMERA", test_iter=2, **kw)
-                for it in range(2):
-                    np.testing.assert_allclose(poses[it, b], o_poses[it], atol=1e-3)
-
+                blobs = {k: host[k] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose", "class_index")
+                         + (("depth_observed", "depth_rendered") if input_depth else ())}
+                free, forced = _pair_oracles(cfg, params, scene, b, poses[:, b], test_iter=2, blobs=blobs, **kw)
+                check_loop(bl["src_pose"][b], poses[:, b], se3[:, b], free, forced, pts, np.linalg.norm(pts.max(0) - pts.min(0)),
+                           tag="cin {} pair {}".format(cin, b), mean_rot_deg=2.0, min_rot_deg=0.5, min_trans_m=1e-3)

@@ -6,8 +6,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from oracle import refine as orefine  # noqa: E402
 from scene import make_scene, make_test_config  # noqa: E402
+from loop_parity import check_loop, moving_head, oracle_free_and_forced  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -22,9 +22,7 @@ def test_c_resident_loop_matches_python_loop_and_oracle(hip_lib):
     sym = deepIM_flownet()
     sym.get_symbol(cfg, is_train=False)
     params = sym.init_weights(cfg, {}, {}, seed=0)
-    rng = np.random.RandomState(1)
-    params["trans_weight"] = (rng.randn(3, 256) * 0.002).astype(np.float32)
-    params["rot_weight"][1:] = (rng.randn(3, 256) * 0.01).astype(np.float32)
+    moving_head(params, seed=1)   # 3-12 deg / 4-42 mm per iteration (tests/loop_parity.py)
     B = 2
     scene = make_scene(B=B, seed=2333, subdiv=3, n_models=1)
     bl = scene["blobs"]
@@ -45,12 +43,12 @@ def test_c_resident_loop_matches_python_loop_and_oracle(hip_lib):
     np.testing.assert_array_equal(pyref.refine().cpu().numpy(), poses_c)
     np.testing.assert_array_equal(pyref.se3_iter.cpu().numpy(), se3_c)
     # (2) the oracle
-    z3, o3 = np.zeros(3), np.ones(3)
     for b in range(B):
         blobs_b = {k: bl[k][b:b + 1] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
-        o_poses, _ = orefine.refine_pair(params, scene["models"][0], blobs_b, scene["K"], cfg.network.PIXEL_MEANS, z3, o3, "CAMERA", test_iter=4)
-        for it in range(4):
-            np.testing.assert_allclose(poses_c[it, b], o_poses[it], atol=1e-3)
+        free, forced = oracle_free_and_forced(params, scene["models"][0], blobs_b, scene["K"], cfg.network.PIXEL_MEANS, poses_c[:, b])
+        pts = scene["models"][0][0].astype(np.float64)
+        check_loop(bl["src_pose"][b], poses_c[:, b], se3_c[:, b], free, forced, pts, np.linalg.norm(pts.max(0) - pts.min(0)),
+                   tag="C loop pair {}".format(b))
     # (3) run() allocates nothing and does not synchronise: it captures into a hipGraph, and replays reproduce the eager call
     args = [dev[k] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose", "class_index")]
     s = torch.cuda.Stream()

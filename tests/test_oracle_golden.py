@@ -42,6 +42,22 @@ def test_calc_RT_delta(g, coord):
         np.testing.assert_allclose(rm, g[coord + "_delta_R"][i], atol=1e-12 if coord != "NAIVE" else 1e-6)
 
 
+@pytest.mark.parametrize("coord", ["MODEL", "CAMERA", "CAMERA_NEW", "NAIVE"])
+def test_euler_deltas_vs_reference(g, golden_dir, coord):
+    """rot_type EULER (RT_transform.py:39-40, :139-140): the oracle's static-xyz restatement against the reference's own outputs"""
+    e = np.load(os.path.join(golden_dir, "se3_euler_golden.npz"))
+    z3, o3 = np.zeros(3), np.ones(3)
+    for i in range(g["pose_src"].shape[0]):
+        np.testing.assert_allclose(ose3.euler2mat(*e["euler"][i]), e["e2m_R"][i], atol=1e-14)
+        got = ose3.RT_transform(g["pose_src"][i], e["euler"][i], g["trans_delta"][i], z3, o3, coord)
+        np.testing.assert_allclose(got, e[coord + "_compose"][i], atol=1e-6 if coord == "NAIVE" else 1e-12)
+        r, t = ose3.calc_RT_delta(g["pose_src"][i], g["pose_tgt"][i], z3, o3, coord, "EULER")
+        np.testing.assert_allclose(np.array(r), e[coord + "_delta_e"][i], atol=1e-6 if coord == "NAIVE" else 1e-12)
+        np.testing.assert_allclose(t, e[coord + "_delta_t"][i], atol=1e-6 if coord == "NAIVE" else 1e-12)
+    for R, want in zip(e["lock_R"], e["lock_e"]):   # gimbal lock: third angle := 0
+        np.testing.assert_allclose(np.array(ose3.mat2euler(R)), want, atol=1e-12)
+
+
 def test_means_stds(g):
     m, s = g["T_means2"], g["T_stds2"]
     for i in range(len(g["pose_src"])):
