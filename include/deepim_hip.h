@@ -135,6 +135,36 @@ int dim_test_blobs_from_raw(const unsigned char* obs_bgr, const unsigned char* r
                             int W, float depth_factor, const float* pixel_means_bgr3, float mask_thr, float* image_observed,
                             float* image_rendered, float* mask_rendered, int* bbox, void* stream);
 
+/* The general form for training AND test batches: reference lib/pair_matching/data_pair.py:22-72 (test) / :144-265 (train) through
+ * lib/utils/image.py get_pair_image :65-183, get_gt_observed_depth :186-207, get_pair_depth :210-269, get_pair_mask :272-491.
+ * Raw inputs, all (B,H,W[,3]) as the files hold them, any may be NULL (its outputs are then skipped):
+ *   obs_bgr / ren_bgr uint8 BGR; bg_bgr uint8 BGR = the VOC background already fitted to (H,W) (image.py:125-165) -- pasted where the
+ *   label image is 0 for samples with use_bg[b] != 0 (use_bg NULL: all), :166-173; depth_ren / depth_a / depth_b uint16 = metres *
+ *   depth_factor; label uint8 label image with mask_idx (B) the object's label value.
+ * Outputs: image_observed / image_rendered (B,3,H,W); mask_rendered (B,1,H,W) = depth with > mask_thr replaced by 1; depth_rendered,
+ * depth_a_out, depth_b_out (B,1,H,W) metres; mask_label = (label == mask_idx), label_raw = (float)label (TRAIN.INIT_MASK 'mask_gt' feeds
+ * the RAW label image, image.py:315-316); bbox_ren / bbox_label (B,4) {min_x,max_x,min_y,max_y} of depth > mask_thr / of mask_label for
+ * dim_box_mask (INIT_MASK box_rendered / box_gt / box_gt_observed / box_).  W % 4 == 0. */
+int dim_pair_blobs_from_raw(const unsigned char* obs_bgr, const unsigned char* bg_bgr, const int* use_bg, const unsigned char* ren_bgr,
+                            const unsigned short* depth_ren, const unsigned short* depth_a, const unsigned short* depth_b,
+                            const unsigned char* label, const int* mask_idx, int B, int H, int W, float depth_factor,
+                            const float* pixel_means_bgr3, float mask_thr, float* image_observed, float* image_rendered,
+                            float* mask_rendered, float* depth_rendered, float* depth_a_out, float* depth_b_out, float* mask_label,
+                            float* label_raw, int* bbox_ren, int* bbox_label, void* stream);
+/* mask_dilate (lib/utils/mask_dilate.py:10-55) with the random draws made by the caller: thickness4 (B,4) = {down, up, right, left}
+ * displacement of the boundary copies, 0 = side skipped.  mask_out != mask_in. */
+int dim_mask_dilate(const float* mask_in, const int* thickness4, float* mask_out, int B, int H, int W, void* stream);
+/* First-iteration flow labels = calc_flow (lib/pair_matching/flow.py:12-81; float64 per pixel like numpy) + the weights of
+ * get_pair_flow (image.py:531-545).  depth_src = rendered depth, depth_tgt = observed depth (B,1,H,W) metres; P12 (B,3,4) float64 (device) =
+ * K se3_mul(pose_tgt, se3_inverse(pose_src)) as the reference forms it on the host; Kinv9_f64 = inv(K) in float64 (host pointer).
+ * weight_type 0 all / 1 viz / 2 valid; flow (B,2,H,W) in "[h, w]" order unless standard_rep; flow_weights (B,2,H,W) or NULL. */
+int dim_calc_flow_labels(const float* depth_src, const float* depth_tgt, const double* P12, const double* Kinv9_f64, int B, int H, int W,
+                         double thresh, int standard_rep, int weight_type, float* flow, float* flow_weights, void* stream);
+/* Point-matching labels (image.py:559-600): model[b,:,j] = table[table_off[b] + idx[b,j]] (idx < 0: zero-padded slot, weight 0),
+ * weights (B,3,n), observed = R_obs model + t_obs.  table (N,3) = the points.xyz of all classes concatenated. */
+int dim_point_clouds(const float* table, const int* table_off, const int* idx, const float* pose_observed, int B, int n, float* model,
+                     float* weights, float* observed, void* stream);
+
 /* ---------------------------------------------------------------- rasteriser
  * Mesh table in HBM: verts (sumV,3), uvs (sumV,2), faces (sumF,3 int32, indices local to the mesh),
  * mesh_table (C,4 int32) = {vert_off, nvert, face_off, nface}; textures = concatenated uint8 RGB images

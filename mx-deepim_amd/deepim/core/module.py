@@ -95,6 +95,7 @@ class MutableModule(object):
             self.m[n] = self.flat_m[off:off + sz].view(shapes[n])
             self.w[n].copy_(torch.as_tensor(np.ascontiguousarray(arg_params[n]), dtype=torch.float32))
             off += psz
+        self.offset_of = off_of   # first element of every tensor in the flat vectors (tensors start on 128-byte boundaries)
         # ---- forward executor shares the master tensors (params dict = views of flat_w)
         self.net = FlowNetHip.__new__(FlowNetHip)
         # gradient buckets [begin, end) of the flat vector, in backward order; the last one also carries the biases; frozen tensors
@@ -552,27 +553,23 @@ class MutableModule(object):
                 continue
             st["mom:" + n] = self.m[n].cpu().numpy()
         if self.flat_v is not None:
-            off = 0
             for n in self.names:
-                sz = self.w[n].numel()
+                off, sz = self.offset_of[n], self.w[n].numel()
                 if n not in FROZEN:
                     st["var:" + n] = self.flat_v[off:off + sz].view(self.shapes[n]).cpu().numpy()
-                off += sz
         np.savez(fname, **st)
 
     def load_optimizer_states(self, fname):
         st = np.load(fname)
         self.num_update = int(st["num_update"])
-        off = 0
         for n in self.names:
-            sz = self.w[n].numel()
+            off, sz = self.offset_of[n], self.w[n].numel()
             if "mom:" + n in st:
                 self.m[n].copy_(torch.as_tensor(st["mom:" + n]))
             if "var:" + n in st:
                 if self.flat_v is None:
                     self.flat_v = torch.zeros_like(self.flat_m)
                 self.flat_v[off:off + sz].view(self.shapes[n]).copy_(torch.as_tensor(st["var:" + n]))
-            off += sz
 
     def get_params(self):
         return {n: self.w[n].cpu().numpy() for n in self.names}

@@ -111,6 +111,7 @@ class Refiner(object):
                                         "mask_rendered": self.init["mask_rendered"], "mask_observed": self.init["mask_observed"]})
         ops.copy(self.pose_init, staged.d_pose)
         ops.copy(self.batch["class_index"], staged.d_cls)
+        loader.release(staged)   # the last read of the staging set's device mirrors is enqueued
         if self.lit and self.test_iter > 1:
             li = np.stack([[np.random.uniform(0.9, 1.1, size=(3,)) for _ in range(self.test_iter - 1)] for _ in range(self.B)])
             self.light_int.copy_(torch.from_numpy(li.transpose(1, 0, 2).astype(np.float32)))

@@ -16,6 +16,7 @@ P = ctypes.c_void_p  # device pointer / host array / stream
 I = ctypes.c_int
 F = ctypes.c_float
 L = ctypes.c_long
+D = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/deepim_hip.h one to one
 SIGNATURES = {
@@ -40,6 +41,10 @@ SIGNATURES = {
     "dim_refiner_run": (I, [P, P, P, P, P, P, P, P, P, P, P]),
     "dim_refiner_destroy": (I, [P]),
     "dim_test_blobs_from_raw": (I, [P, P, P, I, I, I, F, P, F, P, P, P, P, P]),
+    "dim_pair_blobs_from_raw": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, P, F, P, P, P, P, P, P, P, P, P, P, P]),
+    "dim_mask_dilate": (I, [P, P, P, I, I, I, P]),
+    "dim_calc_flow_labels": (I, [P, P, P, P, I, I, I, D, I, I, P, P, P]),
+    "dim_point_clouds": (I, [P, P, P, P, I, I, P, P, P, P]),
     "dim_raster_workspace_bytes": (L, [I, I, I, I]),
     "dim_raster_render": (I, [P, P, P, P, I, I, I, P, P, P, P, P, I, I, I, F, F, I, P, F, P, P, P, P, P, P, P, P]),
     "dim_raster_render_lit": (I, [P, P, P, P, P, I, I, I, P, P, P, P, P, I, I, I, F, F, I, P, P, F, P, F, P, P, P, P, P, P, P, P]),

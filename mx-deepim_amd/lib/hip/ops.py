@@ -6,6 +6,8 @@ hipGraph capture.  No CPU fallback: non-CUDA tensors raise DeepIMHipError.
 """
 import struct
 
+import numpy as np
+
 import torch
 
 from . import capi
@@ -203,6 +205,49 @@ def test_blobs_from_raw(obs_bgr, ren_bgr, depth_ren, depth_factor, pixel_means_b
     check(lib().dim_test_blobs_from_raw(dptr(obs_bgr, torch.uint8), dptr(ren_bgr, torch.uint8), dptr(depth_ren, torch.uint16), B, H, W,
                                         float(depth_factor), mp, float(mask_thr), dptr(image_observed, f32), dptr(image_rendered, f32),
                                         dptr(mask_rendered, f32), dptr(bbox, i32), current_stream()))
+
+
+def pair_blobs_from_raw(B, H, W, depth_factor, pixel_means_bgr, obs_bgr=None, bg_bgr=None, use_bg=None, ren_bgr=None, depth_ren=None,
+                        depth_a=None, depth_b=None, label=None, mask_idx=None, image_observed=None, image_rendered=None, mask_rendered=None,
+                        depth_rendered=None, depth_a_out=None, depth_b_out=None, mask_label=None, label_raw=None, bbox_ren=None,
+                        bbox_label=None, mask_thr=0.2):
+    """raw file pixels of B pairs -> float blobs of a training / test batch on the device (csrc/data.hip; include/deepim_hip.h lists the
+    rules); every tensor optional"""
+    keep, mp = host_f32(pixel_means_bgr, 3)
+    u8, u16 = torch.uint8, torch.uint16
+    check(lib().dim_pair_blobs_from_raw(dptr(obs_bgr, u8), dptr(bg_bgr, u8), dptr(use_bg, i32), dptr(ren_bgr, u8), dptr(depth_ren, u16),
+                                        dptr(depth_a, u16), dptr(depth_b, u16), dptr(label, u8), dptr(mask_idx, i32), B, H, W,
+                                        float(depth_factor), mp, float(mask_thr), dptr(image_observed, f32), dptr(image_rendered, f32),
+                                        dptr(mask_rendered, f32), dptr(depth_rendered, f32), dptr(depth_a_out, f32), dptr(depth_b_out, f32),
+                                        dptr(mask_label, f32), dptr(label_raw, f32), dptr(bbox_ren, i32), dptr(bbox_label, i32),
+                                        current_stream()))
+
+
+def mask_dilate(mask_in, thickness4, out=None):
+    """mask_dilate.py:10-55 with the caller's draws: thickness4 (B,4) int32 = {down, up, right, left}, 0 = side skipped"""
+    B, _, H, W = mask_in.shape
+    out = out if out is not None else torch.empty_like(mask_in)
+    check(lib().dim_mask_dilate(dptr(mask_in, f32), dptr(thickness4, i32), dptr(out, f32), B, H, W, current_stream()))
+    return out
+
+
+FLOW_WEIGHT_ID = {"all": 0, "viz": 1, "valid": 2}
+
+
+def calc_flow_labels(depth_src, depth_tgt, P12, Kinv_f64, flow, flow_weights=None, thresh=3e-3, standard_rep=False, weight_type="viz"):
+    """first-iteration flow labels (calc_flow of lib/pair_matching/flow.py + the weights of get_pair_flow)"""
+    B, _, H, W = depth_src.shape
+    kinv = np.ascontiguousarray(np.asarray(Kinv_f64, dtype=np.float64).reshape(9))
+    check(lib().dim_calc_flow_labels(dptr(depth_src, f32), dptr(depth_tgt, f32), dptr(P12, torch.float64), kinv.ctypes.data, B, H, W, float(thresh),
+                                     int(bool(standard_rep)), FLOW_WEIGHT_ID[weight_type], dptr(flow, f32), dptr(flow_weights, f32),
+                                     current_stream()))
+    return flow, flow_weights
+
+
+def point_clouds(table, table_off, idx, pose_observed, model, weights, observed):
+    B, n = idx.shape
+    check(lib().dim_point_clouds(dptr(table, f32), dptr(table_off, i32), dptr(idx, i32), dptr(pose_observed, f32), B, n, dptr(model, f32),
+                                 dptr(weights, f32), dptr(observed, f32), current_stream()))
 
 
 def conv2d_pack_weight(w_oihw, as_bf16=False):

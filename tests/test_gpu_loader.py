@@ -72,8 +72,8 @@ def test_device_loader_matches_host_batches(hip_lib, tmp_path):
     loader.reset()
     assert loader.iter_next()
     loader.close()
-    cfg.TEST.INIT_MASK = "mask_gt_observed"
-    with pytest.raises(NotImplementedError):
+    cfg.TEST.INIT_MASK = "no_such_kind"
+    with pytest.raises(Exception, match="Unknown init mask type"):
         TestDataLoader(db, cfg, batch_size=B, device=DEV)
     cfg.TEST.INIT_MASK = "box_rendered"
     cfg.dataset.class_name = ["ape"]
@@ -161,4 +161,199 @@ def test_train_batch_assembly_labels(hip_lib, tmp_path):
         np.testing.assert_array_equal(label["flow"][i], f.transpose(2, 0, 1))
         np.testing.assert_allclose(label["point_cloud_observed"][i],
                                    rec["pose_observed"][:, :3] @ label["point_cloud_model"][i] + rec["pose_observed"][:, 3:4], atol=1e-6)
+    cfg.dataset.class_name = ["ape"]
+
+
+# ---------------------------------------------------------------------------------------------------------------- oracle-checked loaders
+def _decoded(rec, extra=()):
+    """what cv2.imread would hand the reference's getters (decoded with PIL here; the decoders are not under test)"""
+    from lib.utils.image import imread_color, imread_unchanged
+
+    raw = {"image_observed": imread_color(rec["image_observed"]), "image_rendered": imread_color(rec["image_rendered"]),
+           "depth_rendered": imread_unchanged(rec["depth_rendered"]), "mask_idx": rec.get("mask_idx", 1),
+           "pose_rendered": rec["pose_rendered"], "pose_observed": rec["pose_observed"]}
+    for k in ("depth_gt_observed", "mask_gt_observed", "depth_observed", "mask_observed") + tuple(extra):
+        if k in rec:
+            raw[k] = imread_unchanged(rec[k])
+    return raw
+
+
+def _oracle_cfg(cfg, phase):
+    t = cfg.TRAIN if phase == "train" else cfg.TEST
+    return {"pixel_means": np.asarray(cfg.network.PIXEL_MEANS, np.float64).reshape(3), "depth_factor": cfg.dataset.DEPTH_FACTOR,
+            "K": np.asarray(cfg.dataset.INTRINSIC_MATRIX), "init_mask": t.INIT_MASK, "mask_dilate": bool(t.get("MASK_DILATE", False)),
+            "input_depth": cfg.network.INPUT_DEPTH, "input_mask": cfg.network.INPUT_MASK, "pred_mask": cfg.network.PRED_MASK,
+            "pred_flow": cfg.network.PRED_FLOW, "pm_loss": cfg.train_iter.SE3_PM_LOSS, "num_3d_sample": int(cfg.train_iter.NUM_3D_SAMPLE),
+            "flow_weight_type": cfg.TRAIN.FLOW_WEIGHT_TYPE, "standard_flow_rep": cfg.network.STANDARD_FLOW_REP,
+            "rot_coord": cfg.network.ROT_COORD, "rot_type": cfg.network.ROT_TYPE, "trans_means": np.asarray(cfg.dataset.trans_means, np.float64),
+            "trans_stds": np.asarray(cfg.dataset.trans_stds, np.float64)}
+
+
+@pytest.mark.parametrize("kind,dilate,input_depth", [("mask_gt_observed", False, False), ("box_gt_observed", True, False),
+                                                     ("mask_observed", True, True), ("box_", False, True), ("box_rendered", True, True)])
+def test_test_loader_variants_vs_oracle(hip_lib, tmp_path, kind, dilate, input_depth):
+    """every TEST.INIT_MASK kind of get_pair_mask (image.py:367-476), TEST.MASK_DILATE and INPUT_DEPTH (get_pair_depth :210-269), built on
+    the device from the file pixels, against oracle/data_layer.py (pinned by the reference's own outputs: tests/test_oracle_data_layer.py).
+    Pair 2's rendered depth is all zero = an undetected object: empty mask whatever the kind."""
+    from deepim.core.loader import TestDataLoader
+    from oracle import data_layer as odl
+
+    cfg = make_test_config(test_iter=1)
+    cfg.dataset.class_name = ["ape", "can", "cat"]
+    cfg.TEST.INIT_MASK, cfg.TEST.MASK_DILATE, cfg.network.INPUT_DEPTH = kind, dilate, input_depth
+    db = _write_pairs(str(tmp_path), 4)
+    for i, rec in enumerate(db):
+        rec["depth_observed"] = rec["depth_gt_observed"]
+        rec["mask_observed"] = rec["mask_gt_observed"]
+    Image.fromarray(np.zeros((H, W), np.uint16)).save(db[2]["depth_rendered"])
+    B = 2
+    np.random.seed(11)
+    loader = TestDataLoader(db, cfg, batch_size=B, device=DEV, workers=4)
+    assert ("depth_observed" in loader.data_name) == input_depth
+    got = [{k: v.cpu().numpy().copy() for k, v in batch.items()} for batch in loader]
+    loader.close()
+    np.random.seed(11)
+    ocfg = _oracle_cfg(cfg, "test")
+    for i, rec in enumerate(db):
+        raw = _decoded(rec)
+        raw["class_index"] = cfg.dataset.class_name.index(rec["gt_class"])
+        want = odl.test_pair(raw, ocfg)
+        b, j = got[i // B], i % B
+        for name in ("image_observed", "image_rendered"):
+            np.testing.assert_allclose(b[name][j], want[name][0], atol=1e-5)
+        for name in ("mask_observed", "mask_rendered") + (("depth_observed", "depth_rendered") if input_depth else ()):
+            np.testing.assert_array_equal(b[name][j], want[name][0].astype(np.float32), err_msg="{} pair {}".format(name, i))
+        if i == 2:
+            assert b["mask_observed"][j].sum() == 0
+        elif dilate:
+            assert b["mask_observed"][j].sum() > 0
+    cfg.TEST.INIT_MASK, cfg.TEST.MASK_DILATE, cfg.network.INPUT_DEPTH = "box_rendered", False, False
+    cfg.dataset.class_name = ["ape"]
+
+
+def _voc_tree(root, n=3, seed=5):
+    rng = np.random.default_rng(seed)
+    voc = os.path.join(root, "VOCdevkit", "VOC2012")
+    os.makedirs(os.path.join(voc, "ImageSets", "Main"))
+    os.makedirs(os.path.join(voc, "JPEGImages"))
+    rows = []
+    for i in range(n):
+        name = "2008_{:06d}".format(i)
+        Image.fromarray(rng.integers(0, 256, size=(375 + 40 * i, 500, 3)).astype(np.uint8)).save(os.path.join(voc, "JPEGImages", name + ".jpg"), quality=95)
+        rows.append("{}  1".format(name))
+    rows.append("2008_999999 -1")
+    with open(os.path.join(voc, "ImageSets", "Main", "diningtable_trainval.txt"), "w") as f:
+        f.write("\n".join(rows) + "\n")
+
+
+@pytest.mark.parametrize("init_mask,dilate,weights,input_depth,rot_type", [("box_rendered", False, "viz", False, "QUAT"),
+                                                                          ("box_gt", True, "valid", True, "QUAT"),
+                                                                          ("mask_gt", True, "all", False, "MATRIX")])
+def test_train_loader_vs_oracle_and_pixel_cache(hip_lib, tmp_path, monkeypatch, init_mask, dilate, weights, input_depth, rot_type):
+    """TrainDataLoader (reference deepim/core/loader.py:120-421 -> data_pair.py:144-265): every data and label blob of a training batch
+    built in HBM from the file pixels, against oracle/data_layer.train_pair with the same draws in the same order; pairs 1 and 3 are
+    synthetic (`data_syn`: VOC background pasted behind the object); class 'can' has fewer model points than NUM_3D_SAMPLE (zero-padded
+    sample).  Second epoch: every file comes from the HBM pixel cache -- no decode -- and gives the same blobs."""
+    import random
+
+    from deepim.core import loader as L
+    from lib.utils import image as I
+    from oracle import data_layer as odl
+
+    cfg = make_train_config()
+    cfg.dataset.class_name = ["ape", "can", "cat"]
+    cfg.TRAIN.INIT_MASK, cfg.TRAIN.MASK_DILATE, cfg.TRAIN.FLOW_WEIGHT_TYPE = init_mask, dilate, weights
+    cfg.network.INPUT_DEPTH, cfg.network.ROT_TYPE = input_depth, rot_type
+    cfg.train_iter.NUM_3D_SAMPLE = 1000
+    cfg.TRAIN.REPLACE_OBSERVED_BG_RATIO = 0.5
+    root = str(tmp_path)
+    cfg.dataset.model_dir, cfg.dataset.root_path = os.path.join(root, "models"), root
+    rng = np.random.default_rng(1)
+    pts = {}
+    for cls, n in (("ape", 1500), ("can", 700), ("cat", 1000)):
+        os.makedirs(os.path.join(cfg.dataset.model_dir, cls))
+        pts[cls] = rng.normal(size=(n, 3)) * 0.05
+        np.savetxt(os.path.join(cfg.dataset.model_dir, cls, "points.xyz"), pts[cls])
+        pts[cls] = np.loadtxt(os.path.join(cfg.dataset.model_dir, cls, "points.xyz"))
+    I.point_cloud_dict.clear()
+    I._voc_lists.clear()
+    _voc_tree(root)
+    db = _write_pairs(os.path.join(root, "imgs"), 4)
+    for i, rec in enumerate(db):
+        # depths consistent with the two poses (identity rotations, pose_r z = 0.70 + 0.01 i, pose_o z = 0.71): a fronto-parallel patch,
+        # so that calc_flow finds most rendered pixels visible in the observed depth
+        ren = np.asarray(Image.open(rec["depth_rendered"])).astype(np.uint16)
+        Image.fromarray(np.where(ren > 200, 700 + 10 * i, ren).astype(np.uint16)).save(rec["depth_rendered"])
+        lab = np.asarray(Image.open(rec["mask_gt_observed"]))
+        Image.fromarray(np.where(lab == 1, 710, 0).astype(np.uint16)).save(rec["depth_gt_observed"])
+        rec["depth_observed"] = rec["depth_gt_observed"]
+        if i in (1, 3):
+            rec["data_syn"] = True
+        elif i == 2:
+            rec["data_syn"] = False   # real image: background replaced with probability REPLACE_OBSERVED_BG_RATIO
+    B = 2
+    decodes = {"n": 0}
+    real_c, real_u = L._imread_color, L._imread_unchanged
+    monkeypatch.setattr(L, "_imread_color", lambda p: (decodes.__setitem__("n", decodes["n"] + 1), real_c(p))[1])
+    monkeypatch.setattr(L, "_imread_unchanged", lambda p: (decodes.__setitem__("n", decodes["n"] + 1), real_u(p))[1])
+    cache = L.PixelCache(DEV, budget_bytes=1 << 30)
+    loader = L.TrainDataLoader(None, db, cfg, batch_size=B, shuffle=False, device=DEV, workers=4, cache=cache)
+    assert loader.data_name[:6] == ["image_observed", "image_rendered", "depth_gt_observed", "class_index", "src_pose", "tgt_pose"]
+    assert loader.label_name == ["rot", "trans", "mask_gt_observed", "flow", "flow_weights", "point_cloud_model", "point_cloud_weights",
+                                 "point_cloud_observed"]
+    epoch1 = [{k: v.cpu().numpy().copy() for k, v in batch.items()} for batch in loader]
+    n_dec1 = decodes["n"]
+    assert len(epoch1) == 2 and n_dec1 > 0
+    # ---- the oracle with the same draws in the same order (the loader seeds like the reference: loader.py:203-208)
+    random.seed(6)
+    np.random.seed(3)
+    rseed = np.random.randint(999999, size=[99999])
+    np.random.seed(rseed[0])
+    ocfg = _oracle_cfg(cfg, "train")
+    n_bg = 0
+    for i, rec in enumerate(db):
+        np.random.randint(18)
+        random.randrange(len(cfg.SCALES))
+        bg = None
+        if "data_syn" in rec and (rec["data_syn"] is True or np.random.rand() < cfg.TRAIN.REPLACE_OBSERVED_BG_RATIO):
+            voc_root, names = I._voc_backgrounds(cfg)
+            pick = names[random.randint(0, len(names) - 1)]
+            bg = I.fit_background(I.imread_color(os.path.join(voc_root, "JPEGImages/{}.jpg".format(pick))), H, W)
+            n_bg += 1
+        raw = _decoded(rec)
+        raw["class_index"] = cfg.dataset.class_name.index(rec["gt_class"])
+        data, label = odl.train_pair(raw, ocfg, points_obj=pts[rec["gt_class"]], bg_fitted=bg)
+        b, j = epoch1[i // B], i % B
+        for name in ("image_observed", "image_rendered"):
+            np.testing.assert_allclose(b[name][j], data[name][0], atol=1e-5, err_msg="{} pair {}".format(name, i))
+        exact = ["depth_gt_observed", "mask_observed", "mask_rendered", "mask_gt_observed", "point_cloud_weights"] + \
+            (["depth_observed", "depth_rendered"] if input_depth else [])
+        for name in exact:
+            want = (data[name] if name in data else label[name])[0].astype(np.float32)
+            np.testing.assert_array_equal(b[name][j], want, err_msg="{} pair {}".format(name, i))
+        np.testing.assert_array_equal(b["src_pose"][j], data["src_pose"][0].astype(np.float32))
+        np.testing.assert_array_equal(b["tgt_pose"][j], data["tgt_pose"][0].astype(np.float32))
+        assert int(b["class_index"][j]) == int(data["class_index"][0])
+        np.testing.assert_allclose(b["rot"][j], label["rot"][0], atol=2e-6)
+        np.testing.assert_allclose(b["trans"][j], label["trans"][0], atol=2e-6)
+        # float64 per pixel on both sides; the blob is float32
+        np.testing.assert_allclose(b["flow"][j], label["flow"][0], atol=2e-5, err_msg="flow pair {}".format(i))
+        assert (b["flow_weights"][j] != label["flow_weights"][0]).sum() == 0
+        assert np.abs(label["flow"][0]).max() > 0.5 and 0 < label["flow_weights"][0].mean() <= 1
+        np.testing.assert_allclose(b["point_cloud_model"][j], label["point_cloud_model"][0], atol=1e-7)
+        np.testing.assert_allclose(b["point_cloud_observed"][j], label["point_cloud_observed"][0], atol=1e-6)
+        if rec["gt_class"] == "can":
+            assert b["point_cloud_weights"][j][:, 700:].sum() == 0 and b["point_cloud_weights"][j][:, :700].min() == 1
+    assert n_bg >= 2
+    # ---- second epoch: served from the HBM pixel cache (the random VOC pick may name a background not seen before)
+    hits0 = cache.hits
+    loader.reset()
+    epoch2 = [{k: v.cpu().numpy().copy() for k, v in batch.items()} for batch in loader]
+    loader.close()
+    per_pair = 5 + int(input_depth)
+    assert cache.hits - hits0 >= per_pair * len(db) and decodes["n"] - n_dec1 <= 3, (cache.hits - hits0, decodes["n"] - n_dec1)
+    for b1, b2 in zip(epoch1, epoch2):
+        for name in ("image_rendered", "depth_gt_observed", "mask_rendered", "mask_gt_observed", "flow", "flow_weights", "rot", "trans"):
+            np.testing.assert_array_equal(b1[name], b2[name])
+    cfg.network.INPUT_DEPTH, cfg.network.ROT_TYPE = False, "QUAT"
     cfg.dataset.class_name = ["ape"]

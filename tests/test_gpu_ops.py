@@ -347,19 +347,20 @@ def test_rasteriser_near_plane_clipping_vs_oracle(ops):
     rng = np.random.default_rng(8)
     B = 4
     cls = np.array([0, 1, 0, 1], np.int32)
-    poses = np.zeros((B, 3, 4), np.float32)
-    for b, tz in enumerate((0.30, 0.26, 0.12, 0.05)):   # diameters 0.1-0.3 m: straddling; the last two reach behind the eye
-        q = rng.normal(size=4)
-        poses[b, :, :3] = ose3.quat2mat(q / np.linalg.norm(q))
-        poses[b, :, 3] = [0.01 * b, -0.01, tz]
-    big = []   # make sure the meshes are large enough to straddle at every distance above
+    big = []   # 0.6 m across: deep enough along any view direction to reach from behind the eye to beyond the near plane
     for v, t, f, tex in models:
-        v = v * (0.3 / (v.max(0) - v.min(0)).max())
+        v = v * (0.6 / (v.max(0) - v.min(0)).max())
         big.append((v.astype(np.float32), t, f, tex))
+    poses = np.zeros((B, 3, 4), np.float32)
     for b in range(B):
-        zc = (big[cls[b]][0] @ poses[b, :, :3].T + poses[b, :, 3])[:, 2]
-        assert zc.min() < 0.25 < zc.max(), (b, zc.min(), zc.max())
-    assert (big[0][0] @ poses[2, :, :3].T + poses[2, :, 3])[:, 2].min() < 0
+        q = rng.normal(size=4)
+        R = ose3.quat2mat(q / np.linalg.norm(q))
+        zr = (big[cls[b]][0] @ R.T)[:, 2]
+        # near plane through the middle of the object / only the far third beyond it / the last two also reach behind the eye (Z < 0)
+        tz = (0.25 - 0.5 * (zr.min() + zr.max()), 0.25 - 0.67 * zr.max(), -0.5 * zr.min(), -0.8 * zr.min())[b]
+        poses[b, :, :3], poses[b, :, 3] = R, [0.01 * b, -0.01, tz]
+        zc = zr + tz
+        assert zc.min() < 0.25 < zc.max() and (b < 2 or zc.min() < -0.02), (b, zc.min(), zc.max())
     for bil in (False, True):
         rm = Render_Py(None, ["a", "b"], K, meshes=big, tex_bilinear=bil)
         depth = torch.empty((B, 1, 480, 640), device=DEV)
