@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--no-fresh-batch", action="store_true", help="skip the (non-headline) `fresh_batch` object: a new batch uploaded every step")
     ap.add_argument("--no-variants", action="store_true", help="skip the (non-headline) `full_graph` and `modelnet_lit` objects (BASELINE configs[3] / [4] per GPU)")
     ap.add_argument("--no-train", action="store_true", help="skip the (non-headline) `train` object: timed training iterations at 16 pairs per GPU")
+    ap.add_argument("--no-train-files", action="store_true", help="skip the (non-headline) `train_fresh_batch` object: training fed from image files")
     ap.add_argument("--train-steps", type=int, default=5, help="timed training iterations per phase for the `train` object")
     ap.add_argument("--autotune", action="store_true", help="time tile/split-K candidates per layer first (untimed); default: fixed plan")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="bounded CPU-baseline sample (pairs refined by the oracle)")
@@ -308,6 +309,87 @@ def fresh_batch_bench(cfg, rm, refiner, B, dev, steps, warmup):
             "status_flags": int(refiner.status_iter.abs().sum().item()),
             "pipeline": "host RAM (uint8 BGR x2 + uint16 depth) -> pinned staging (2 sets) -> copy stream -> dim_test_blobs_from_raw + "
                         "dim_box_mask -> hipGraph replay; decode of image files not included"}
+
+
+def train_fresh_batch_bench(cfg, models, rm, B, dev, epochs=4, n_batches=6):
+    """Non-headline `train_fresh_batch` object: the training step of the `train` object, but every data batch comes FROM
+    IMAGE FILES through deepim/core/loader.TrainDataLoader -- PNG decode on a thread pool -> pinned staging -> copy stream -> every blob
+    and label of get_data_pair_train_batch built in HBM (csrc/data.hip) -> fit_batch (TRAIN_ITER_SIZE forward / backward / update +
+    re-render in between).  Epoch 1 decodes the files; from epoch 2 on every file is served by the decoded-pixel cache in HBM.
+    `resident` = the same fit_batch on one batch that never leaves HBM.  A synthetic LINEMOD-shaped dataset is written to a scratch
+    directory first (untimed)."""
+    import shutil
+    import tempfile
+
+    from deepim.core.loader import PixelCache, TrainDataLoader
+    from deepim.core.module import MutableModule, fit_batch
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+    from lib.dataset.synthetic_files import write_synthetic_dataset
+    from lib.pair_matching.batch_updater_py_multi import batchUpdaterPyMulti
+    from lib.utils import image as I
+
+    root = tempfile.mkdtemp(prefix="dim_bench_dataset_")
+    keep = (cfg.dataset.model_dir, cfg.TRAIN.INIT_MASK, cfg.TRAIN.MASK_DILATE, cfg.TRAIN.FLOW_WEIGHT_TYPE)
+    try:
+        t0 = time.perf_counter()
+        pairdb = write_synthetic_dataset(root, rm, models, list(cfg.dataset.class_name), B * n_batches, seed=4242)
+        t_write = time.perf_counter() - t0
+        cfg.dataset.model_dir = os.path.join(root, "models")
+        I.point_cloud_dict.clear()
+        sym = deepIM_flownet()
+        sym.get_symbol(cfg, is_train=True)
+        params = sym.init_weights(cfg, {}, {}, seed=0)
+        upd = batchUpdaterPyMulti(cfg, 480, 640, render_machine=rm)
+        n_iter = int(cfg.network.TRAIN_ITER_SIZE) if cfg.network.TRAIN_ITER else 1
+        res = {"pairs_per_gpu": B, "batches_per_epoch": n_batches, "train_iter_size": n_iter, "files_per_pair": 5,
+               "dataset_write_s": round(t_write, 2), "init_mask": cfg.TRAIN.INIT_MASK, "mask_dilate": bool(cfg.TRAIN.MASK_DILATE),
+               "pipeline": "PNG files -> PIL decode (thread pool) -> pinned staging (2 sets) -> copy stream -> dim_pair_blobs_from_raw + "
+                           "dim_box_mask / dim_mask_dilate + dim_se3_delta + dim_calc_flow_labels + dim_point_clouds -> fit_batch; epoch >= 2: "
+                           "decoded-pixel cache in HBM (device-to-device copies, no decode, no PCIe)"}
+        for dtype in ("f32", "bf16"):
+            mod = MutableModule(cfg, params, B, device=dev, compute_dtype=dtype)
+            cache = PixelCache(dev, budget_bytes=8 << 30)
+            loader = TrainDataLoader(None, pairdb, cfg, batch_size=B, shuffle=False, device=dev, workers=min(16, host_cores()), cache=cache)
+            per_epoch = []
+            for ep in range(epochs):
+                loader.reset()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for batch in loader:
+                    fit_batch(mod, batch, upd, 1e-5)
+                torch.cuda.synchronize()
+                per_epoch.append((time.perf_counter() - t0) / n_batches * 1e3)
+            # the data layer alone, cached: staging (cache look-ups, device-to-device copies) + the blob kernels, no training
+            loader.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for batch in loader:
+                pass
+            torch.cuda.synchronize()
+            loader_ms = (time.perf_counter() - t0) / n_batches * 1e3
+            loader.reset()
+            resident = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in next(loader).items()}
+            loader.close()
+            fit_batch(mod, dict(resident), upd, 1e-5)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_batches):
+                fit_batch(mod, dict(resident), upd, 1e-5)
+            torch.cuda.synchronize()
+            res_ms = (time.perf_counter() - t0) / n_batches * 1e3
+            warm = float(np.mean(per_epoch[1:])) if epochs > 1 else per_epoch[0]
+            res[dtype] = {"epoch1_ms_per_batch": round(per_epoch[0], 2), "cached_ms_per_batch": round(warm, 2),
+                          "resident_ms_per_batch": round(res_ms, 2), "data_layer_alone_cached_ms_per_batch": round(loader_ms, 2),
+                          "cached_pairs_per_s": round(B / warm * 1e3, 1),
+                          "resident_pairs_per_s": round(B / res_ms * 1e3, 1), "cached_over_resident": round(res_ms / warm, 3),
+                          "cache_hits": cache.hits, "cache_misses": cache.misses, "cache_mb": round(cache.used / 2 ** 20, 1),
+                          "finite": bool(torch.isfinite(mod.flat_w).all().item())}
+            del mod, loader, cache
+            torch.cuda.empty_cache()
+        return res
+    finally:
+        cfg.dataset.model_dir, cfg.TRAIN.INIT_MASK, cfg.TRAIN.MASK_DILATE, cfg.TRAIN.FLOW_WEIGHT_TYPE = keep
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps, progress=None):
@@ -579,6 +661,11 @@ def main():
                 if rank == 0:
                     print(json.dumps(out), flush=True)
                 os._exit(3)
+    if world == 1 and not args.no_train and not args.no_train_files:
+        try:
+            out["train_fresh_batch"] = train_fresh_batch_bench(cfg, models, rm, int(cfg.TRAIN.BATCH_PAIRS) if args.batch_pairs is None else B, dev)
+        except Exception as e:
+            out["train_fresh_batch"] = {"error": "{}: {}".format(type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, params, models, batch, args.cpu_pairs)
     if rank == 0:

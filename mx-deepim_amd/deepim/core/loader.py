@@ -15,10 +15,10 @@ is where the bytes are turned into blobs:
               staging slot with a device-to-device copy -- no decode, no PCIe: every epoch after the first, and pairs that share an
               observed image inside an epoch.  LINEMOD's training set is ~3 MB per pair decoded, so a whole dataset fits the 288 GB.
 
-Randomness (training) is drawn in the main thread in pair order with the reference's calls in the reference's order for one pair
+Randomness (training) is drawn by the single staging thread in pair order with the reference's calls in the reference's order for one pair
 (get_data_pair_train_batch([rec]): np.random.randint(18); random.randrange(len(SCALES)); [np.random.rand()]; [random.randint bg];
-mask_dilate's draws; np.random.shuffle for the point sample), so a seeded run is reproducible -- the reference itself is not (its
-draws happen in pool processes).
+mask_dilate's draws; np.random.shuffle for the point sample), so a seeded run is reproducible as long as nothing else draws from
+the global generators while an epoch is being staged -- the reference itself is not reproducible (its draws happen in pool processes).
 
 Not built (raise): img_flipped (the reference raises too), TRAIN.MASK_SYN, network.MASK_INPUTS, SCALES other than the image size.
 `RawPairSource` is the seam for pixels that do not come from files (bench.py's synthetic `fresh_batch` line).
@@ -163,48 +163,71 @@ class _DeviceLoader(object):
         self.fields = tuple(fields)
         self.sets = [_Staging(self.batch_size, self.H, self.W, self.device, self.fields, n_points) for _ in range(2)]
         self.cache = cache
+        # ONE background thread stages batch k+1 (draws, cache look-ups, decode fan-out over the pool, copy-stream traffic) while the
+        # caller's thread is already enqueueing the work on batch k: with staging in the caller's thread the GPU sat idle for the
+        # decode time of every batch.  A single stager keeps the random draws in pair order.
+        self._stager = ThreadPoolExecutor(max_workers=1)
         self._lock = threading.Lock()
 
     def __len__(self):
         return self.size // self.batch_size   # whole batches (the resident executors are built for one batch size)
 
     def _rewind(self):
+        if getattr(self, "_inflight", None) is not None:
+            self._inflight.result()   # a batch staged ahead but never consumed: let it finish before the sets are reused
         self.cur = 0
         self._slot = 0
         self._inflight = None
 
+    def _prefetch(self):
+        """start staging the first batch of the epoch right away (called at the end of reset())"""
+        if self._inflight is None:
+            self._inflight = self._submit()
+
     def iter_next(self):
         return self._inflight is not None or self.cur + self.batch_size <= self.size
 
+    def _stage_in_thread(self, st, first):
+        torch.cuda.set_device(self.device)
+        return self._stage(st, first)
+
     def _submit(self):
+        """start staging the next batch in the background -> a future of its staging set, or None at the end of the epoch"""
         if self.cur + self.batch_size > self.size:
             return None
         st = self.sets[self._slot]
         self._slot ^= 1
         first, self.cur = self.cur, self.cur + self.batch_size
-        return self._stage(st, first)   # runs here (its decodes fan out over the pool) while the GPU still works on the batch before
+        return self._stager.submit(self._stage_in_thread, st, first)
 
     def next_raw(self):
-        """-> the staging set of the next batch (device mirrors valid once `ready` has been waited for); stages the batch after it"""
-        st = self._inflight if self._inflight is not None else self._submit()
-        if st is None:
+        """-> the staging set of the next batch (device mirrors valid once `ready` has been waited for); the batch after it starts
+        staging in the background before this one is handed out"""
+        fut = self._inflight if self._inflight is not None else self._submit()
+        if fut is None:
             raise StopIteration
-        self._inflight = self._submit()   # decode + upload of batch k+1 start before batch k is consumed
+        st = fut.result()
+        self._inflight = self._submit()
         return st
 
     def _fill_files(self, st, jobs):
         """jobs: [(field, slot j, cache key or None, decode() -> ndarray, meta_of(ndarray) or None)].  Cache hits become device-to-device
         copies on the copy stream, misses are decoded by the pool into the pinned set, uploaded slot by slot and then cached.
         -> {(field, j): meta} for the entries that carry one"""
-        metas, todo = {}, []
+        metas, todo, hit_dst, hit_src = {}, [], {}, {}
+        for field, j, key, decode, meta_of in jobs:
+            hit = self.cache.get(key) if (self.cache is not None and key is not None) else None
+            if hit is not None:
+                # (the multi-tensor copy has no uint16 kernel: 16-bit depth goes as int16, the same bytes)
+                as_copyable = (lambda t: t.view(torch.int16)) if hit[0].dtype == torch.uint16 else (lambda t: t)
+                hit_dst.setdefault(hit[0].dtype, []).append(as_copyable(st.d[field][j]))
+                hit_src.setdefault(hit[0].dtype, []).append(as_copyable(hit[0]))
+                metas[(field, j)] = hit[1]
+            else:
+                todo.append((field, j, key, decode, meta_of))
         with torch.cuda.stream(self.copy_stream):
-            for field, j, key, decode, meta_of in jobs:
-                hit = self.cache.get(key) if (self.cache is not None and key is not None) else None
-                if hit is not None:
-                    st.d[field][j].copy_(hit[0], non_blocking=True)
-                    metas[(field, j)] = hit[1]
-                else:
-                    todo.append((field, j, key, decode, meta_of))
+            for dt, dst in hit_dst.items():   # one multi-tensor copy per element type instead of one launch per file
+                torch._foreach_copy_(dst, hit_src[dt], non_blocking=True)
 
         def run(job):
             field, j, key, decode, meta_of = job
@@ -233,6 +256,7 @@ class _DeviceLoader(object):
             st.ready.record(self.copy_stream)
 
     def close(self):
+        self._stager.shutdown(wait=True)
         self.pool.shutdown(wait=True)
 
     def __iter__(self):
@@ -310,6 +334,7 @@ class TestDataLoader(_DeviceLoader):
         self._rewind()
         if self.shuffle:
             np.random.shuffle(self.index)
+        self._prefetch()
 
     def _stage(self, st, first):
         ids = self.index[first:first + self.batch_size]
@@ -472,6 +497,7 @@ class TrainDataLoader(_DeviceLoader):
         self._rewind()
         if self.shuffle:
             np.random.shuffle(self.index)
+        self._prefetch()
 
     # ---- point tables ------------------------------------------------------------------------------------------------------------
     def _points_of(self, cls):

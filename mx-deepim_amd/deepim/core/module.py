@@ -83,6 +83,10 @@ class MutableModule(object):
         self.flat_v = None  # second Adam state, allocated on first use
         self.flat_g16 = None  # bf16 image of the gradient bucket (bf16 mode, more than one rank)
         self.force_bf16_bucket = False  # tests: round the bucket through bf16 in a single process too
+        # tests: another executor (same batch, forward done) whose stored activations supply every LeakyReLU' mask of backward() -- so
+        # that a bf16-vs-f32 or permuted-vs-original gradient comparison measures arithmetic, not which side of zero a pre-activation
+        # within the forward noise of it fell on (tests/test_gpu_train_bf16.py)
+        self.lrelu_mask_from = None
         self.w, self.g, self.m = {}, {}, {}
         self.n_weight = sum(sz for n, sz in zip(self.names, padded) if n not in FROZEN and n.endswith("_weight"))
         self.n_bias = sum(sz for n, sz in zip(self.names, padded) if n not in FROZEN and not n.endswith("_weight"))
@@ -332,7 +336,8 @@ class MutableModule(object):
             self._decoder_backward()
         # ---------------- pose head (fc7, rot, trans, fc6)
         fc6a = net.fc6.view(B, 256)
-        ops.pose_head_bwd(fc6a, net.fc7, self.rot_raw, d_rn, d_t, w, self.d_rot, self.dz7, self.dz6)
+        msk = self.lrelu_mask_from.net if self.lrelu_mask_from is not None else net   # whose activation signs gate the gradients
+        ops.pose_head_bwd(msk.fc6.view(B, 256), msk.fc7, self.rot_raw, d_rn, d_t, w, self.d_rot, self.dz7, self.dz6)
         ops.fc_wgrad(self.d_rot, net.fc7, g["rot_weight"], g["rot_bias"])
         ops.fc_wgrad(d_t, net.fc7, g["trans_weight"], g["trans_bias"])
         ops.fc_wgrad(self.dz7, fc6a, g["fc7_weight"], g["fc7_bias"])
@@ -357,7 +362,7 @@ class MutableModule(object):
                 ops.copy_nhwc_channels(dy, 0, self.dconcat2, 0, 512, add=True)   # skip connection into Concat2
             if name == "conv4_1" and self.has_decoder:
                 ops.copy_nhwc_channels(dy, 0, self.dconcat3, 0, 512, add=True)   # skip connection into Concat3
-            ops.lrelu_bwd_bias_grad(net.acts[name], dy, cout, g[name + "_bias"], workspace=self.bias_ws)   # dz in place + bias gradient
+            ops.lrelu_bwd_bias_grad(msk.acts[name], dy, cout, g[name + "_bias"], workspace=self.bias_ws)   # dz in place + bias gradient
             x = net.acts[prev[name]] if prev[name] else net.X
             if name in self.wino_wgrad:
                 S, sp = self.wino_wgrad[name]
@@ -429,6 +434,31 @@ class MutableModule(object):
             return None
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
+    def snapshot_lrelu_masks(self, perm=None):
+        """tests: a frozen copy of the activations whose signs gate backward() (every encoder layer, the two decoder concat buffers,
+        fc6 / fc7), optionally with the batch dimension permuted -- assign it to another executor's (or this one's) `lrelu_mask_from`.
+        -> object with a `.net` attribute shaped like FlowNetHip for exactly those reads"""
+        import types
+
+        net = self.net
+        take = (lambda t: t.clone()) if perm is None else (lambda t: t[perm].contiguous())
+        snap = types.SimpleNamespace(acts={k: take(v) for k, v in net.acts.items()}, fc6=take(net.fc6), fc7=take(net.fc7),
+                                     concat2=take(net.concat2) if self.has_decoder else None,
+                                     concat3=take(net.concat3) if self.has_decoder else None)
+        return types.SimpleNamespace(net=snap)
+
+    def count_lrelu_flips(self, other):
+        """tests: {layer: (units whose LeakyReLU branch differs between this executor's stored activations and `other`'s, units)}"""
+        out = {}
+        mine, theirs = self.net, other.net
+        for k, a in mine.acts.items():
+            b = theirs.acts[k]
+            out[k] = (int(((a > 0) != (b > 0)).sum().item()), a.numel())
+        for k in ("fc6", "fc7"):
+            a, b = getattr(mine, k), getattr(theirs, k)
+            out[k] = (int(((a > 0) != (b > 0)).sum().item()), a.numel())
+        return out
+
     def pending_buckets(self):
         """[(begin, end, completed)] of the buckets handed to the collective and not yet consumed by update() -- for a watchdog
         that has to say WHICH transfer never finished"""
@@ -467,14 +497,15 @@ class MutableModule(object):
         # ---------------- decoder level 4: Concat3 = [ReLU6 | ReLU12 (deconv4) | upsample_flow5to4]
         ops.deconv4x4s2_tiny_bwd(net.flow5, self.dconcat3, 768, w["upsample_flow5to4_weight"], self.dflow5, g["upsample_flow5to4_weight"],
                                  g["upsample_flow5to4_bias"])
-        ops.lrelu_bwd(net.concat3, self.dconcat3, 256, y_coff=512, dy_coff=512)
+        msk = self.lrelu_mask_from.net if self.lrelu_mask_from is not None else net
+        ops.lrelu_bwd(msk.concat3, self.dconcat3, 256, y_coff=512, dy_coff=512)
         self._deconv_bwd("deconv4", x=net.concat2, x_c=1026, x_cpad=ops.pad64(1026), dz=self.dconcat3, dz_coff=512, cout=256, dx=self.dconcat2)
         ops.conv_small_cout_bwd(net.concat2, 1026, self.dflow5, w["Convolution2_weight"], self.dconcat2, g["Convolution2_weight"],
                                 g["Convolution2_bias"], accumulate_dx=True, workspace=self.ws)
         # ---------------- decoder level 5: Concat2 = [ReLU8 | ReLU11 (deconv5) | upsample_flow6to5]
         ops.deconv4x4s2_tiny_bwd(net.flow6, self.dconcat2, 1024, w["upsample_flow6to5_weight"], self.dflow6, g["upsample_flow6to5_weight"],
                                  g["upsample_flow6to5_bias"])
-        ops.lrelu_bwd(net.concat2, self.dconcat2, 512, y_coff=512, dy_coff=512)
+        ops.lrelu_bwd(msk.concat2, self.dconcat2, 512, y_coff=512, dy_coff=512)
         self._deconv_bwd("deconv5", x=net.acts["conv6_1"], x_c=1024, x_cpad=1024, dz=self.dconcat2, dz_coff=512, cout=512, dx=d10)
         ops.conv_small_cout_bwd(net.acts["conv6_1"], 1024, self.dflow6, w["Convolution1_weight"], d10, g["Convolution1_weight"],
                                 g["Convolution1_bias"], accumulate_dx=True, workspace=self.ws)

@@ -29,6 +29,9 @@ def parse_args():
     parser.add_argument("--vis", help="turn on visualization", action="store_true")
     parser.add_argument("--num_pairs", help="synthetic pairs per epoch (all ranks together)", default=256, type=int)
     parser.add_argument("--max_batches", help="stop every epoch after this many batches (0 = all)", default=0, type=int)
+    parser.add_argument("--from_files", help="train through the file path of the data layer: a LINEMOD-shaped synthetic dataset (PNG files, "
+                        "points.xyz) is written under this directory once and read back by deepim.core.loader.TrainDataLoader "
+                        "(thread-pool decode, pinned staging, blobs built on the GPU, decoded-pixel cache)", default="", type=str)
     return parser.parse_args()
 
 
@@ -89,6 +92,30 @@ def train_net(args):
     if config.TRAIN.RESUME and os.path.exists(states):
         mod.load_optimizer_states(states)
     updater = batchUpdaterPyMulti(config, 480, 640, render_machine=data.render_machine)
+    file_loader = None
+    if args.from_files:
+        # the reference's path: pairdb records -> TrainDataLoader (train.py:136).  No dataset exists offline, so the records name the
+        # files of a synthetic dataset written here once by rank 0; every rank reads its own equal share of the batches.
+        import pickle
+
+        from deepim.core.loader import PixelCache, TrainDataLoader
+        from lib.dataset.synthetic_files import write_synthetic_dataset
+
+        db_file = os.path.join(args.from_files, "pairdb_{}.pkl".format(args.num_pairs))
+        if rank == 0 and not os.path.exists(db_file):
+            pairdb = write_synthetic_dataset(args.from_files, data.render_machine, data.models, list(config.dataset.class_name), args.num_pairs)
+            with open(db_file, "wb") as f:
+                pickle.dump(pairdb, f, protocol=2)
+        if dist is not None:
+            dist.barrier()
+        with open(db_file, "rb") as f:
+            pairdb = pickle.load(f)
+        per_rank = (len(pairdb) // (B * world)) * B
+        pairdb = pairdb[rank * per_rank:(rank + 1) * per_rank]
+        config.dataset.model_dir = os.path.join(args.from_files, "models")
+        file_loader = TrainDataLoader(sym_instance, pairdb, config, batch_size=B, shuffle=bool(config.TRAIN.SHUFFLE), device=device,
+                                      cache=PixelCache(device))
+        print("training from files: {} pairs on this rank under {}".format(len(pairdb), args.from_files))
 
     eval_metrics = metric.CompositeEvalMetric()
     if config.network.PRED_FLOW:
@@ -110,7 +137,9 @@ def train_net(args):
 
     for epoch in range(begin_epoch, end_epoch):
         eval_metrics.reset()
-        for nbatch, data_batch in enumerate(data.train_batches(epoch)):
+        if file_loader is not None:
+            file_loader.reset()
+        for nbatch, data_batch in enumerate(file_loader if file_loader is not None else data.train_batches(epoch)):
             if args.max_batches and nbatch >= args.max_batches:
                 break
             n_iter = int(config.network.TRAIN_ITER_SIZE) if config.network.TRAIN_ITER else 1
@@ -121,6 +150,9 @@ def train_net(args):
             for o in outs:
                 eval_metrics.update(None, o)
             batch_end_callback(callback.BatchEndParam(epoch=epoch, nbatch=nbatch, eval_metric=eval_metrics, locals=None))
+        if file_loader is not None and file_loader.cache is not None:
+            print("pixel cache after epoch {}: {} files, {:.0f} MB, {} hits / {} misses".format(epoch, len(file_loader.cache), file_loader.cache.used / 2 ** 20,
+                                                                                         file_loader.cache.hits, file_loader.cache.misses))
         names, values = eval_metrics.get()
         line = "Epoch[%d] " % epoch + " ".join("Train-%s=%f" % (n, v) for n, v in zip(names, values))
         print(line)

@@ -212,18 +212,29 @@ def test_config2_training_gradients_batch16(hip_lib):
         # f32 noise of 0 in one of the two runs, which the shared forward makes rare: half the bar the flip-exposed tensors get against
         # the oracle above (measured 1e-5 .. 2.4e-3, the largest on conv6_weight, which sits under every decoder branch)
         assert l2 <= 5e-3, (k, l2)
-    # (3) permutation invariance of the summed gradient
+    # (3) permutation invariance of the summed gradient.  A sample's position decides which Winograd / stream-K / split-K partition its
+    # rows fall into, so the activations of the two runs differ by <= 1e-5 (f32 summation order) and a handful of the 1.3-20 M
+    # pre-activations per layer change sign, each turning one LeakyReLU' from 1 into 0.1.  The two effects are separated: the flips are
+    # COUNTED (bounded at 1e-5 of the units), and the gradients are compared with the LeakyReLU' masks of the original run applied to
+    # the permuted one (MutableModule.lrelu_mask_from), which leaves summation order only -- 2e-4 instead of the 5e-3 the un-masked
+    # comparison needed.
     perm = torch.as_tensor(np.random.RandomState(5).permutation(B), device=DEV)
-    mod16.forward_backward({k: v[perm].contiguous() for k, v in dev.items()})
+    masks = mod16.snapshot_lrelu_masks(perm=perm)
+    permuted = {k: v[perm].contiguous() for k, v in dev.items()}
+    mod16.forward(permuted)
+    flips = mod16.count_lrelu_flips(masks)
+    n_flip, n_unit = sum(f for f, _ in flips.values()), sum(n for _, n in flips.values())
+    print("permuted batch: {} of {} LeakyReLU units on the other branch ({})".format(n_flip, n_unit, {k: f for k, (f, _) in flips.items() if f}))
+    assert n_flip <= 1e-5 * n_unit
+    mod16.lrelu_mask_from = masks
+    mod16.backward(permuted)
+    mod16.lrelu_mask_from = None
     gp = mod16.get_grads()
     for k, a in g16.items():
         if np.abs(a).max() == 0:
             continue
         l2 = np.linalg.norm((gp[k] - a).ravel()) / (np.linalg.norm(a.ravel()) + 1e-30)
-        # a sample's position decides which Winograd / stream-K / split-K partition its rows fall into: the activations of the two runs
-        # differ by <= 1e-5 (f32 summation order; tools/diag_first_iter.py) and 0-9 of the 1.3-20 M pre-activations per layer change
-        # sign, each turning one LeakyReLU' from 1 into 0.1: measured 2.8e-3 on conv6_bias, 2.4e-3 on conv6_weight, <= 1.5e-3 elsewhere
-        assert l2 <= 5e-3, (k, l2)
+        assert l2 <= 2e-4, (k, l2)
     # (4) one SGD step moves every learnable tensor and keeps the frozen ones
     before = mod16.get_params()
     mod16.update(cfg.TRAIN.lr)

@@ -36,6 +36,21 @@ def test_train_then_test_entry_points(hip_lib, tmp_path):
     assert glob.glob(os.path.join(cwd, "output", "deepim_hip", "*", "synthetic_val_ape", "*_results.pkl"))
 
 
+def test_train_entry_point_from_files(hip_lib, tmp_path):
+    """deepim/train.py --from_files: the reference's data path (pairdb -> TrainDataLoader, train.py:136) on a synthetic dataset written to
+    disk -- epoch 0 decodes the PNG files, every later epoch is served by the decoded-pixel cache in HBM"""
+    import re
+
+    cwd = str(tmp_path)
+    out = _run("train.py", ["--num_pairs", "32", "--frequent", "1", "--from_files", os.path.join(cwd, "dataset")], cwd)
+    assert "training from files: 32 pairs" in out and "Epoch[7]" in out and "Train-Flow_L2Loss=" in out
+    assert len(glob.glob(os.path.join(cwd, "dataset", "pairs", "*-color.png"))) == 32
+    m = re.findall(r"pixel cache after epoch (\d+): (\d+) files, \d+ MB, (\d+) hits / (\d+) misses", out)
+    assert len(m) == 8 and int(m[0][1]) == 5 * 32 and int(m[0][3]) == 5 * 32       # first epoch: every file decoded once
+    assert int(m[-1][3]) == 5 * 32 and int(m[-1][2]) == 7 * 5 * 32                 # later epochs: hits only
+    assert not any(v != v for v in map(float, re.findall(r"Train-Flow_L2Loss=([-+0-9.e]+|nan)", out)))
+
+
 def test_two_rank_training_replicas_stay_identical(hip_lib, tmp_path):
     """world_size 2 on ONE card (gloo carries the gradient sum; on a multi-GPU node the same code runs over RCCL): after 2 epochs x 4
     updates with different pairs per rank both replicas hold bit-identical weights (deepim/train.py asserts it and prints the digest).

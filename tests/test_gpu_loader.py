@@ -357,3 +357,61 @@ def test_train_loader_vs_oracle_and_pixel_cache(hip_lib, tmp_path, monkeypatch, 
             np.testing.assert_array_equal(b1[name], b2[name])
     cfg.network.INPUT_DEPTH, cfg.network.ROT_TYPE = False, "QUAT"
     cfg.dataset.class_name = ["ape"]
+
+
+def test_training_from_files_equals_training_from_resident_copies(hip_lib, tmp_path):
+    """fit_batch fed straight from TrainDataLoader (staging sets re-used while the previous batch is still being trained on, pixel
+    cache from the second epoch on) ends in the same weights, bit for bit, as fit_batch fed private copies of the same batches --
+    i.e. nothing the loader hands out is overwritten while the training step still reads it.  Dataset: the synthetic LINEMOD-shaped
+    tree of lib/dataset/synthetic_files.py (PNG files + points.xyz)."""
+    from deepim.core.loader import PixelCache, TrainDataLoader
+    from deepim.core.module import MutableModule, fit_batch
+    from deepim.symbols.deepIM_flownet import deepIM_flownet
+    from lib.dataset.synthetic_files import write_synthetic_dataset
+    from lib.pair_matching.batch_updater_py_multi import batchUpdaterPyMulti
+    from lib.render_hip.render_py_multi import Render_Py
+    from lib.utils import image as I
+    from lib.utils import synthetic as syn
+
+    cfg = make_train_config()
+    cfg.dataset.class_name = ["ape", "can"]
+    cfg.TRAIN.INIT_MASK, cfg.TRAIN.MASK_DILATE, cfg.TRAIN.FLOW_WEIGHT_TYPE = "box_rendered", True, "viz"
+    cfg.network.TRAIN_ITER_SIZE = 2
+    cfg.train_iter.NUM_3D_SAMPLE = 500
+    models = syn.make_models(seed=2333, n_models=2, subdiv=3)
+    rm = Render_Py(None, cfg.dataset.class_name, syn.LINEMOD_K, meshes=models)
+    B, n = 2, 6
+    db = write_synthetic_dataset(str(tmp_path), rm, models, cfg.dataset.class_name, n, seed=77, chunk=4)
+    assert len(db) == n and os.path.exists(os.path.join(str(tmp_path), "models", "can", "points.xyz"))
+    cfg.dataset.model_dir = os.path.join(str(tmp_path), "models")
+    I.point_cloud_dict.clear()
+    sym = deepIM_flownet()
+    sym.get_symbol(cfg, is_train=True)
+    params = sym.init_weights(cfg, {}, {}, seed=0)
+    upd = batchUpdaterPyMulti(cfg, H, W, render_machine=rm)
+
+    def run(private_copies):
+        mod = MutableModule(cfg, params, B)
+        loader = TrainDataLoader(None, db, cfg, batch_size=B, shuffle=False, device=DEV, workers=4, cache=PixelCache(DEV, 1 << 30))
+        losses = []
+        for epoch in range(2):
+            loader.reset()
+            for batch in loader:
+                if private_copies:
+                    batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+                    torch.cuda.synchronize()
+                outs = fit_batch(mod, batch, upd, 1e-4)
+                losses.append(float(outs[-1]["flow_loss_sum"]) + float(outs[-1]["point_matching_loss_sum"]))
+        hits = loader.cache.hits
+        loader.close()
+        return mod.flat_w.clone(), losses, hits
+
+    w_a, loss_a, hits_a = run(False)
+    w_b, loss_b, hits_b = run(True)
+    assert torch.isfinite(w_a).all() and hits_a >= 5 * n   # the whole second epoch came from the cache
+    # (the loss read-outs are sums of per-workgroup atomic adds: equal up to the order of the additions; the weights are not)
+    np.testing.assert_allclose(loss_a, loss_b, rtol=1e-5)
+    assert all(np.isfinite(loss_a)) and max(loss_a) > 0
+    assert torch.equal(w_a, w_b)
+    cfg.dataset.class_name = ["ape"]
+    cfg.network.TRAIN_ITER_SIZE = 4
