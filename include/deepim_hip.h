@@ -348,6 +348,9 @@ int dim_conv2d_dgrad_bf16(const float* dy, const void* w_dgrad_packed_bf16, floa
 int dim_deconv4x4s2_fwd_bf16(const float* x, const void* w_packed_bf16, const float* bias, float* y, int N, int H, int W, int Cin,
                              int in_cstride, int Cout, int OH, int OW, int crop, float slope, int out_cstride, int out_coff, int tile,
                              void* stream);
+/* pixel-split count that makes dim_conv2d_wgrad_bf16's whole grid resident at once on n_cu compute units (size the slab workspace
+ * with it: dim_conv2d_wgrad_workspace_floats) */
+int dim_conv2d_wgrad_bf16_splits(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int n_cu);
 int dim_conv2d_wgrad_bf16(const float* x, const float* dz, float* dw_packed, float* workspace, int N, int H, int W, int Cin, int in_cstride,
                           int Ho, int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits,
                           int accumulate, void* stream);

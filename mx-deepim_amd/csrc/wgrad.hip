@@ -32,6 +32,8 @@ struct WgradArgs {
   int chunks_per_plane, dz_plane_stride;
   int bf16;  // products on v_mfma_f32_32x32x16_bf16 (conv_wgrad_bf16_kernel); the result is f32 in the same packed layout
   int xcd;   // number the workgroups XCD-contiguously (wgrad_block below)
+  int dbg;   // timing-only ablation switches of the bf16 kernel (DIM_WGB_DBG; results are wrong when set): 1 no LDS stores after the
+             // first step, 8 no MFMAs, 16 no global loads after the prologue
 };
 
 // (chunk tile, output-channel tile, pixel split) of this workgroup.  The hardware deals linear block ids round-robin to the 8 XCDs, so
@@ -214,6 +216,13 @@ __device__ __forceinline__ wbf16x4 wg_to_bf16x4(const float4& v) {
   return p;
 }
 
+// Occupancy: 40 KB of LDS per workgroup of the wide instantiation (NW = 4, NCH = 4) = 3 workgroups per CU, whatever the register count
+// (measured: a grid of 768 = 3 x 256 workgroups runs 20-25 % faster than one of 1024; amdgpu_waves_per_eu(4, 4) fits the kernel into 124
+// registers without spilling and changes nothing).  The phases of a step -- global loads, convert + LDS stores, barrier, transposing
+// reads, MFMAs -- do not overlap inside one workgroup (timing-only ablations: 221 us = 49 skeleton + epilogue + slab sum, + 33 MFMA,
+// + ~35 LDS reads, + ~25 stores, + ~80 global loads on conv3_1), so the co-resident workgroups are what hides them: the launcher's
+// callers size the pixel split so that the whole grid is resident at once, and the global loads run TWO steps ahead (two register
+// sets: the registers are there, occupancy is LDS-bound).
 template <int NW, bool CIN8, int NCH>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
   constexpr int BP = 32;              // pixels per step = two k-steps of the instruction
@@ -261,8 +270,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
   const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz), 0, a.dz_bytes, 0x00020000);
   const int z_voff = (a.dz_coff + co0 + zq * 4) * 4;
 
-  float4 rz[4], rx[XP][NCH];
-  auto load_step = [&](int st, bool pf) {
+  // two staging register sets: while set A (step st + 1) waits to be written to LDS, the loads of step st + 2 fill set B
+  float4 rzA[4], rxA[XP][NCH], rzB[4], rxB[XP][NCH];
+  auto load_step = [&](float4 (&rz)[4], float4 (&rx)[XP][NCH], int st, bool pf) {
     const int p0 = st * BP;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
       }
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](const float4 (&rz)[4], const float4 (&rx)[XP][NCH], int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<wbf16x4*>(&sZ[buf][(zr0 + ZR_STEP * i) * LDZ + zq * 4]) = wg_to_bf16x4(rz[i]);
 #pragma unroll
@@ -317,17 +327,13 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
   const int x_el = (8 * (g >> 1) + tq) * LDX + wc * (32 * TJ) + 16 * (g & 1) + 4 * tp;
   typedef ws16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
-  if (step_begin < step_end) {
-    load_step(step_begin, true);
-    store_step(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int st = step_begin; st < step_end; ++st) {
-    load_step(min(st + 1, a.nsteps - 1), st + 1 < step_end);
+  const int dbg = a.dbg;
+  union Frag { ws16x4 h[2]; wbf16x8 v; };
+  // the MFMAs of the step in LDS buffer `buf`
+  auto compute = [&](int buf) {
+    Frag fa[TI], fb;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      union { ws16x4 h[2]; wbf16x8 v; } fa[TI];
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
         const __bf16* pz = &sZ[buf][z_el + 16 * ks * LDZ + 32 * i];
@@ -336,17 +342,34 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
-        union { ws16x4 h[2]; wbf16x8 v; } fb;
         const __bf16* px = &sX[buf][x_el + 16 * ks * LDX + 32 * j];
         fb.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(px));
         fb.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(px + 4 * LDX));
+        if (!(dbg & 8)) {
 #pragma unroll
-        for (int i = 0; i < TI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].v, fb.v, acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].v, fb.v, acc[i][j], 0, 0, 0);
+        }
       }
     }
-    store_step(buf ^ 1);
+  };
+  const int last = a.nsteps - 1;
+  if (step_begin < step_end) {
+    load_step(rzA, rxA, step_begin, true);
+    store_step(rzA, rxA, 0);
+    load_step(rzA, rxA, min(step_begin + 1, last), step_begin + 1 < step_end);   // step st + 1 is in flight when the loop starts
+  }
+  __syncthreads();
+  // two steps per trip so that the register sets keep their names: LDS buffer 0 holds step st, set A step st + 1
+  for (int st = step_begin; st < step_end; st += 2) {
+    if (!(dbg & 16)) load_step(rzB, rxB, min(st + 2, last), st + 2 < step_end);
+    compute(0);
+    if (!(dbg & 1)) store_step(rzA, rxA, 1);
     __syncthreads();
-    buf ^= 1;
+    if (st + 1 >= step_end) break;
+    if (!(dbg & 16)) load_step(rzA, rxA, min(st + 3, last), st + 3 < step_end);
+    compute(1);
+    if (!(dbg & 1)) store_step(rzB, rxB, 0);
+    __syncthreads();
   }
   // D: col = lane&31 -> kin, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co within the tile's 32
   const int fi = lane & 31, fh = lane >> 5;
@@ -367,6 +390,123 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
         *o = v;
       }
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------- bf16, patch form
+// The gathered-tap kernel above moves 32 KB of f32 operands through the vector memory pipe per 32-pixel step of a 128 x 128 tile:
+// 512 cycles of a CU's 64 B/clk against 258 cycles of MFMA work -- it is bound by that pipe, not by latency (timing-only ablations
+// and a two-step-ahead prefetch that changed nothing).  For the 3x3 / stride-1 layers this kernel cuts the bytes per MFMA 3.2x:
+//   workgroup  = 128 output channels x ONE 32-channel input slice x ALL nine taps (288 packed columns), 4 waves = 4 strips of 32 rows
+//   step       = one 8 x 8 block of output pixels: the dZ tile (64 px x 128 co) and ONE 10 x 10 input patch of the slice are staged in
+//                LDS (bf16); every tap reads its own shifted window of the patch through the transposing read (a lane supplies the
+//                address of its own pixel row, so a window is just nine different base offsets)
+//   per step   : 44.8 KB through the memory pipe (700 clk) for 1160 clk of MFMA work -- the gathered form needs 144 KB for the same work
+// Patch pixels are 64 B apart: the four pixels a 16-lane group transposes sit on four disjoint quarters of the 64 banks.
+// Pixel blocks that hang over the map edge load zeros (buffer range check), so partial blocks need no special path.
+template <int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_bf16_patch_kernel(WgradArgs a) {
+  constexpr int BM = 128, TAPS = KS * KS, PW = 8 + KS - 1, PP = PW * PW;   // patch: (8 + K - 1)^2 input pixels
+  constexpr int LDZ = BM + 32;                   // dZ rows: 320 B apart (bank quarters of the transposing read, as above)
+  constexpr int ZF4 = 64 * (BM / 4) / 256;       // float4 per thread of the dZ tile = 8
+  constexpr int XF4 = (PP * 8 + 255) / 256;      // float4 per thread of the patch (100 px x 8) = 4
+  __shared__ __attribute__((aligned(16))) __bf16 sZ[2][64 * LDZ];
+  __shared__ __attribute__((aligned(16))) __bf16 sX[2][PP * 32];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cc = blockIdx.x;           // input-channel slice
+  const int co0 = blockIdx.y * BM;
+  const int split = blockIdx.z;
+  const int nbx = (a.Wo + 7) >> 3, nby = (a.Ho + 7) >> 3;
+  const int nblocks = a.N * nby * nbx;
+  const int blk_begin = split * a.steps_per_split, blk_end = min(nblocks, blk_begin + a.steps_per_split);
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz), 0, a.dz_bytes, 0x00020000);
+  const int zq = tid & 31, zc = tid >> 5;   // dZ: float4 column zq of pixel column zc, block rows 0..7
+  float4 rzA[ZF4], rxA[XF4];   // ONE staging set: the loads of block b + 1 are issued before the ~1200 cycles of MFMAs of block b
+  auto load_block = [&](float4 (&rz)[ZF4], float4 (&rx)[XF4], int blk, bool pf) {
+    const int n = blk / (nby * nbx), r = blk - n * (nby * nbx), by = r / nbx, bx = r - by * nbx;
+    const int y0 = by * 8, x0 = bx * 8;
+#pragma unroll
+    for (int i = 0; i < ZF4; ++i) {
+      const int y = y0 + i, x = x0 + zc;
+      const bool ok = pf && y < a.Ho && x < a.Wo;
+      rz[i] = buf_load16(rsz, ok ? (((n * a.Ho + y) * a.Wo + x) * a.dz_cstride + a.dz_coff + co0 + zq * 4) * 4 : -1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < XF4; ++i) {
+      const int idx = tid + 256 * i, pp = idx >> 3, c4 = idx & 7;
+      const int py = pp / PW, px = pp - py * PW;
+      const int iy = y0 - a.pad + py, ix = x0 - a.pad + px;
+      const bool ok = pf && idx < PP * 8 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      rx[i] = buf_load16(rsx, ok ? (((n * a.H + iy) * a.W + ix) * a.in_cstride + cc * 32 + c4 * 4) * 4 : -1, 0);
+    }
+  };
+  auto store_block = [&](const float4 (&rz)[ZF4], const float4 (&rx)[XF4], int buf) {
+#pragma unroll
+    for (int i = 0; i < ZF4; ++i) *reinterpret_cast<wbf16x4*>(&sZ[buf][(8 * i + zc) * LDZ + zq * 4]) = wg_to_bf16x4(rz[i]);
+#pragma unroll
+    for (int i = 0; i < XF4; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < PP * 8) *reinterpret_cast<wbf16x4*>(&sX[buf][idx * 4]) = wg_to_bf16x4(rx[i]);
+    }
+  };
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposing-read addresses (see the gathered kernel): lane 4q + p of 16-lane group g points at pixel 8 (g >> 1) + q of the k-step,
+  // channels 16 (g & 1) + 4p .. +3.  A k-step = two rows of the 8 x 8 block: pixel j -> block row 2 ks + (j >> 3), column j & 7.
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  const int z_el = (8 * (g >> 1) + tq) * LDZ + wave * 32 + 16 * (g & 1) + 4 * tp;
+  const int x_el = ((g >> 1) * PW + tq) * 32 + 16 * (g & 1) + 4 * tp;   // patch pixel (row g >> 1, column tq) of tap (0, 0)
+  typedef ws16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+  union Frag { ws16x4 h[2]; wbf16x8 v; };
+  auto compute = [&](int buf) {
+#pragma unroll 1
+    for (int ks = 0; ks < 4; ++ks) {   // not unrolled: hipcc hoists every fragment read of an unrolled body (36 x 4 registers)
+      Frag fa;
+      const __bf16* pz = &sZ[buf][z_el + 16 * ks * LDZ];
+      fa.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pz));
+      fa.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pz + 4 * LDZ));
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int dy = t / KS, dx = t - dy * KS;
+        Frag fb;
+        const __bf16* px = &sX[buf][x_el + ((2 * ks + dy) * PW + dx) * 32];
+        fb.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(px));
+        fb.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(px + 4 * 32));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[t], 0, 0, 0);
+      }
+    }
+  };
+
+  if (blk_begin < blk_end) {
+    load_block(rzA, rxA, blk_begin, true);
+    store_block(rzA, rxA, 0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int blk = blk_begin; blk < blk_end; ++blk) {
+    load_block(rzA, rxA, min(blk + 1, nblocks - 1), blk + 1 < blk_end);
+    compute(buf);
+    store_block(rzA, rxA, buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // D: col = lane & 31 -> kin, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> co within the wave's 32
+  const int fi = lane & 31, fh = lane >> 5;
+  float* base = gridDim.z == 1 ? a.dw : a.dw + (long)split * a.nchunks * a.Cout * 32;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    float* out = base + ((long)(cc * TAPS + t) * a.Cout + co0 + wave * 32 + 4 * fh) * 32 + fi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(long)((r & 3) + 8 * (r >> 2)) * 32] = acc[t][r];
   }
 }
 
@@ -506,6 +646,11 @@ __global__ void lrelu_bwd_kernel(const float* __restrict__ y, int y_cstride, int
 
 namespace dim {
 int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, int accumulate, void* stream);
+// shapes the patch form of the bf16 kernel takes: 3x3 / stride 1 / pad 1 on maps large enough that 8 x 8 blocks waste little
+static bool wgrad_patch_ok(const WgradArgs& a) {
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 32 == 0 && a.Cout % 128 == 0 && a.chunks_per_plane == 0 &&
+         a.H == a.Ho && a.W == a.Wo && a.Ho * a.Wo >= 1200;
+}
 }
 using namespace dim;
 
@@ -539,6 +684,33 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   a.div_ho = make_fastdiv((unsigned)Ho);
   a.nchunks = (Cin == 8) ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
   return wgrad_launch(a, dw_packed, workspace, splits, accumulate, stream);
+}
+
+// The pixel-split count that makes the whole grid of dim_conv2d_wgrad_bf16 resident at once on a chip of n_cu compute units (one
+// plan for every caller: the training executor sizes its slab workspace with it).  Gathered form: 3 workgroups of the 128-row kernel
+// per CU (40 KB of LDS each), 4 of the 64-row one, a workgroup = 4 K chunks; patch form: 2 workgroups per CU (235 registers), a
+// workgroup = one 32-channel slice x all taps, the split unit is an 8 x 8 pixel block.  Every split keeps at least 4 steps.
+int dim_conv2d_wgrad_bf16_splits(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int n_cu) {
+  if (N <= 0 || n_cu <= 0) return 1;
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  WgradArgs a = {};
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+  static const int patch_env = [] { const char* e = getenv("DIM_WGB_PATCH"); return e ? atoi(e) : 1; }();
+  long tiles, steps, slots;
+  if (patch_env && wgrad_patch_ok(a)) {
+    tiles = (long)(Cin / 32) * (Cout / 128);
+    steps = (long)N * ((Ho + 7) / 8) * ((Wo + 7) / 8);
+    slots = 2L * n_cu;
+  } else {
+    const bool wide = Cout % 128 == 0;
+    const long nchunks = Cin == 8 ? (KH * KW + 3) / 4 : (long)KH * KW * (Cin / 32);
+    tiles = (nchunks + 3) / 4 * (wide ? Cout / 128 : Cout / 64);
+    steps = ((long)N * Ho * Wo + 31) / 32;
+    slots = (wide ? 3L : 4L) * n_cu;
+  }
+  long sp = slots / (tiles > 0 ? tiles : 1);
+  if (sp > steps / 4) sp = steps / 4;
+  return (int)(sp < 1 ? 1 : sp);
 }
 
 int dim_conv2d_wgrad_bf16(const float* x, const float* dz, float* dw_packed, float* workspace, int N, int H, int W, int Cin, int in_cstride,
@@ -581,8 +753,25 @@ int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, i
   a.accumulate = accumulate;
   static const int xcd_env = [] { const char* e = getenv("DIM_WGRAD_XCD"); return e ? atoi(e) : 1; }();
   a.xcd = xcd_env;
+  static const int dbg_env = [] { const char* e = getenv("DIM_WGB_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg_env;
   hipStream_t st = as_stream(stream);
   const bool nw4 = Cout % 128 == 0;
+  static const int patch_env = [] { const char* e = getenv("DIM_WGB_PATCH"); return e ? atoi(e) : 1; }();
+  if (a.bf16 && patch_env && wgrad_patch_ok(a)) {
+    // patch form: the split unit is an 8 x 8 pixel block, the grid (Cin / 32, Cout / 128, splits)
+    const int nblocks = a.N * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
+    if (splits > nblocks) splits = nblocks;
+    a.steps_per_split = ceil_div(nblocks, splits);
+    splits = ceil_div(nblocks, a.steps_per_split);
+    a.dw = splits > 1 ? workspace : dw_packed;
+    DIM_REQUIRE(!accumulate, "accumulate is not supported by the patch form");
+    hipLaunchKernelGGL((conv_wgrad_bf16_patch_kernel<3>), dim3(Cin / 32, Cout / 128, splits), dim3(256), 0, st, a);
+    int rcp = check_launch("conv_wgrad_bf16_patch");
+    if (rcp != DIM_OK) return rcp;
+    if (splits > 1) return dim_splitk_reduce(workspace, nullptr, dw_packed, (long)a.nchunks * Cout * 32 / 4, 4, splits, 1.0f, stream);
+    return DIM_OK;
+  }
   if (a.bf16) {
     const int nch = a.nchunks >= 4 ? 4 : a.nchunks >= 2 ? 2 : 1;  // chunks (x 32 packed columns) per workgroup sharing one dZ tile
     dim3 gridb(ceil_div(a.nchunks, nch), Cout / (nw4 ? 128 : 64), splits);

@@ -162,17 +162,19 @@ class MutableModule(object):
             blocks = nchunks * (cout // 128 if cout % 128 == 0 else cout // 64)
             nsteps = -(-B * ho * wo // 32)
             sp = max(1, min(-(-4096 // blocks), max(1, nsteps // 4)))
-            if self.bf16:  # a workgroup covers four K chunks (128 packed columns); ~1024 workgroups, each at least 4 pixel steps long
-                # (iteration at B = 16 with the XCD-contiguous numbering, same box: target 512: 7.22 ms, 768: 7.42, 1024: 7.21, 1280: 7.22,
-                # 1536: 7.41, 2048: 7.29, 3072: 7.51, 4096: 7.71 -- 768 workgroups are resident at once)
-                blocks = -(-nchunks // 4) * (cout // 128 if cout % 128 == 0 else cout // 64)
-                sp = max(1, min(-(-1024 // blocks), max(1, nsteps // 4)))
+            if self.bf16:
+                # the WHOLE grid must be resident at once (2-4 workgroups per CU by kernel form): a grid one workgroup over that runs a
+                # second, nearly empty round in which nothing overlaps the phases of a step.  tools/wgrad_sweep.py at B = 16,
+                # workgroups: us -- conv3_1 756: 155, 1044: 187, 1512: 168; conv2 767: 252, 1027: 318 (the round-2 rule aimed at ~1024
+                # with a ceiling division and overshot the 768 slots on every layer).  One plan function for every caller:
+                sp = ops.lib().dim_conv2d_wgrad_bf16_splits(B, h, w, c, cout, k, k, s, p, 256)
             self.wgrad_splits[name] = sp
             max_ws = max(max_ws, ops.lib().dim_conv2d_wgrad_workspace_floats(cout, c, k, k, sp))
             max_pack = max(max_pack, ops.lib().dim_conv2d_packed_weight_floats(cout, c, k, k))
             h, w, c = ho, wo, cout
         max_pack = max(max_pack, 256 * 81920, 4 * 4 * 512 * 1024, 4 * 4 * 256 * ops.pad64(1026))
-        max_ws = max(max_ws, ops.lib().dim_conv_small_cout_bwd_workspace_floats(B, 30, 40, 770, 2, 3, 3),
+        max_ws = max(max_ws, ops.lib().dim_conv2d_wgrad_workspace_floats(ops.pad64(1026), 256, 4, 4, 3),   # deconv4's split gradient (_deconv_bwd)
+                     ops.lib().dim_conv_small_cout_bwd_workspace_floats(B, 30, 40, 770, 2, 3, 3),
                      ops.lib().dim_conv_small_cout_bwd_workspace_floats(B, 15, 20, 1026, 2, 3, 3),
                      ops.lib().dim_conv_small_cout_bwd_workspace_floats(B, 8, 10, 1024, 2, 3, 3))
         self.ws = torch.empty(max_ws, dtype=torch.float32, device=d)
@@ -516,7 +518,10 @@ class MutableModule(object):
         g, w = self.g, self.w
         N, h, wd, _ = x.shape
         # weight gradient through the convolution view: conv'(input = dz, k4, s2, pad 1) with "output gradient" = x
-        ops.conv2d_wgrad_ex(dz, dz_coff, cout, x, 0, x_cpad, 4, 4, 2, 1, self.gpack, bf16_mfma=self.bf16)
+        # (bf16: deconv4's view is 544 workgroups of the 64-row kernel: three pixel splits fill the resident slots, 183 -> 151 us)
+        sp = 3 if (self.bf16 and N * h * wd >= 4096 and x_cpad % 128 != 0) else 1
+        ops.conv2d_wgrad_ex(dz, dz_coff, cout, x, 0, x_cpad, 4, 4, 2, 1, self.gpack, splits=sp, workspace=self.ws if sp > 1 else None,
+                            bf16_mfma=self.bf16)
         ops.conv2d_unpack_weight(self.gpack, g[name + "_weight"], CoutPad=x_cpad)
         ops.bias_grad(dz, cout, g[name + "_bias"], dz_coff=dz_coff, workspace=self.bias_ws)
         # data gradient: the same convolution applied to dz

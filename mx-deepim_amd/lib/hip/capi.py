@@ -66,6 +66,7 @@ SIGNATURES = {
     "dim_conv2d_fwd_ex_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_conv2d_dgrad_bf16": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_deconv4x4s2_fwd_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, P]),
+    "dim_conv2d_wgrad_bf16_splits": (I, [I, I, I, I, I, I, I, I, I, I]),
     "dim_conv2d_wgrad_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_conv2d_fwd_ex": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_conv2d_pack_weight_padded": (I, [P, P, I, I, I, I, I, P]),

@@ -109,6 +109,11 @@ BWD_CASES = [
     (2, 8, 10, 256, 512, 3, 1, 1, 1),
     (1, 21, 35, 128, 256, 3, 1, 1, 2),
     (3, 13, 9, 32, 64, 3, 1, 1, 2),    # one chunk column group only partly filled (9 chunks, 4 per workgroup)
+    # the patch form of the weight gradient (3x3 / stride 1, >= 1200 pixels, Cout % 128 == 0): 8 x 8 pixel blocks that hang over both map
+    # edges, several input slices / output tiles, block ranges split unevenly, and a single split
+    (2, 36, 44, 64, 128, 3, 1, 1, 7),
+    (1, 40, 48, 96, 256, 3, 1, 1, 1),
+    (3, 30, 40, 32, 128, 3, 1, 1, 100),   # more splits than blocks per split can fill: clamped
 ]
 
 
