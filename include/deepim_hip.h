@@ -345,6 +345,13 @@ int dim_conv2d_fwd_ex_bf16(const float* x, const void* w_packed_bf16, const floa
 int dim_conv2d_dgrad_bf16(const float* dy, const void* w_dgrad_packed_bf16, float* dx, int N, int H, int W, int Cin, int dx_cstride,
                           int Ho, int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad, int accumulate, int tile,
                           void* stream);
+/* The same with the contraction (taps x output channels of dy) cut into `splits` ranges (tile 3 / 4 only): the small maps give too
+ * few tiles to fill the chip.  Partial sums go to `workspace` (dim_conv2d_dgrad_splitk_workspace_floats: `splits` copies of dx) and
+ * one pass adds them up in a fixed order (deterministic); every phase of a strided gradient needs >= splits K chunks. */
+long dim_conv2d_dgrad_splitk_workspace_floats(int N, int H, int W, int dx_cstride, int splits);
+int dim_conv2d_dgrad_bf16_splitk(const float* dy, const void* w_dgrad_packed_bf16, float* dx, float* workspace, int N, int H, int W, int Cin,
+                                 int dx_cstride, int Ho, int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad,
+                                 int accumulate, int tile, int splits, void* stream);
 int dim_deconv4x4s2_fwd_bf16(const float* x, const void* w_packed_bf16, const float* bias, float* y, int N, int H, int W, int Cin,
                              int in_cstride, int Cout, int OH, int OW, int crop, float slope, int out_cstride, int out_coff, int tile,
                              void* stream);

@@ -53,6 +53,8 @@ struct ConvArgs {
   int slab_row0;   // split-K slabs hold rows [slab_row0, M)
   long slab_stride;  // elements between the slabs of consecutive splits
   int bf16;          // weights are packed bf16, products on v_mfma_f32_32x32x16_bf16 (conv_bf16_kernel)
+  int slab_full;     // split-K slabs are whole copies of the OUTPUT tensor (its channel stride, offset and scatter): the partial
+                     // results of a strided / scattered launch (input-gradient phases) land where the final values go, slab by slab
 };
 
 // Epilogue of the gathered-tap kernels (f32 and bf16): bias + LeakyReLU (+ accumulate) and the store of a wave's TM x TN accumulator
@@ -66,17 +68,18 @@ struct ConvArgs {
 template <int TM, int TN>
 __device__ __forceinline__ void conv_store_tiles(const ConvArgs& a, const f32x16 (&acc)[TM][TN], float* yb, int mrow, int ncol, int split) {
   const bool final = gridDim.z == 1;
-  const int ldc = final ? a.out_cstride : a.Cout;
+  const bool shaped = final || a.slab_full;   // addressed like the output tensor itself
+  const int ldc = shaped ? a.out_cstride : a.Cout;
   float* base = final ? yb : yb + (long)split * a.slab_stride;
-  const unsigned extent = final ? a.y_bytes : (unsigned)((long)(a.M - a.slab_row0) * a.Cout * 4);
+  const unsigned extent = shaped ? a.y_bytes : (unsigned)((long)(a.M - a.slab_row0) * a.Cout * 4);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(base, 0, extent, 0x00020000);
   float bv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) bv[j] = (final && a.has_bias) ? a.bias[ncol + 32 * j] : 0.f;
   const float slope = final ? a.slope : 1.0f;
   int voff[TM][16];   // byte offset of the row's channel ncol (tile j: + 128 j bytes), -1 = not stored
-  if (!final || a.dense_out) {
-    const int col_b = ((final ? a.out_coff : 0) + ncol) * 4, row0 = final ? 0 : a.slab_row0;
+  if (!shaped || a.dense_out) {
+    const int col_b = ((shaped ? a.out_coff : 0) + ncol) * 4, row0 = shaped ? 0 : a.slab_row0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1553,6 +1556,7 @@ struct ConvEx {
   long bx = 0, bw = 0, by = 0;
   int boy = 0, box = 0;  // scattered output: per-problem offset increments (see ConvArgs)
   int bf16 = 0;          // w_packed holds bf16 (dim_f32_to_bf16 of the f32 packed array): run on the bf16 matrix pipe
+  int slab_full = 0;     // split-K into output-shaped slabs (ConvArgs.slab_full): the caller sums them (slab_sum_rows)
 };
 
 static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
@@ -1598,8 +1602,11 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   a.chunks_per_split = (a.nchunks + splits - 1) / splits;
   splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
   DIM_REQUIRE(splits == 1 || workspace, "split-K needs a workspace (dim_conv2d_workspace_floats)");
-  DIM_REQUIRE(splits == 1 || !ex || (a.dense_out && a.out_cstride == Cout && a.out_coff == 0),
+  a.slab_full = (ex && ex->slab_full && splits > 1) ? 1 : 0;
+  DIM_REQUIRE(splits == 1 || !ex || a.slab_full || (a.dense_out && a.out_cstride == Cout && a.out_coff == 0),
               "split-K writes a dense [M][Cout] result: not available with a strided / scattered output");
+  DIM_REQUIRE(!a.slab_full || (a.bf16 && (tile == 3 || tile == 4) && (!ex || ex->batch == 1)),
+              "output-shaped split-K slabs: bf16 gathered-tap kernel (tile 3 / 4), single problem");
   a.y = splits > 1 ? workspace : y;
   // every kernel stores through a buffer descriptor with 32-bit byte offsets (branch-free epilogues)
   DIM_REQUIRE((long)N * a.OH * a.OW * a.out_cstride * 4 < (1L << 31), "output too large for 32-bit byte offsets (%ld bytes)",
@@ -1608,7 +1615,7 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   DIM_REQUIRE(splits == 1 || (long)a.M * Cout * 4 < (1L << 31), "split-K slab too large for 32-bit byte offsets (%ld bytes)", (long)a.M * Cout * 4);
   a.tile_off = 0;
   a.slab_row0 = 0;
-  a.slab_stride = (long)N * a.Ho * a.Wo * Cout;
+  a.slab_stride = a.slab_full ? (long)N * a.OH * a.OW * a.out_cstride : (long)N * a.Ho * a.Wo * Cout;
   const int batch = ex ? ex->batch : 1;
   a.bx = ex ? ex->bx : 0; a.bw = ex ? ex->bw : 0; a.by = ex ? ex->by : 0;
   a.boy = ex ? ex->boy : 0; a.box = ex ? ex->box : 0;
@@ -1743,6 +1750,7 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   }
   int rc = launch(a, splits, 0, -1);
   if (rc != DIM_OK) return rc;
+  if (a.slab_full) return DIM_OK;   // the caller sums the output-shaped slabs once all its launches are in
   if (splits > 1 && !partial_only) return dim_splitk_reduce(workspace, bias, y, (long)a.M, Cout, splits, slope, stream);
   return DIM_OK;
 }
@@ -1916,10 +1924,31 @@ int dim_conv2d_dgrad_pack_weight_bf16(const float* w_oihw, void* w_packed_bf16, 
 }
 
 // dx (N,H,W,dx_cstride)[..., :Cin] (+)= dgrad(dy (N,Ho,Wo,dy_cstride)[..., :Cout]).  accumulate != 0 adds to dx (skip connections).
+// dst[row][0:width] (+)= sum over the slabs of slab[row][0:width]; rows are `pitch` floats apart in dst and in every slab
+__global__ __launch_bounds__(256) void slab_sum_rows_kernel(const float* __restrict__ slabs, long slab_stride, int nslabs,
+                                                            float* __restrict__ dst, long rows, int width4, int pitch, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * width4) return;
+  const long row = i / width4;
+  const int c = (int)(i - row * width4) * 4;
+  const long o = row * pitch + c;
+  float4 s = accumulate ? *reinterpret_cast<const float4*>(dst + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < nslabs; ++k) {   // fixed order: deterministic
+    const float4 v = *reinterpret_cast<const float4*>(slabs + (long)k * slab_stride + o);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(dst + o) = s;
+}
+
 static int conv2d_dgrad_impl(const float* dy, const float* w_dgrad_packed, float* dx, int N, int H, int W, int Cin, int dx_cstride, int Ho,
                              int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad, int accumulate, int tile, int bf16,
-                             void* stream) {
+                             void* stream, float* workspace = nullptr, int splits = 1) {
   if (N == 0) return DIM_OK;
+  // split-K (bf16, gathered-tap tiles): the small maps give 80-600 workgroups to 1280 resident slots and every workgroup walks
+  // K = 4608 .. 9216 alone on its CU; `splits` K ranges write output-shaped slabs (every phase of a strided gradient into the same
+  // slabs, each to its own pixels) and ONE pass sums them into dx
+  const bool split = splits > 1;
+  DIM_REQUIRE(!split || (bf16 && workspace && (tile == 3 || tile == 4)), "split-K input gradient: bf16, tile 3 or 4, workspace required");
   DIM_REQUIRE(stride == 1 || stride == 2, "dgrad supports stride 1 or 2");
   int CinPad = (Cin + 63) / 64 * 64;
   DIM_REQUIRE(dx_cstride >= CinPad, "dx channel stride (%d) must be >= Cin rounded up to 64 (%d)", dx_cstride, CinPad);
@@ -1935,16 +1964,22 @@ static int conv2d_dgrad_impl(const float* dy, const float* w_dgrad_packed, float
         ex.pad_w = -aw.emin;
         ex.Ho = Th;
         ex.Wo = Tw;
-        ex.accumulate = accumulate;
+        ex.accumulate = split ? 0 : accumulate;
         ex.bf16 = bf16;
+        ex.slab_full = split ? 1 : 0;
         if (total > 0) {
           // tile 9 (bf16 patch kernel) takes the phases with 2 .. 9 taps; a single-tap phase is a 1x1 convolution: gathered-tap kernel
           int ptile = tile;
           if (tile == 9 && !(bf16 && ah.ntaps <= 3 && aw.ntaps <= 3 && ah.ntaps * aw.ntaps >= 2))
             ptile = CinPad % 128 == 0 ? 4 : 3;
+          // every slab of every phase must be written: the phase's K chunks have to make exactly `splits` non-empty ranges
+          const int nch = ah.ntaps * aw.ntaps * (Cout / 32);
+          const int psplits = split ? splits : 1;
+          DIM_REQUIRE(!split || (nch >= splits && (nch + (nch + splits - 1) / splits - 1) / ((nch + splits - 1) / splits) == splits),
+                      "split-K input gradient: a phase has %d K chunks, which do not make %d non-empty splits", nch, splits);
           int rc = conv2d_fwd_impl(dy, bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(w_dgrad_packed) + 2 * off)
-                                            : w_dgrad_packed + off, nullptr, dx, nullptr, N, Ho, Wo, Cout, CinPad, ah.ntaps, aw.ntaps, 1,
-                                   -ah.emin, 1.0f, 1, ptile, 0, stream, &ex);
+                                            : w_dgrad_packed + off, nullptr, dx, split ? workspace : nullptr, N, Ho, Wo, Cout, CinPad,
+                                   ah.ntaps, aw.ntaps, 1, -ah.emin, 1.0f, psplits, ptile, 0, stream, &ex);
           if (rc != DIM_OK) return rc;
         } else if (!accumulate) {
           return set_err(DIM_ERR_ARG, "phase (%d,%d) has no taps: dX rows of that phase would stay unwritten", py, px);
@@ -1952,6 +1987,12 @@ static int conv2d_dgrad_impl(const float* dy, const float* w_dgrad_packed, float
       }
       off += total;
     }
+  if (split) {
+    const long rows = (long)N * H * W;
+    hipLaunchKernelGGL(slab_sum_rows_kernel, dim3(ceil_div(rows * (CinPad / 4), 256)), dim3(256), 0, as_stream(stream), workspace,
+                       rows * dx_cstride, splits, dx, rows, CinPad / 4, dx_cstride, accumulate);
+    return check_launch("slab_sum_rows");
+  }
   return DIM_OK;
 }
 
@@ -1966,6 +2007,20 @@ int dim_conv2d_dgrad_bf16(const float* dy, const void* w_dgrad_packed_bf16, floa
                           void* stream) {
   return conv2d_dgrad_impl(dy, reinterpret_cast<const float*>(w_dgrad_packed_bf16), dx, N, H, W, Cin, dx_cstride, Ho, Wo, Cout, dy_cstride,
                            KH, KW, stride, pad, accumulate, tile, 1, stream);
+}
+
+long dim_conv2d_dgrad_splitk_workspace_floats(int N, int H, int W, int dx_cstride, int splits) {
+  return splits > 1 ? (long)splits * N * H * W * dx_cstride : 0;
+}
+
+int dim_conv2d_dgrad_bf16_splitk(const float* dy, const void* w_dgrad_packed_bf16, float* dx, float* workspace, int N, int H, int W, int Cin,
+                                 int dx_cstride, int Ho, int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad,
+                                 int accumulate, int tile, int splits, void* stream) {
+  DIM_REQUIRE(splits >= 1, "splits >= 1");
+  DIM_REQUIRE(dx_cstride % 4 == 0 && (reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+              "split-K input gradient: dx / workspace 16-byte aligned, channel stride a multiple of 4");
+  return conv2d_dgrad_impl(dy, reinterpret_cast<const float*>(w_dgrad_packed_bf16), dx, N, H, W, Cin, dx_cstride, Ho, Wo, Cout, dy_cstride,
+                           KH, KW, stride, pad, accumulate, tile, 1, stream, workspace, splits);
 }
 
 int dim_conv2d_fwd_partial(const float* x, const float* w_packed, float* workspace, int N, int H, int W, int Cin, int Cout, int KH,

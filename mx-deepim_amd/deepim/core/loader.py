@@ -172,7 +172,13 @@ class _DeviceLoader(object):
     def __len__(self):
         return self.size // self.batch_size   # whole batches (the resident executors are built for one batch size)
 
+    def _fresh(self):
+        """nothing consumed since the last reset(): a second reset() in a row (an epoch loop that resets before its first epoch,
+        right after the constructor did) keeps the batch already being staged"""
+        return getattr(self, "_handed_out", 1) == 0
+
     def _rewind(self):
+        self._handed_out = 0
         if getattr(self, "_inflight", None) is not None:
             self._inflight.result()   # a batch staged ahead but never consumed: let it finish before the sets are reused
         self.cur = 0
@@ -207,6 +213,7 @@ class _DeviceLoader(object):
         if fut is None:
             raise StopIteration
         st = fut.result()
+        self._handed_out += 1
         self._inflight = self._submit()
         return st
 
@@ -331,6 +338,8 @@ class TestDataLoader(_DeviceLoader):
         self.reset()
 
     def reset(self):
+        if self._fresh():
+            return
         self._rewind()
         if self.shuffle:
             np.random.shuffle(self.index)
@@ -494,6 +503,8 @@ class TrainDataLoader(_DeviceLoader):
         self.reset()
 
     def reset(self):
+        if self._fresh():
+            return
         self._rewind()
         if self.shuffle:
             np.random.shuffle(self.index)

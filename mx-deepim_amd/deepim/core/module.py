@@ -170,6 +170,9 @@ class MutableModule(object):
                 sp = ops.lib().dim_conv2d_wgrad_bf16_splits(B, h, w, c, cout, k, k, s, p, 256)
             self.wgrad_splits[name] = sp
             max_ws = max(max_ws, ops.lib().dim_conv2d_wgrad_workspace_floats(cout, c, k, k, sp))
+            if self.bf16 and c != 8:   # split-K slabs of this layer's input gradient (copies of dX), see _dgrad_splits
+                ksp = self._dgrad_splits(self._bf16_gemm_tile(B * ho * wo, ops.pad64(c)), B * ho * wo, ops.pad64(c), cout)
+                max_ws = max(max_ws, ops.lib().dim_conv2d_dgrad_splitk_workspace_floats(B, h, w, ops.pad64(c), ksp))
             max_pack = max(max_pack, ops.lib().dim_conv2d_packed_weight_floats(cout, c, k, k))
             h, w, c = ho, wo, cout
         max_pack = max(max_pack, 256 * 81920, 4 * 4 * 512 * 1024, 4 * 4 * 256 * ops.pad64(1026))
@@ -399,8 +402,9 @@ class MutableModule(object):
                         dg_tile = 7   # stride-1 input gradient of a large map: LDS-halo kernel
                     if self.bf16 and BF16_PATCH and k in (3, 5) and dy.shape[1] * dy.shape[2] >= 1200:
                         dg_tile = 9   # stride-1 patch kernel: the gradient itself (stride 1) or its four phase convolutions (stride 2)
+                    ksp = self._dgrad_splits(dg_tile, dy.shape[0] * dy.shape[1] * dy.shape[2], ops.pad64(cin[name]), cout) if self.bf16 else 1
                     ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False,
-                                     tile=dg_tile)
+                                     tile=dg_tile, splits=ksp, workspace=self.ws if ksp > 1 else None)
         self._bucket_ready(None)
         return g
 
@@ -527,6 +531,20 @@ class MutableModule(object):
         # data gradient: the same convolution applied to dz
         ops.conv2d_fwd_ex(dz, dz_coff, cout, self.dgrad_packed[name], None, dx, 0, x_cpad, 4, 4, 2, 1, Ho=h, Wo=wd, accumulate=False,
                           tile=self._bf16_gemm_tile(N * h * wd, x_cpad) if self.bf16 else 3)
+
+    @staticmethod
+    def _dgrad_splits(tile, rows, cols, cout):
+        """split-K count of a bf16 input gradient on the gathered-tap kernel: the small maps (conv5 .. conv6_1: 1280-4800 rows per
+        launch) make 144-600 tiles of 64 x 64 for the 1280 workgroups that fit the chip (5 per CU), and each walks K = 4608-9216 alone.
+        The K range is cut so that the grid fills the slots; every phase of a strided gradient must keep >= splits chunks of 32 dy
+        channels (its 1-tap phase has cout / 32).  DIM_BF16_DGRAD_SPLITK=0: off."""
+        if tile != 3 or os.environ.get("DIM_BF16_DGRAD_SPLITK", "1") == "0":
+            return 1
+        tiles = -(-rows // 64) * (cols // 64)
+        for sp in (8, 4, 2):
+            if sp * tiles <= 1280 and (cout // 32) % sp == 0:
+                return sp
+        return 1
 
     @staticmethod
     def _bf16_gemm_tile(rows, cols):

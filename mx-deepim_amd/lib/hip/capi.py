@@ -65,6 +65,8 @@ SIGNATURES = {
     "dim_conv2d_fwd_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, P]),
     "dim_conv2d_fwd_ex_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_conv2d_dgrad_bf16": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dim_conv2d_dgrad_splitk_workspace_floats": (L, [I, I, I, I, I]),
+    "dim_conv2d_dgrad_bf16_splitk": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_deconv4x4s2_fwd_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, P]),
     "dim_conv2d_wgrad_bf16_splits": (I, [I, I, I, I, I, I, I, I, I, I]),
     "dim_conv2d_wgrad_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),

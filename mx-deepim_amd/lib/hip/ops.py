@@ -609,11 +609,20 @@ def conv2d_dgrad_pack_weight(w_oihw, stride, pad, as_bf16=False):
     return wp
 
 
-def conv2d_dgrad(dy_nhwc, Cout, w_dgrad_packed, dx_nhwc, Cin, KH, KW, stride, pad, accumulate=False, tile=3):
-    """dx[..., :Cin] (+)= dgrad(dy[..., :Cout]); dx / dy may be wider concat buffers."""
+def conv2d_dgrad(dy_nhwc, Cout, w_dgrad_packed, dx_nhwc, Cin, KH, KW, stride, pad, accumulate=False, tile=3, splits=1, workspace=None):
+    """dx[..., :Cin] (+)= dgrad(dy[..., :Cout]); dx / dy may be wider concat buffers.
+    splits > 1 (bf16 weights, tile 3 / 4): split-K through output-shaped slabs in `workspace` (small maps: too few tiles for the chip)"""
     N, Ho, Wo, dy_cs = dy_nhwc.shape
     _, H, W, dx_cs = dx_nhwc.shape
     wp, is16 = _wp(w_dgrad_packed)
+    if splits > 1:
+        assert is16, "split-K input gradient is built for the bf16 kernels"
+        need = lib().dim_conv2d_dgrad_splitk_workspace_floats(N, H, W, dx_cs, splits)
+        if workspace is None or workspace.numel() < need:
+            workspace = _new((need,), dx_nhwc)
+        check(lib().dim_conv2d_dgrad_bf16_splitk(dptr(dy_nhwc, f32), wp, dptr(dx_nhwc, f32), dptr(workspace, f32), N, H, W, Cin, dx_cs, Ho, Wo,
+                                                 Cout, dy_cs, KH, KW, stride, pad, int(accumulate), tile, splits, current_stream()))
+        return dx_nhwc
     fn = lib().dim_conv2d_dgrad_bf16 if is16 else lib().dim_conv2d_dgrad
     check(fn(dptr(dy_nhwc, f32), wp, dptr(dx_nhwc, f32), N, H, W, Cin, dx_cs, Ho, Wo, Cout, dy_cs,
              KH, KW, stride, pad, int(accumulate), tile, current_stream()))

@@ -148,6 +148,17 @@ def test_dgrad_wgrad_bf16(ops, case):
         ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dx9, Cin, k, k, s, p, accumulate=True, tile=9)   # out += result
         got9 = dx9[..., :Cin].permute(0, 3, 1, 2).cpu().double().numpy()
         assert np.abs(got9 - 2 * xr.grad.numpy()).max() <= 2e-4 * xr.grad.abs().max().item() + 2e-5
+    # split-K through output-shaped slabs (the small maps): same result as the single launch up to f32 summation order; every phase of a
+    # strided gradient needs >= splits K chunks (a 1-tap phase of a 32-wide dy has one)
+    ksp = 2 if s == 1 or Cout >= 64 else 1
+    if ksp > 1:
+        dxs = torch.full((N, H, W, ops.pad64(Cin)), 5.0, device=DEV)
+        ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dxs, Cin, k, k, s, p, accumulate=False, tile=3, splits=ksp)
+        gots = dxs[..., :Cin].permute(0, 3, 1, 2).cpu().double().numpy()
+        assert np.abs(gots - xr.grad.numpy()).max() <= 1e-4 * xr.grad.abs().max().item() + 1e-5
+        ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, dxs, Cin, k, k, s, p, accumulate=True, tile=3, splits=ksp)   # dx += result
+        gots = dxs[..., :Cin].permute(0, 3, 1, 2).cpu().double().numpy()
+        assert np.abs(gots - 2 * xr.grad.numpy()).max() <= 2e-4 * xr.grad.abs().max().item() + 2e-5
     dwp = torch.zeros_like(ops.conv2d_pack_weight(w.float().to(DEV)))
     ops.conv2d_wgrad(nhwc(x.float()), Cin, nhwc(dy.float()), Cout, k, k, s, p, dwp, splits=splits, bf16_mfma=True)
     ref = ops.conv2d_pack_weight(wr.grad.float().to(DEV))
