@@ -241,7 +241,11 @@ class FlowNetHip(object):
             for name, cout, k, s, p in ENCODER:
                 h, w = ops.conv_out_hw(h, w, k, k, s, p)
                 tiles = -(-batch_size * h * w // 128) * (cout // 128) if cout % 128 == 0 else 0
-                self.conv_plan[name] = (bf16_tile(cout) if c != 8 else 3, 1 if (tiles == 0 or tiles >= 256) else min(4, -(-512 // tiles)))
+                # split-K on the small maps: the 8-wave 128 x 128 kernel keeps 2 workgroups per CU = 512 resident slots, and a grid just
+                # over that pays a second, nearly empty round (the round-2 rule, ceil(512 / tiles) capped at 4, gave conv5 / conv5_1
+                # 608 workgroups).  tools/fwd_bf16_sweep.py at B = 16, splits: us incl. the slab sum -- conv5 3: 54, 4: 62; conv5_1 3: 52,
+                # 4: 59; conv6 3: 32, 4: 39, 6: 36; conv6_1 3: 50, 4: 61, 6: 49
+                self.conv_plan[name] = (bf16_tile(cout) if c != 8 else 3, 1 if (tiles == 0 or tiles >= 256) else max(1, min(3, 512 // tiles)))
                 # 3x3 / stride-1 layers on large maps: the LDS-halo kernel (conv.hip conv_bf16_halo_kernel, tile 7).  Measured at B = 16
                 # against the gathered-tap kernel: conv3_1 0.150 vs 0.161 ms, conv4_1 0.175 vs 0.177; the stride-2 layers lose (conv2
                 # 0.366 vs 0.256, conv3 0.286 vs 0.247, conv4 0.143 vs 0.102: their 45-53 KB patches + 41 KB of weight buffers leave
