@@ -225,6 +225,11 @@ int dim_splitk_reduce(const float* slabs, const float* bias, float* y, long M, i
  * as a split-K launch of proportionally shorter workgroups + reduce.  Needs workspace = dim_conv2d_workspace_floats(..., splits=0).
  * dim_conv2d_tail_plan reports the plan for a shape: first tile of the tail and its split count (1 = single launch). */
 int dim_conv2d_tail_plan(int M, int Cout, int Cin, int KH, int KW, int tile, int* tail_begin_tile, int* tail_splits);
+/* The default launch plans of the f32 forward path, in ONE place for every host (FlowNetHip in Python, dim_refiner_create in C):
+ * (tile, splits) of a direct layer with M GEMM rows and `nchunks` K chunks of 32 (splits 0 = the "auto" tail plan above), and the
+ * workgroup tile of a Winograd layer's plane GEMMs (3 / 4 / 5 = 64 x 64 / 128 x 128 / 128 x 256) for `tiles` transform tiles. */
+int dim_conv_auto_plan(long M, int Cout, int nchunks, int cin, int* tile, int* splits);
+int dim_winograd_gemm_tile(int Cout, long tiles);
 int dim_conv2d_fwd_ex(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int in_cstride,
                       int Cout, int KH, int KW, int stride, int pad, float slope, int tile, int out_cstride, int out_coff, int OH,
                       int OW, int osy, int osx, int ooy, int oox, int Ho, int Wo, int pad_w, int accumulate, void* stream);

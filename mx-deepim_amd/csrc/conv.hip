@@ -1525,6 +1525,42 @@ static void conv_tail_plan(int M, int Cout, int nchunks, int tile, int* tail_beg
   }
 }
 
+// ONE copy of the default launch plans of the f32 forward path: the Python executor (FlowNetHip) and the C resident loop
+// (dim_refiner_create) both call these, so the two cannot drift apart.
+// (tile, splits) of a direct layer (tools/tune_conv.py, batch 16, MI355X): 128 x 128 tiles on 8 waves (tile 4) wherever Cout allows,
+// 64 x 64 (tile 3) for Cout = 64 and the 8-channel first layer; splits 0 = "auto" (whole tiles per CU + split-K tail inside the
+// library) when every CU gets at least one tile, otherwise the split-K count that minimises the busiest CU's share: all workgroups
+// of a launch are equal, the busiest CU gets ceil(tiles s / CUs) of them, each 1 / s of a tile-time long, + 2 % of a tile-time per
+// slab for the extra prologues, slab traffic and the reduce.
+int dim_conv_auto_plan(long M, int Cout, int nchunks, int cin, int* tile, int* splits) {
+  DIM_REQUIRE(tile && splits && M > 0 && Cout > 0 && nchunks > 0, "bad arguments");
+  const int n_cu = 256;
+  auto best_split = [&](long tiles, int smax) {
+    double best = 1e30;
+    int bs = 1;
+    for (int s = 1; s <= smax; ++s) {
+      if (!(s * 4 <= nchunks || s == 1)) continue;
+      const double t = (double)((tiles * s + n_cu - 1) / n_cu) / s + 0.02 * s;
+      if (t < best) { best = t; bs = s; }
+    }
+    return bs;
+  };
+  const bool wide = Cout % 128 == 0 && cin != 8;
+  const long tiles = wide ? (M + 127) / 128 * (Cout / 128) : (M + 63) / 64 * (Cout / 64);
+  *tile = wide ? 4 : 3;
+  *splits = tiles >= n_cu ? 0 : best_split(tiles, 8);
+  return DIM_OK;
+}
+
+// workgroup tile of a Winograd layer's plane GEMMs (wino_gemm.hip): 5 = 128 rows x 256 output channels (V is streamed once per 256
+// channels: conv3, conv3_1, conv4_1), 4 = 128 x 128 (conv2: Cout = 128), 3 = 64 x 64 for the small maps.  DIM_WINO_BN256=0 keeps the
+// 128 x 128 tile everywhere (A/B timing).
+int dim_winograd_gemm_tile(int Cout, long tiles) {
+  static const int bn256 = [] { const char* e = getenv("DIM_WINO_BN256"); return e ? atoi(e) : 1; }();
+  if (tiles < 1024 || Cout % 128) return 3;
+  return (Cout % 256 == 0 && bn256) ? 5 : 4;
+}
+
 int dim_conv2d_tail_plan(int M, int Cout, int Cin, int KH, int KW, int tile, int* tail_begin_tile, int* tail_splits) {
   DIM_REQUIRE(tail_begin_tile && tail_splits, "null pointer");
   if (tile == 0) tile = (Cout % 128 == 0 && Cin != 8 && M >= 128) ? 4 : 3;

@@ -24,35 +24,7 @@ static const Layer kEncoder[10] = {{"flow_conv1", 64, 7, 2, 3}, {"conv2", 128, 5
                                    {"conv4", 512, 3, 2, 1},     {"conv4_1", 512, 3, 1, 1}, {"conv5", 512, 3, 2, 1},  {"conv5_1", 512, 3, 1, 1},
                                    {"conv6", 1024, 3, 2, 1},    {"conv6_1", 1024, 3, 1, 1}};
 
-// lib/hip/ops.py conv_auto_plan: (tile, splits) of a direct layer
-static void auto_plan(long M, int Cout, int nchunks, int cin, int* tile, int* splits) {
-  const int n_cu = 256;
-  auto best_split = [&](long tiles, int smax) {
-    double best = 1e30;
-    int bs = 1;
-    for (int s = 1; s <= smax; ++s) {
-      if (!(s * 4 <= nchunks || s == 1)) continue;
-      double t = (double)((tiles * s + n_cu - 1) / n_cu) / s + 0.02 * s;
-      if (t < best) { best = t; bs = s; }
-    }
-    return bs;
-  };
-  if (Cout % 128 == 0 && cin != 8) {
-    long tiles = (M + 127) / 128 * (Cout / 128);
-    *tile = 4;
-    *splits = tiles >= n_cu ? 0 : best_split(tiles, 8);
-  } else {
-    long blocks = (M + 63) / 64 * (Cout / 64);
-    *tile = 3;
-    *splits = blocks >= n_cu ? 0 : best_split(blocks, 8);
-  }
-}
-
-// deepim/symbols/deepIM_flownet.py FlowNetHip._wino_tile
-static int wino_tile(int cout, long tiles) {
-  if (tiles < 1024 || cout % 128) return 3;
-  return cout % 256 == 0 ? 5 : 4;
-}
+// (the launch plans come from dim_conv_auto_plan / dim_winograd_gemm_tile in conv.hip: one copy for this file and for FlowNetHip)
 
 struct LayerPlan {
   int kind;  // 0 direct, 1 Winograd F(4x4,3x3), 2 phase-image Winograd (5x5 / stride 2)
@@ -142,14 +114,14 @@ int dim_refiner_create(dim_refiner** out, const dim_refiner_desc* desc, const ch
     TRY(dev_alloc(r, (void**)&P.out, (size_t)M * ly.cout * 4));
     if (ly.k == 3 && ly.s == 1 && ly.p == 1) {
       P.kind = 1;
-      P.tile = wino_tile(ly.cout, (long)B * ((h + 3) / 4) * ((w + 3) / 4));
+      P.tile = dim_winograd_gemm_tile(ly.cout, (long)B * ((h + 3) / 4) * ((w + 3) / 4));
       P.splits = 1;
       TRY(dev_alloc(r, (void**)&P.w_packed, (size_t)dim_winograd_packed_weight_floats(ly.cout, c, 4) * 4));
       TRY(dim_winograd_pack_weight(wsrc, P.w_packed, ly.cout, c, 4, stream));
       max_ws = std::max(max_ws, dim_winograd_workspace_floats(B, h, w, c, ly.cout, 4));
     } else if (ly.k == 5 && ly.s == 2 && ly.p == 2) {
       P.kind = 2;
-      P.tile = wino_tile(ly.cout, (long)B * ((P.ho + 3) / 4) * ((P.wo + 3) / 4));
+      P.tile = dim_winograd_gemm_tile(ly.cout, (long)B * ((P.ho + 3) / 4) * ((P.wo + 3) / 4));
       P.splits = 1;
       TRY(dev_alloc(r, (void**)&P.w_packed, (size_t)dim_winograd5x5s2_packed_weight_floats(ly.cout, c) * 4));
       TRY(dim_winograd5x5s2_pack_weight(wsrc, P.w_packed, ly.cout, c, stream));
@@ -157,7 +129,7 @@ int dim_refiner_create(dim_refiner** out, const dim_refiner_desc* desc, const ch
     } else {
       P.kind = 0;
       const int nchunks = c == 8 ? (ly.k * ly.k + 3) / 4 : ly.k * ly.k * (c / 32);
-      auto_plan(M, ly.cout, nchunks, c, &P.tile, &P.splits);
+      TRY(dim_conv_auto_plan(M, ly.cout, nchunks, c, &P.tile, &P.splits));
       if (c == 8 && ly.k == 7 && ly.s == 2 && ly.cout == 64) { P.tile = 6; P.splits = 1; }  // LDS-halo first-layer kernel, as FlowNetHip
       TRY(dev_alloc(r, (void**)&P.w_packed, (size_t)dim_conv2d_packed_weight_floats(ly.cout, c, ly.k, ly.k) * 4));
       TRY(dim_conv2d_pack_weight(wsrc, P.w_packed, ly.cout, c, ly.k, ly.k, stream));

@@ -335,14 +335,8 @@ class FlowNetHip(object):
 
     @staticmethod
     def _wino_tile(cout, tiles):
-        """workgroup tile of a layer's plane GEMMs (wino_gemm.hip): 5 = 128 rows x 256 output channels (V is streamed once per 256
-        channels instead of once per 128: conv3, conv3_1, conv4_1), 4 = 128 x 128 (conv2: Cout = 128), 3 = 64 x 64 for the small maps.
-        DIM_WINO_BN256=0 keeps the 128 x 128 tile everywhere (A/B timing)."""
-        import os
-
-        if tiles < 1024 or cout % 128:
-            return 3
-        return 5 if (cout % 256 == 0 and os.environ.get("DIM_WINO_BN256", "1") != "0") else 4
+        """workgroup tile of a layer's plane GEMMs: dim_winograd_gemm_tile, the one copy of the rule (shared with csrc/refiner.hip)"""
+        return int(ops.lib().dim_winograd_gemm_tile(int(cout), int(tiles)))
 
     @staticmethod
     def _wino_info(m, S, tile, tiles, cin, cout, x_floats, y_floats):

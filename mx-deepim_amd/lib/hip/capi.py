@@ -88,6 +88,8 @@ SIGNATURES = {
     "dim_conv_small_cout_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_deconv4x4s2_tiny_bwd": (I, [P, I, P, I, I, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dim_conv2d_tail_plan": (I, [I, I, I, I, I, I, P, P]),
+    "dim_conv_auto_plan": (I, [L, I, I, I, P, P]),
+    "dim_winograd_gemm_tile": (I, [I, L]),
     "dim_winograd_packed_weight_floats": (L, [I, I, I]),
     "dim_winograd_workspace_floats": (L, [I, I, I, I, I, I]),
     "dim_winograd_pack_weight": (I, [P, P, I, I, I, P]),

@@ -276,27 +276,13 @@ TILE_NAMES = {1: "128x128 (4 waves)", 2: "128x64", 3: "64x64", 4: "128x128 (8 wa
 
 
 def conv_auto_plan(M, Cout, nchunks, cin=32):
-    """default (tile, splits) when the caller does not autotune (tools/tune_conv.py, batch 16, MI355X): 128x128 tiles with 8 waves
-    (tile 4) wherever Cout allows, 64x64 tiles (tile 3) for Cout = 64 and the 8-channel first layer.  splits: 0 (auto: whole tiles
-    per CU + split-K tail, decided inside the library) when every CU gets at least one tile, otherwise the split-K count that
-    minimises the busiest CU's share."""
-    n_cu = 256
+    """default (tile, splits) of a direct f32 layer when the caller does not autotune: dim_conv_auto_plan -- the ONE copy of the
+    rule, shared with the C resident loop (csrc/refiner.hip)"""
+    import ctypes
 
-    def best_split(tiles, smax):
-        # all workgroups of a launch are equal: the busiest CU gets ceil(tiles*s / CUs) of them, each 1/s of a tile-time long
-        # (+2 % of a tile-time per slab for the extra prologues, slab traffic and the reduce)
-        cands = [(-(-tiles * s // n_cu) / float(s) + 0.02 * s, s) for s in range(1, smax + 1) if s * 4 <= nchunks or s == 1]
-        return min(cands)[1]
-
-    if Cout % 128 == 0 and cin != 8:
-        tiles = -(-M // 128) * (Cout // 128)
-        if tiles >= n_cu:
-            return 4, 0      # auto: whole tiles per CU + split tail (dim_conv2d_fwd, splits == 0)
-        return 4, best_split(tiles, 8)
-    blocks = -(-M // 64) * (Cout // 64)
-    if blocks >= n_cu:
-        return 3, 0
-    return 3, best_split(blocks, 8)
+    tile, splits = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib().dim_conv_auto_plan(int(M), int(Cout), int(nchunks), int(cin), ctypes.byref(tile), ctypes.byref(splits)))
+    return tile.value, splits.value
 
 
 def copy(dst, src):
