@@ -311,12 +311,13 @@ def fresh_batch_bench(cfg, rm, refiner, B, dev, steps, warmup):
                         "dim_box_mask -> hipGraph replay; decode of image files not included"}
 
 
-def train_fresh_batch_bench(cfg, models, rm, B, dev, epochs=4, n_batches=6):
+def train_fresh_batch_bench(cfg, models, rm, B, dev, epochs=5, n_batches=6):
     """Non-headline `train_fresh_batch` object: the training step of the `train` object, but every data batch comes FROM
     IMAGE FILES through deepim/core/loader.TrainDataLoader -- PNG decode on a thread pool -> pinned staging -> copy stream -> every blob
     and label of get_data_pair_train_batch built in HBM (csrc/data.hip) -> fit_batch (TRAIN_ITER_SIZE forward / backward / update +
-    re-render in between).  Epoch 1 decodes the files; from epoch 2 on every file is served by the decoded-pixel cache in HBM.
-    `resident` = the same fit_batch on one batch that never leaves HBM.  A synthetic LINEMOD-shaped dataset is written to a scratch
+    re-render in between).  Epoch 1 decodes the files; from epoch 2 on every file is served by the decoded-pixel cache in HBM
+    (`cached_*`: epochs 3 .. 5, the steady state).
+    `resident` = the same fit_batch over private copies of the same batches that never touch the loader.  A synthetic LINEMOD-shaped dataset is written to a scratch
     directory first (untimed)."""
     import shutil
     import tempfile
@@ -367,18 +368,23 @@ def train_fresh_batch_bench(cfg, models, rm, B, dev, epochs=4, n_batches=6):
                 pass
             torch.cuda.synchronize()
             loader_ms = (time.perf_counter() - t0) / n_batches * 1e3
+            # the same six batches as private copies that never touch the loader (one pass: fit_batch rewrites a batch in place -- poses,
+            # rendered image, labels -- so only pristine copies are the same work as a loader epoch)
             loader.reset()
-            resident = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in next(loader).items()}
+            resident = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()} for batch in loader]
             loader.close()
-            fit_batch(mod, dict(resident), upd, 1e-5)
+            fit_batch(mod, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in resident[0].items()}, upd, 1e-5)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(n_batches):
-                fit_batch(mod, dict(resident), upd, 1e-5)
+            for batch in resident:
+                fit_batch(mod, batch, upd, 1e-5)
             torch.cuda.synchronize()
-            res_ms = (time.perf_counter() - t0) / n_batches * 1e3
-            warm = float(np.mean(per_epoch[1:])) if epochs > 1 else per_epoch[0]
-            res[dtype] = {"epoch1_ms_per_batch": round(per_epoch[0], 2), "cached_ms_per_batch": round(warm, 2),
+            res_ms = (time.perf_counter() - t0) / len(resident) * 1e3
+            # epoch 1 decodes the files; epoch 2 is the first one served by the cache (first use of the hit path: module loads,
+            # allocator growth); the steady state is epochs 3 ..
+            warm = float(np.mean(per_epoch[2:])) if epochs > 2 else per_epoch[-1]
+            res[dtype] = {"epoch1_ms_per_batch": round(per_epoch[0], 2), "epoch2_first_cached_ms_per_batch": round(per_epoch[min(1, epochs - 1)], 2),
+                          "cached_ms_per_batch": round(warm, 2),
                           "resident_ms_per_batch": round(res_ms, 2), "data_layer_alone_cached_ms_per_batch": round(loader_ms, 2),
                           "cached_pairs_per_s": round(B / warm * 1e3, 1),
                           "resident_pairs_per_s": round(B / res_ms * 1e3, 1), "cached_over_resident": round(res_ms / warm, 3),
