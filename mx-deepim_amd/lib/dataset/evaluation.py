@@ -114,7 +114,7 @@ class PoseEvaluator(object):
         num_iter = config.TEST.test_iter
         count_all = np.zeros((self.num_classes,), dtype=np.float32)
         count_correct = {k: np.zeros((self.num_classes, num_iter), dtype=np.float32) for k in fixed}
-        dx = curve[1] - curve[0]
+        dx = fmt["dx"]   # the reference passes the python float it built the curve from (:489, :711), not the float32 spacing
         count_correct["mean"] = np.zeros((self.num_classes, num_iter, len(curve)), dtype=np.float32)
         errors = {}
         num_valid_class = 0
@@ -182,7 +182,7 @@ class PoseEvaluator(object):
         uses_adi = any(c in SYM_CLASSES for c in self.classes)
         return self._threshold_eval(
             config, all_poses_est, all_poses_gt, err, {"0.02": 0.02, "0.05": 0.05, "0.10": 0.10},
-            np.arange(0, 0.1, 0.0001).astype(np.float32), lambda c: self._diameters[c], 0.1, {"range": "0.10"},
+            np.arange(0, 0.1, 0.0001).astype(np.float32), lambda c: self._diameters[c], 0.1, {"range": "0.10", "dx": 0.0001},
             "evaluating pose add", "add", output_dir, "{}_xys.pkl".format("adi" if uses_adi else "add"), logger)
 
     # ------------------------------------------------------------------------------------------------ :683-
@@ -196,5 +196,5 @@ class PoseEvaluator(object):
 
         return self._threshold_eval(
             config, all_poses_est, all_poses_gt, err, {"2": 2.0, "5": 5.0, "10": 10.0, "20": 20.0},
-            np.arange(0, 50, 0.1).astype(np.float32), lambda c: 1.0, 50.0, {"range": "50"},
+            np.arange(0, 50, 0.1).astype(np.float32), lambda c: 1.0, 50.0, {"range": "50", "dx": 0.1},
             "evaluating pose average re-projection 2d error", "arp_2d", output_dir, "arp_2d_xys.pkl", logger)

@@ -1,5 +1,5 @@
 """Evaluation: pose-error primitives vs golden vectors produced by the reference's own functions, and the
-aggregation of lib/dataset/LM6D_REFINE.py:329-830 vs a literal loop restatement of it on seeded poses."""
+aggregation of lib/dataset/LM6D_REFINE.py:329-893 vs oracle/evaluation.py (the reference's loops, restated outside the package)."""
 import os
 
 import numpy as np
@@ -63,64 +63,57 @@ def _scene(seed=5):
     return classes, points, diam, est, gt
 
 
-def test_evaluate_pose_vs_loop_restatement():
+def test_evaluate_pose_vs_oracle():
+    """PoseEvaluator.evaluate_pose (vectorised) == oracle/evaluation.py (the loops of LM6D_REFINE.py:329-459), digit for digit"""
+    from oracle import evaluation as oe
+
     classes, points, diam, est, gt = _scene()
     out = PoseEvaluator(classes, points, diam).evaluate_pose(_Cfg, est, gt)
-    assert out["num_valid_class"] == 3
-    rot_t, tr_t = np.arange(1, 11, 1), np.arange(0.01, 0.11, 0.01)
-    for ci, c in enumerate(classes[:3]):
-        for it in range(2):
-            rd, td = [], []
-            for e, g in zip(est[ci][it], gt[ci][0]):
-                r, t = pe.calc_rt_dist_m(e, g)
-                if c == "eggbox" and r > 90:
-                    r, t = pe.calc_rt_dist_m(se3_mul(e, RT_Z), g)
-                rd.append(r); td.append(t)
-            rd, td = np.array(rd)[:, None], np.array(td)[:, None]
-            for k in range(10):
-                assert out["rot_acc"][ci, it, k] == np.mean(rd < rot_t[k])
-                assert out["trans_acc"][ci, it, k] == np.mean(td < tr_t[k])
-                assert out["space_acc"][ci, it, k] == np.mean(np.logical_and(rd < rot_t[k], td < tr_t[k]))
+    rot, tra, spc, overall, nvalid = oe.evaluate_pose(classes, est, gt, 2)
+    assert out["num_valid_class"] == nvalid == 3
+    np.testing.assert_array_equal(out["rot_acc"], rot)
+    np.testing.assert_array_equal(out["trans_acc"], tra)
+    np.testing.assert_array_equal(out["space_acc"], spc)
+    for it in range(2):
+        for k in ("RotAcc", "TraAcc", "SpcAcc"):
+            assert out["overall"][it][k] == overall[it][k]
     assert np.all(out["rot_acc"][3] == 0)                      # class without results stays zero and is not counted
     assert out["overall"][1]["RotAcc"] > out["overall"][0]["RotAcc"]   # iteration 2 poses are closer
     eg = classes.index("eggbox")
     assert out["rot_acc"][eg, 1, 9] > 0.9                      # flipped twins were folded back
+    assert 0 < rot[0, 0].min() and rot[0, 0].max() < 1         # the scene spreads over the thresholds: the table is not all 0 / 1
 
 
-def test_evaluate_pose_add_and_arp2d_vs_loop_restatement(tmp_path):
+def test_evaluate_pose_add_and_arp2d_vs_oracle(tmp_path):
+    """ADD / ADI (:461-681) and ARP-2D (:683-893) tables: fixed-threshold accuracies, per-threshold curves, Simpson areas and the
+    over-classes rows against the oracle's per-pose / per-threshold loops"""
+    from oracle import evaluation as oe
+
     classes, points, diam, est, gt = _scene(seed=9)
     ev = PoseEvaluator(classes, points, diam)
     out = ev.evaluate_pose_add(_Cfg, est, gt, output_dir=str(tmp_path))
     assert os.path.exists(os.path.join(str(tmp_path), "adi_xys.pkl"))
-    dx = 0.0001
-    base = np.arange(0, 0.1, dx).astype(np.float32)
-    for ci, c in enumerate(classes[:3]):
-        for it in range(2):
-            cnt = {"0.02": 0, "0.05": 0, "0.10": 0}
-            curve = np.zeros(len(base), np.float32)
-            thr = base * np.float32(diam[c])
-            for e, g in zip(est[ci][it], gt[ci][0]):
-                fn = pe.adi if c in ("eggbox", "glue") else pe.add
-                err = fn(e[:3, :3], e[:, 3], g[:3, :3], g[:, 3], points[c])
-                for k, f in (("0.02", 0.02), ("0.05", 0.05), ("0.10", 0.10)):
-                    cnt[k] += err < np.float32(f * diam[c])
-                for ti in range(len(thr)):                     # the reference's per-threshold loop (:538-540)
-                    if err < thr[ti]:
-                        curve[ti] += 1
-            res = out["per_class"][(c, it)]
-            for k in cnt:
-                assert res[k] == 100.0 * cnt[k] / 25
-            np.testing.assert_array_equal(out["count_correct"]["mean"][ci, it], curve)
-            assert 0.0 <= res["auc"] <= 100.0
+    per_class, overall, cc, count_all = oe.evaluate_pose_add(classes, points, diam, est, gt, 2)
+    np.testing.assert_array_equal(out["count_all"], count_all)
+    for k in ("0.02", "0.05", "0.10", "mean"):
+        np.testing.assert_array_equal(out["count_correct"][k], cc[k])
+    assert set(out["per_class"]) == set(per_class) and len(per_class) == 6
+    for key, res in per_class.items():
+        for k, v in res.items():
+            assert out["per_class"][key][k] == v, (key, k)
+    for it in range(2):
+        for k, v in overall[it].items():
+            assert abs(out["overall"][it][k] - v) <= 1e-12 * max(1.0, abs(v)), (it, k)
     assert out["overall"][1]["0.10"] >= out["overall"][0]["0.10"]
+    assert 0 < per_class[("ape", 1)]["0.10"] < 100 and 0 < per_class[("ape", 1)]["auc"] < 100   # not a degenerate table
+
     arp = ev.evaluate_pose_arp_2d(_Cfg, est, gt)
-    K = _Cfg.dataset.INTRINSIC_MATRIX
-    for ci, c in enumerate(classes[:3]):
-        errs = []
-        for e, g in zip(est[ci][1], gt[ci][0]):
-            if c == "eggbox" and pe.re(e[:3, :3], g[:3, :3]) > 90:
-                e = se3_mul(e, RT_Z)
-            errs.append(pe.arp_2d(e[:3, :3], e[:, 3], g[:3, :3], g[:, 3], points[c], K))
-        errs = np.array(errs)
-        for k in ("2", "5", "10", "20"):
-            assert arp["per_class"][(c, 1)][k] == 100.0 * np.sum(errs < float(k)) / 25
+    per_class, overall, cc, count_all = oe.evaluate_pose_arp_2d(classes, points, _Cfg.dataset.INTRINSIC_MATRIX, est, gt, 2)
+    for k in ("2", "5", "10", "20", "mean"):
+        np.testing.assert_array_equal(arp["count_correct"][k], cc[k])
+    for key, res in per_class.items():
+        for k, v in res.items():
+            assert arp["per_class"][key][k] == v, (key, k)
+    for it in range(2):
+        for k, v in overall[it].items():
+            assert abs(arp["overall"][it][k] - v) <= 1e-12 * max(1.0, abs(v)), (it, k)

@@ -1,4 +1,4 @@
-"""MXNet NDArray-list (.params) reader / writer: round trips, hand-built legacy / V1 / V2 / V3 records, error paths,
+"""MXNet NDArray-list (.params) reader / writer: round trips, legacy / V1 / V2 / V3 records built by oracle/mx_ndarray_format.py, error paths,
 and the reference-named checkpoint helpers (lib/utils/load_model.py, save_model.py)."""
 import struct
 
@@ -42,23 +42,43 @@ def test_list_without_names(tmp_path):
 
 
 def _file(records, names):
-    out = struct.pack("<QQQ", 0x112, 0, len(records)) + b"".join(records) + struct.pack("<Q", len(names))
-    for n in names:
-        out += struct.pack("<Q", len(n)) + n.encode()
-    return out
+    from oracle import mx_ndarray_format as fmt
+
+    return fmt.file_bytes(records, names)
 
 
-def test_older_on_disk_generations(tmp_path):
-    a = np.arange(6, dtype=np.float32).reshape(2, 3)
-    legacy = struct.pack("<I2I", 2, 2, 3) + struct.pack("<ii", 2, 0) + struct.pack("<i", 0) + a.tobytes()      # gpu(0) context
-    v1 = struct.pack("<II2q", 0xF993FAC8, 2, 2, 3) + struct.pack("<ii", 1, 0) + struct.pack("<i", 0) + a.tobytes()
-    v2 = struct.pack("<IiI2q", 0xF993FAC9, 0, 2, 2, 3) + struct.pack("<ii", 1, 0) + struct.pack("<i", 0) + a.tobytes()
-    v3 = struct.pack("<Iii2q", 0xF993FACA, 0, 2, 2, 3) + struct.pack("<ii", 1, 0) + struct.pack("<i", 0) + a.tobytes()
-    f = tmp_path / "gen.params"
-    f.write_bytes(_file([legacy, v1, v2, v3], ["arg:a", "arg:b", "arg:c", "arg:d"]))
-    back = mxp.nd_load(str(f))
-    for k in ("arg:a", "arg:b", "arg:c", "arg:d"):
-        np.testing.assert_array_equal(back[k], a)
+def test_writer_and_reader_against_the_oracle_format(tmp_path):
+    """the package's writer against oracle/mx_ndarray_format.py's parser and byte builder (a second, independent statement of
+    MXNet 1.2.0's NDArray::Save), and the package's reader against every generation the oracle can write"""
+    from oracle import mx_ndarray_format as fmt
+
+    rng = np.random.RandomState(3)
+    data = {"arg:w": rng.randn(4, 3, 2, 2).astype(np.float32), "arg:b": rng.randn(4).astype(np.float32),
+            "aux:m": rng.randn(2, 5).astype(np.float64), "arg:i": np.arange(6, dtype=np.int32).reshape(2, 3),
+            "arg:h": rng.randn(3).astype(np.float16), "arg:u": np.arange(5, dtype=np.uint8), "arg:q": np.array([2 ** 40, -7], np.int64)}
+    f = str(tmp_path / "w-0001.params")
+    mxp.nd_save(f, data)
+    raw = open(f, "rb").read()
+    arrays, names = fmt.parse(raw)                                     # product writer -> oracle reader
+    assert names == list(data)
+    for a, k in zip(arrays, names):
+        assert a.dtype == data[k].dtype and a.shape == data[k].shape
+        np.testing.assert_array_equal(a, data[k])
+    assert raw == fmt.file_bytes([fmt.record(v, "V2") for v in data.values()], list(data))   # and byte for byte what 1.2.0 writes
+    for gen in ("legacy", "V1", "V2", "V3"):                            # oracle writer -> product reader
+        for dev in ((1, 0), (2, 3)):                                    # saved from cpu(0) or gpu(3): the context is read and dropped
+            g = tmp_path / "g.params"
+            g.write_bytes(fmt.file_bytes([fmt.record(v, gen, *dev) for v in data.values()], list(data)))
+            back = mxp.nd_load(str(g))
+            assert list(back) == list(data)
+            for k in data:
+                assert back[k].dtype == data[k].dtype
+                np.testing.assert_array_equal(back[k], data[k])
+    g = tmp_path / "list.params"                                        # no names: mx.nd.load returns a list
+    g.write_bytes(fmt.file_bytes([fmt.record(data["arg:w"], "V1")], []))
+    back = mxp.nd_load(str(g))
+    assert isinstance(back, list) and len(back) == 1
+    np.testing.assert_array_equal(back[0], data["arg:w"])
 
 
 def test_errors(tmp_path):
