@@ -319,6 +319,16 @@ long dim_conv2d_wgrad_workspace_floats(int Cout, int Cin, int KH, int KW, int sp
 int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* workspace, int N, int H, int W, int Cin, int in_cstride,
                      int Ho, int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits,
                      int accumulate, void* stream);
+/* The same weight gradient delivered in the MXNet layout dw_oihw (Cout_rows, Cin, KH, KW) = (accumulate ? dw_oihw : 0) + scale * dW (rows
+ * Cout_rows .. Cout - 1 of a channel-padded gradient are dropped): the pixel-split slabs stay in `workspace` --
+ * dim_conv2d_wgrad_workspace_floats(Cout, Cin, KH, KW, splits + 1) floats, also for splits == 1 -- and the layout converter sums
+ * them in slab order on its way out, so the packed intermediate, its round trip through HBM and the reduce launch of
+ * dim_conv2d_wgrad + dim_conv2d_unpack_weight disappear; same bits as that pair whenever it sums slabs serially (fewer than 64 slabs or
+ * slabs of >= 2^18 floats; otherwise the lane-parallel reduce runs first, as there).  bf16_mfma: products on the bf16 matrix pipe
+ * (dim_conv2d_wgrad_bf16).  Replaces the weight-gradient half of the executor's backward (deepim/core/module.py:1205-1213). */
+int dim_conv2d_wgrad_oihw(const float* x, const float* dz, float* dw_oihw, float* workspace, int N, int H, int W, int Cin, int in_cstride,
+                          int Ho, int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits,
+                          int bf16_mfma, int Cout_rows, float scale, int accumulate, void* stream);
 /* ---------------------------------------------------------------- bf16 matrix pipe (training mode, BASELINE configs[2])
  * The reference trains in fp32 (deepim/train.py:338-414); these twins of the convolution entry points run the same implicit GEMMs
  * on v_mfma_f32_32x32x16_bf16 (f32 accumulate, 16x the f32 matrix rate): activations and gradients stay fp32 in HBM and are rounded

@@ -95,6 +95,8 @@ struct WTileArgs {
   long sg, sr, rows_x, rows_y, dq, packed_x;
   float scale;
   int accumulate;
+  int nslab;         // packed -> rows only: the packed side is the sum of nslab (0 = 1) arrays slab_stride floats apart, added in
+  long slab_stride;  // slab order (the pixel-split slabs of a weight gradient: the separate reduce pass and its round trip folded in)
   int jq[32];
   long jbase[32], jx[32];
 };
@@ -155,12 +157,12 @@ __global__ __launch_bounds__(256) void weight_tile_kernel(WTileArgs a) {
       packed[off + t] = (PT)(okp ? v : 0.f);
     }
   } else {
-    const float* packed = reinterpret_cast<const float*>(a.src) + pbase;
     float* rows = reinterpret_cast<float*>(a.dst) + rbase;
     __syncthreads();
     for (int i0 = threadIdx.x; i0 < n_packed; i0 += 1024) {
       bool okp[4];
       int laddr[4];
+      long poff[4];
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -170,7 +172,15 @@ __global__ __launch_bounds__(256) void weight_tile_kernel(WTileArgs a) {
         const long off = table ? s_jb[j] : bx * a.packed_x + j * a.dq;
         okp[e] = i < n_packed && q >= 0 && g < gvalid && r < rvalid;
         laddr[e] = WT_ADDR(g, r, max(q, 0));
-        v[e] = *(okp[e] ? packed + off + t : reinterpret_cast<const float*>(a.src));
+        poff[e] = okp[e] ? pbase + off + t : 0;
+        v[e] = reinterpret_cast<const float*>(a.src)[poff[e]];
+      }
+      for (int sl = 1; sl < a.nslab; ++sl) {  // same order as splitk_reduce_kernel: ((s0 + s1) + s2) + ...
+        float p[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = reinterpret_cast<const float*>(a.src)[poff[e] + (okp[e] ? sl * a.slab_stride : 0)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p[e];
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -206,6 +216,10 @@ inline void wtile_launch(const WTileArgs& a, int gx, int gy, hipStream_t st) {
   hipLaunchKernelGGL((weight_tile_kernel<TO_PACKED, PT>), dim3(gx, gy), dim3(256), wtile_lds_bytes(a.G, a.Q), st, a);
 }
 #endif
+
+// train.hip: packed weight-gradient layout -> (Cout, Cin, KH, KW), the packed side given as nslab slabs to be summed on the way
+int conv2d_unpack_weight_slabs(const float* w_packed, int nslab, long slab_stride, float* w_oihw, int Cout, int CoutPad, int Cin, int KH, int KW,
+                               float scale, int accumulate, void* stream);
 
 // ---- plane GEMMs of the Winograd layers (wino_gemm.hip): launch plan, shared with the input-transform kernels of conv.hip, whose
 // spare blocks zero the output tiles that two stream-K workgroups share (saves a launch per layer)

@@ -525,8 +525,9 @@ using namespace dim;
 
 extern "C" {
 
-int dim_conv2d_unpack_weight(const float* w_packed, float* w_oihw, int Cout, int CoutPad, int Cin, int KH, int KW, float scale,
-                             int accumulate, void* stream) {
+// packed = the sum of nslab arrays slab_stride floats apart (a weight gradient's pixel-split slabs, added in slab order)
+extern "C++" int dim::conv2d_unpack_weight_slabs(const float* w_packed, int nslab, long slab_stride, float* w_oihw, int Cout, int CoutPad, int Cin,
+                                                 int KH, int KW, float scale, int accumulate, void* stream) {
   DIM_REQUIRE(w_packed && w_oihw, "null pointer");
   DIM_REQUIRE(CoutPad >= Cout, "CoutPad < Cout");
   long total = (long)Cout * Cin * KH * KW;
@@ -538,12 +539,23 @@ int dim_conv2d_unpack_weight(const float* w_packed, float* w_oihw, int Cout, int
     a.sg = (long)Cin * T; a.sr = T; a.rows_x = 32L * T; a.rows_y = (long)G * Cin * T;
     a.dq = (long)CoutPad * 32; a.packed_x = (long)T * CoutPad * 32;
     a.scale = scale; a.accumulate = accumulate;
+    a.nslab = nslab; a.slab_stride = slab_stride;
     wtile_launch<false, float>(a, Cin / 32, CoutPad / G, as_stream(stream));
   } else {
+    if (nslab > 1) {  // no tiling for this shape (the 8-lane first layer): sum into slab 0 first
+      DIM_REQUIRE(slab_stride % 4 == 0, "slab stride must be a multiple of 4 floats");
+      int rc = dim_splitk_reduce(w_packed, nullptr, const_cast<float*>(w_packed), slab_stride / 4, 4, nslab, 1.0f, stream);
+      if (rc != DIM_OK) return rc;
+    }
     hipLaunchKernelGGL(unpack_conv_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_packed, w_oihw, Cout, CoutPad,
                        Cin, KH, KW, Cin == 8, scale, accumulate);
   }
   return check_launch("unpack_conv_weight");
+}
+
+int dim_conv2d_unpack_weight(const float* w_packed, float* w_oihw, int Cout, int CoutPad, int Cin, int KH, int KW, float scale,
+                             int accumulate, void* stream) {
+  return conv2d_unpack_weight_slabs(w_packed, 1, 0, w_oihw, Cout, CoutPad, Cin, KH, KW, scale, accumulate, stream);
 }
 
 int dim_fc_unpack_weight(const float* w_packed, float* w_out_in, int Out, int C, int H, int W, void* stream) {

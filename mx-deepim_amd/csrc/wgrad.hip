@@ -645,7 +645,8 @@ __global__ void lrelu_bwd_kernel(const float* __restrict__ y, int y_cstride, int
 }  // namespace dim
 
 namespace dim {
-int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, int accumulate, void* stream);
+// keep_slabs != nullptr: the split slabs stay in `workspace` (also for one split), unreduced; *keep_slabs = how many
+int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, int accumulate, void* stream, int* keep_slabs = nullptr);
 // shapes the patch form of the bf16 kernel takes: 3x3 / stride 1 / pad 1 on maps large enough that 8 x 8 blocks waste little
 static bool wgrad_patch_ok(const WgradArgs& a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 32 == 0 && a.Cout % 128 == 0 && a.chunks_per_plane == 0 &&
@@ -662,18 +663,15 @@ long dim_conv2d_wgrad_workspace_floats(int Cout, int Cin, int KH, int KW, int sp
   return n * splits;
 }
 
-// dw_packed (+)= wgrad(x, dz).  splits > 1: pixel range split through `workspace` (slabs) and summed deterministically.
-int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* workspace, int N, int H, int W, int Cin, int in_cstride,
-                     int Ho, int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits,
-                     int accumulate, void* stream) {
-  if (N == 0) return DIM_OK;
-  DIM_REQUIRE(x && dz && dw_packed, "null pointer");
+static int wgrad_args(WgradArgs& a, const float* x, const float* dz, int N, int H, int W, int Cin, int in_cstride, int Ho, int Wo, int Cout,
+                      int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad) {
+  DIM_REQUIRE(x && dz, "null pointer");
   DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
   DIM_REQUIRE(Cout % 64 == 0, "Cout must be a multiple of 64 (got %d)", Cout);
   DIM_REQUIRE((long)N * H * W * in_cstride < (1L << 29) && (long)N * Ho * Wo * dz_cstride < (1L << 29),
               "tensor too large for 32-bit byte offsets");
   DIM_REQUIRE(dz_cstride % 4 == 0 && dz_coff % 4 == 0 && in_cstride % 4 == 0, "channel strides / offsets must be multiples of 4");
-  WgradArgs a = {};
+  a = WgradArgs{};
   a.x = x; a.dz = dz;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_cstride = in_cstride; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.dz_cstride = dz_cstride; a.dz_coff = dz_coff; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
@@ -683,7 +681,53 @@ int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* w
   a.div_wo = make_fastdiv((unsigned)Wo);
   a.div_ho = make_fastdiv((unsigned)Ho);
   a.nchunks = (Cin == 8) ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
+  return DIM_OK;
+}
+
+// dw_packed (+)= wgrad(x, dz).  splits > 1: pixel range split through `workspace` (slabs) and summed deterministically.
+int dim_conv2d_wgrad(const float* x, const float* dz, float* dw_packed, float* workspace, int N, int H, int W, int Cin, int in_cstride,
+                     int Ho, int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits,
+                     int accumulate, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(dw_packed, "null pointer");
+  WgradArgs a;
+  int rc = wgrad_args(a, x, dz, N, H, W, Cin, in_cstride, Ho, Wo, Cout, dz_cstride, dz_coff, KH, KW, stride, pad);
+  if (rc != DIM_OK) return rc;
   return wgrad_launch(a, dw_packed, workspace, splits, accumulate, stream);
+}
+
+// The weight gradient straight into the MXNet layout: the pixel-split slabs stay in `workspace` and ONE layout-converter launch sums
+// them in slab order on its way to dw_oihw -- the same bits as dim_conv2d_wgrad[_bf16] + dim_conv2d_unpack_weight whenever those sum
+// their slabs serially (fewer than 64 slabs, or large ones), without the packed intermediate's round trip and the reduce launch.
+int dim_conv2d_wgrad_oihw(const float* x, const float* dz, float* dw_oihw, float* workspace, int N, int H, int W, int Cin, int in_cstride, int Ho,
+                          int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits, int bf16_mfma,
+                          int Cout_rows, float scale, int accumulate, void* stream) {
+  DIM_REQUIRE(dw_oihw && workspace, "null pointer");
+  DIM_REQUIRE(Cout_rows >= 1 && Cout_rows <= Cout, "Cout_rows must be in 1 .. Cout");
+  const long slab = (Cin == 8) ? (long)((KH * KW + 3) / 4) * 32 * Cout : (long)KH * KW * Cin * Cout;
+  if (N == 0) {
+    if (!accumulate) {
+      hipError_t e = hipMemsetAsync(dw_oihw, 0, (size_t)Cout_rows * Cin * KH * KW * 4, as_stream(stream));
+      if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    return DIM_OK;
+  }
+  WgradArgs a;
+  int rc = wgrad_args(a, x, dz, N, H, W, Cin, in_cstride, Ho, Wo, Cout, dz_cstride, dz_coff, KH, KW, stride, pad);
+  if (rc != DIM_OK) return rc;
+  a.bf16 = bf16_mfma ? 1 : 0;
+  int nslab = 0;
+  rc = wgrad_launch(a, nullptr, workspace, splits, 0, stream, &nslab);
+  if (rc != DIM_OK) return rc;
+  const float* src = workspace;
+  if (nslab >= 64 && slab / 4 < 65536) {  // many small slabs: the lane-parallel reduce (dim_splitk_reduce picks it), into the slot after them
+    float* sum = workspace + (long)nslab * slab;
+    rc = dim_splitk_reduce(workspace, nullptr, sum, slab / 4, 4, nslab, 1.0f, stream);
+    if (rc != DIM_OK) return rc;
+    src = sum;
+    nslab = 1;
+  }
+  return conv2d_unpack_weight_slabs(src, nslab, slab, dw_oihw, Cout_rows, Cout, Cin, KH, KW, scale, accumulate, stream);
 }
 
 // The pixel-split count that makes the whole grid of dim_conv2d_wgrad_bf16 resident at once on a chip of n_cu compute units (one
@@ -717,22 +761,10 @@ int dim_conv2d_wgrad_bf16(const float* x, const float* dz, float* dw_packed, flo
                           int Ho, int Wo, int Cout, int dz_cstride, int dz_coff, int KH, int KW, int stride, int pad, int splits,
                           int accumulate, void* stream) {
   if (N == 0) return DIM_OK;
-  DIM_REQUIRE(x && dz && dw_packed, "null pointer");
-  DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
-  DIM_REQUIRE(Cout % 64 == 0, "Cout must be a multiple of 64 (got %d)", Cout);
-  DIM_REQUIRE((long)N * H * W * in_cstride < (1L << 29) && (long)N * Ho * Wo * dz_cstride < (1L << 29),
-              "tensor too large for 32-bit byte offsets");
-  DIM_REQUIRE(dz_cstride % 4 == 0 && dz_coff % 4 == 0 && in_cstride % 4 == 0, "channel strides / offsets must be multiples of 4");
-  WgradArgs a = {};
-  a.x = x; a.dz = dz;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.in_cstride = in_cstride; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
-  a.dz_cstride = dz_cstride; a.dz_coff = dz_coff; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
-  a.M = N * Ho * Wo;
-  a.x_bytes = (unsigned)((long)N * H * W * in_cstride * 4);
-  a.dz_bytes = (unsigned)((long)N * Ho * Wo * dz_cstride * 4);
-  a.div_wo = make_fastdiv((unsigned)Wo);
-  a.div_ho = make_fastdiv((unsigned)Ho);
-  a.nchunks = (Cin == 8) ? (KH * KW + 3) / 4 : KH * KW * (Cin / 32);
+  DIM_REQUIRE(dw_packed, "null pointer");
+  WgradArgs a;
+  int rc = wgrad_args(a, x, dz, N, H, W, Cin, in_cstride, Ho, Wo, Cout, dz_cstride, dz_coff, KH, KW, stride, pad);
+  if (rc != DIM_OK) return rc;
   a.bf16 = 1;
   return wgrad_launch(a, dw_packed, workspace, splits, accumulate, stream);
 }
@@ -741,15 +773,15 @@ int dim_conv2d_wgrad_bf16(const float* x, const float* dz, float* dw_packed, flo
 
 namespace dim {
 
-int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, int accumulate, void* stream) {
+int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, int accumulate, void* stream, int* keep_slabs) {
   const int Cin = a.Cin, Cout = a.Cout;
   a.nsteps = ceil_div(a.M, 32);
   if (splits < 1) splits = 1;
   if (splits > a.nsteps) splits = a.nsteps;
   a.steps_per_split = ceil_div(a.nsteps, splits);
   splits = ceil_div(a.nsteps, a.steps_per_split);
-  DIM_REQUIRE(splits == 1 || workspace, "split wgrad needs a workspace (dim_conv2d_wgrad_workspace_floats)");
-  a.dw = splits > 1 ? workspace : dw_packed;
+  DIM_REQUIRE((splits == 1 && !keep_slabs) || workspace, "split wgrad needs a workspace (dim_conv2d_wgrad_workspace_floats)");
+  a.dw = (splits > 1 || keep_slabs) ? workspace : dw_packed;
   a.accumulate = accumulate;
   static const int xcd_env = [] { const char* e = getenv("DIM_WGRAD_XCD"); return e ? atoi(e) : 1; }();
   a.xcd = xcd_env;
@@ -764,11 +796,12 @@ int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, i
     if (splits > nblocks) splits = nblocks;
     a.steps_per_split = ceil_div(nblocks, splits);
     splits = ceil_div(nblocks, a.steps_per_split);
-    a.dw = splits > 1 ? workspace : dw_packed;
+    a.dw = (splits > 1 || keep_slabs) ? workspace : dw_packed;
     DIM_REQUIRE(!accumulate, "accumulate is not supported by the patch form");
     hipLaunchKernelGGL((conv_wgrad_bf16_patch_kernel<3>), dim3(Cin / 32, Cout / 128, splits), dim3(256), 0, st, a);
     int rcp = check_launch("conv_wgrad_bf16_patch");
     if (rcp != DIM_OK) return rcp;
+    if (keep_slabs) { *keep_slabs = splits; return DIM_OK; }
     if (splits > 1) return dim_splitk_reduce(workspace, nullptr, dw_packed, (long)a.nchunks * Cout * 32 / 4, 4, splits, 1.0f, stream);
     return DIM_OK;
   }
@@ -783,6 +816,7 @@ int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, i
 #undef DIM_WGB_LAUNCH
     int rcb = check_launch("conv_wgrad_bf16");
     if (rcb != DIM_OK) return rcb;
+    if (keep_slabs) { *keep_slabs = splits; return DIM_OK; }
     if (splits > 1) {
       DIM_REQUIRE(!accumulate, "accumulate with splits > 1 is not supported");
       return dim_splitk_reduce(workspace, nullptr, dw_packed, (long)a.nchunks * Cout * 32 / 4, 4, splits, 1.0f, stream);
@@ -802,6 +836,7 @@ int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, i
 #undef DIM_WG_LAUNCH
   int rc = check_launch("conv_wgrad");
   if (rc != DIM_OK) return rc;
+  if (keep_slabs) { *keep_slabs = splits; return DIM_OK; }
   if (splits > 1) {
     long n = (long)a.nchunks * Cout * 32;
     if (accumulate) {

@@ -123,6 +123,7 @@ SIGNATURES = {
     "dim_conv2d_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_conv2d_wgrad_workspace_floats": (L, [I, I, I, I, I]),
     "dim_conv2d_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dim_conv2d_wgrad_oihw": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
     "dim_bias_grad_workspace_floats": (L, [I, I]),
     "dim_bias_grad": (I, [P, P, P, I, I, I, I, I, P]),
     "dim_lrelu_bwd": (I, [P, I, I, P, I, I, L, I, F, P]),

@@ -627,6 +627,21 @@ def conv2d_wgrad(x_nhwc, Cin, dz_nhwc, Cout, KH, KW, stride, pad, dw_packed, spl
     return dw_packed
 
 
+def conv2d_wgrad_oihw(x_nhwc, Cin, dz_nhwc, Cout, KH, KW, stride, pad, dw_oihw, splits=1, dz_coff=0, workspace=None, bf16_mfma=False,
+                      scale=1.0, accumulate=False):
+    """dw_oihw (rows <= Cout, Cin, KH, KW) (+)= scale * weight gradient, slabs summed inside the layout converter (dim_conv2d_wgrad_oihw)"""
+    N, H, W, in_cs = x_nhwc.shape
+    _, Ho, Wo, dz_cs = dz_nhwc.shape
+    assert dw_oihw.is_contiguous() and tuple(dw_oihw.shape[1:]) == (Cin, KH, KW) and dw_oihw.shape[0] <= Cout
+    need = lib().dim_conv2d_wgrad_workspace_floats(Cout, Cin, KH, KW, max(int(splits), 1) + 1)
+    if workspace is None or workspace.numel() < need:
+        workspace = _new((need,), x_nhwc)
+    check(lib().dim_conv2d_wgrad_oihw(dptr(x_nhwc, f32), dptr(dz_nhwc, f32), dptr(dw_oihw, f32), dptr(workspace, f32), N, H, W, Cin, in_cs, Ho, Wo,
+                                      Cout, dz_cs, dz_coff, KH, KW, stride, pad, int(splits), int(bool(bf16_mfma)), dw_oihw.shape[0],
+                                      float(scale), int(accumulate), current_stream()))
+    return dw_oihw
+
+
 def bias_grad(dz_nhwc, C, db, dz_coff=0, workspace=None, accumulate=False):
     M = dz_nhwc.numel() // dz_nhwc.shape[-1]
     if workspace is None:

@@ -164,6 +164,17 @@ def test_dgrad_wgrad_bf16(ops, case):
     ref = ops.conv2d_pack_weight(wr.grad.float().to(DEV))
     assert (dwp - ref).abs().max().item() <= 1e-4 * wr.grad.abs().max().item() + 1e-5
     assert l2rel(dwp.cpu().numpy(), ops.conv2d_pack_weight(wf.grad.float().to(DEV)).cpu().numpy()) <= L2_BAR
+    # the same gradient delivered in the MXNet layout with the slab sum folded into the layout converter: the bits of the two-step path
+    two = ops.conv2d_unpack_weight(dwp, torch.empty((Cout, Cin, k, k), device=DEV))
+    one = torch.full((Cout, Cin, k, k), 7.0, device=DEV)
+    ops.conv2d_wgrad_oihw(nhwc(x.float()), Cin, nhwc(dy.float()), Cout, k, k, s, p, one, splits=splits, bf16_mfma=True)
+    assert torch.equal(one, two)
+    ops.conv2d_wgrad_oihw(nhwc(x.float()), Cin, nhwc(dy.float()), Cout, k, k, s, p, one, splits=splits, bf16_mfma=True, scale=0.5, accumulate=True)
+    assert torch.equal(one, two + 0.5 * two)
+    f32_two = torch.zeros_like(dwp)
+    ops.conv2d_wgrad(nhwc(x.float()), Cin, nhwc(dy.float()), Cout, k, k, s, p, f32_two, splits=splits)
+    f32_one = ops.conv2d_wgrad_oihw(nhwc(x.float()), Cin, nhwc(dy.float()), Cout, k, k, s, p, torch.empty_like(one), splits=splits)
+    assert torch.equal(f32_one, ops.conv2d_unpack_weight(f32_two, torch.empty_like(one)))
 
 
 def test_wgrad_bf16_first_layer_cin8_and_fc6(ops):
@@ -178,6 +189,17 @@ def test_wgrad_bf16_first_layer_cin8_and_fc6(ops):
     ops.conv2d_wgrad(nhwc(x.float()), 8, nhwc(dy.float()), 64, 7, 7, 2, 3, dwp, splits=4, bf16_mfma=True)
     ref = ops.conv2d_pack_weight(wr.grad.float().to(DEV))
     assert (dwp - ref).abs().max().item() <= 1e-4 * wr.grad.abs().max().item() + 1e-5
+    # the MXNet-layout entry: the 8-lane layer has no tiled converter (slabs are summed first, then the element-wise converter); 85 small
+    # slabs take the lane-parallel reduce first, exactly as the two-step path does
+    xb = torch.randn((2, 8, 65, 81), generator=g, dtype=torch.float64)
+    dyb = torch.randn((2, 64, 33, 41), generator=g, dtype=torch.float64)
+    for xi, dyi, sp in ((x, dy, 4), (xb, dyb, 1000)):
+        ops.conv2d_wgrad(nhwc(xi.float()), 8, nhwc(dyi.float()), 64, 7, 7, 2, 3, dwp, splits=sp, bf16_mfma=True)
+        two = ops.conv2d_unpack_weight(dwp, torch.empty((64, 8, 7, 7), device=DEV))
+        one = ops.conv2d_wgrad_oihw(nhwc(xi.float()), 8, nhwc(dyi.float()), 64, 7, 7, 2, 3, torch.empty_like(two), splits=sp, bf16_mfma=True)
+        assert torch.equal(one, two)
+    refb = torch.nn.grad.conv2d_weight(r16(xb), (64, 8, 7, 7), r16(dyb), stride=2, padding=3)
+    assert (two.cpu().double() - refb).abs().max().item() <= 1e-4 * refb.abs().max().item() + 1e-5
     B = 3
     feat = torch.randn((B, 1024, 8, 10), generator=g, dtype=torch.float64)
     w6 = torch.randn((256, 81920), generator=g, dtype=torch.float64, requires_grad=True)
