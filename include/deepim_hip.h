@@ -337,6 +337,7 @@ int dim_conv2d_wgrad_oihw(const float* x, const float* dz, float* dw_oihw, float
  * dim_conv2d_pack_weight_padded), so every packer is shared.  Arguments otherwise as the f32 functions (dim_conv2d_fwd_bf16:
  * splits >= 1, no "auto" mode).  dim_conv2d_wgrad_bf16 returns an fp32 gradient in the packed layout, like dim_conv2d_wgrad.
  * Declared tolerance vs the fp32 path: 2^-8 relative per product, i.e. ~4e-3 L2-relative on a layer output / gradient tensor.
+ * Tile 6 (the 8-channel 7x7 / stride-2 / 64-filter first layer from an LDS-resident patch) exists on both pipes.
  * bf16-only tiles: 7 = LDS-halo kernel (8 x 16 pixels x 128 channels; 3x3 / 5x5, stride 1 / 2, dense output); 8 = 128 x 256 gathered taps;
  * 9 = stride-1 patch kernel (16 x 16 pixels x 128 or 64 channels, KH, KW <= 3 with 2 .. 9 taps, Cin % 32 == 0, Cout % 64 == 0, dense or
  * scattered output, batched phases); dim_conv2d_dgrad_bf16 with tile 9 applies it to every phase of a strided gradient that has >= 2

@@ -273,8 +273,10 @@ class FlowNetHip(object):
             self.acts[name] = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=d)
             nchunks = -(-k * k // 4) if c == 8 else k * k * (c // 32)
             tile, splits = self.conv_plan.get(name, ops.conv_auto_plan(B * ho * wo, cout, nchunks, cin=c))
-            if name == "flow_conv1" and not self.bf16 and name not in (conv_plan or {}) and os.environ.get("DIM_CONV1_HALO", "1") != "0":
-                tile, splits = 6, 1   # LDS-halo first-layer kernel (conv.hip conv1_halo_kernel); DIM_CONV1_HALO=0: the gathered-tap kernel
+            if name == "flow_conv1" and name not in (conv_plan or {}) and os.environ.get("DIM_CONV1_HALO", "1") != "0":
+                # LDS-halo first-layer kernel (conv.hip conv1_halo_kernel, on the bf16 pipe conv1_halo_bf16_kernel: 0.26 -> ~0.12 ms at
+                # B = 16, the layer's HBM bytes once); DIM_CONV1_HALO=0: the gathered-tap kernel
+                tile, splits = 6, 1
             self.conv_plan[name] = (tile, splits)
             self.layer_info[name] = dict(M=B * ho * wo, K=c * k * k, N=cout, flops=2 * B * ho * wo * cout * c * k * k, tile=tile,
                                          splits=splits, cin=c, min_bytes=4 * (B * h * w * c + cout * c * k * k + B * ho * wo * cout))
