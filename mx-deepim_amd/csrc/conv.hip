@@ -483,104 +483,133 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
   return p;
 }
 
-// flow_conv1 on the bf16 pipe from an LDS-resident patch: the twin of conv1_halo_kernel (same 8 x 16 pixel block, same roles: weights =
-// the A operand, pixels = B, so the epilogue is the same 8 float4 stores per lane).  With 16x the matrix rate this layer is pure HBM
-// traffic -- 157 MB of input, 315 MB of output at B = 16 -- and the gathered-tap kernel (conv_bf16_kernel<64,64,2,2,true>, 13 K chunks
-// per workgroup, the 49 taps re-gathered 3.7x through the 64 B/clk vector memory path) ran it at 0.23 of that roof.  Here the 21 x 37 x 8
-// patch is read once, rounded to bf16 on the way into LDS (16 B per pixel, 12 KB per workgroup), and one v_mfma_f32_32x32x16_bf16
-// multiplies TWO taps: lane half h supplies tap 2 i + h, for the weights the 16 bytes k = 16 s + 8 h + {0..7} of chunk i / 2 in the bf16
-// image of the packed array (tap 49 = the zero padding of chunk 12; its pixel operand re-reads tap 48: finite, multiplied by zero).
+// flow_conv1 on the bf16 pipe: PERSISTENT workgroups, the whole weight array and the input patches in LDS.  With 16x the matrix rate
+// this layer is pure HBM traffic -- 157 MB of input, 315 MB of output at B = 16 = ~95 us -- and the gathered-tap kernel
+// (conv_bf16_kernel<64,64,2,2,true>: 13 K chunks per workgroup, the 49 taps re-gathered 3.7x through the 64 B/clk vector memory path)
+// took 0.28 ms.  A one-to-one twin of conv1_halo_kernel (weights per tap from L2, one block per workgroup) took 0.25 ms: without f32
+// MFMAs to hide under, every wave streaming the 53 KB of weights from L2 (1.9 GB per launch) is the bound.  So: one 8-wave workgroup per
+// CU keeps the bf16 image of the packed [chunk][64][32] weights in LDS (80-byte rows: conflict-free ds_read_b128) and walks a
+// contiguous range of 16 x 16 pixel blocks; a block's 37 x 37 x 8 patch is loaded ONCE, rounded to bf16 on the way into LDS (16 B per
+// pixel, two buffers), the next block's loads are in flight while this one multiplies, one barrier per block.  Roles as in
+// conv1_halo_kernel (weights = the A operand, pixels = B: 8 float4 stores per lane); one v_mfma_f32_32x32x16_bf16 multiplies TWO taps:
+// lane half h supplies tap 2 i + h, for the weights the 16 bytes k = 16 s + 8 h + {0..7} of chunk i / 2 (tap 49 = the zero padding
+// of chunk 12; its pixel operand re-reads tap 48: finite, multiplied by zero).
 template <int KH, int KW>
-__global__ __launch_bounds__(256) void conv1_halo_bf16_kernel(ConvArgs a) {
-  constexpr int TH = 8, TW = 16, S = 2;
-  constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;   // 21 x 37 input pixels
-  constexpr int NPIX = PH * PW, NT = KH * KW, NPAIR = (NT + 1) / 2;
-  __shared__ __attribute__((aligned(16))) bf16x8 patch[NPIX];
+__global__ __launch_bounds__(512) void conv1_halo_bf16_kernel(ConvArgs a, int tiles, int per_wg) {
+  constexpr int TH = 16, TW = 16, S = 2;
+  constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;   // 37 x 37 input pixels
+  constexpr int NPIX = PH * PW, NT = KH * KW, NPAIR = (NT + 1) / 2, NCH = (NT + 3) / 4;
+  constexpr int WROW = 40;                                         // bf16 elements per weight row in LDS (32 + 8 pad)
+  constexpr int ITEMS = (NPIX + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* sw = reinterpret_cast<__bf16*>(smem);                    // [NCH * 64][WROW]
+  bf16x8* patch = reinterpret_cast<bf16x8*>(sw + NCH * 64 * WROW);  // [2][NPIX]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = wg_xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // neighbouring block ranges (shared halos) on one XCD
+  const int t_begin = wg * per_wg, t_end = min(tiles, t_begin + per_wg);
+  if (t_begin >= t_end) return;
   const int tiles_w = (a.Wo + TW - 1) / TW, tiles_h = (a.Ho + TH - 1) / TH;
-  int id = wg_xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-  const int twi = id % tiles_w;
-  id /= tiles_w;
-  const int thi = id % tiles_h;
-  const int n = id / tiles_h;
-  const int ho0 = thi * TH, wo0 = twi * TW;
-  const int hi0 = ho0 * S - a.pad_h, wi0 = wo0 * S - a.pad_w;
 
+  // ---- weights -> LDS, once: rows of 64 bytes, four 16-byte pieces each
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  for (int it = tid; it < NCH * 64 * 4; it += 512) {
+    const int row = it >> 2, piece = it & 3;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, (row * 32 + piece * 8) * 2, 0, 0);
+    *reinterpret_cast<u32x4*>(sw + row * WROW + piece * 8) = v;
+  }
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-  constexpr int ITEMS = (NPIX + 255) / 256;
   float4 lo[ITEMS], hi[ITEMS];
+  auto tile_origin = [&](int t, int& n, int& ho0, int& wo0) {
+    const int twi = t % tiles_w;
+    const int r = t / tiles_w;
+    n = r / tiles_h;
+    ho0 = (r - n * tiles_h) * TH;
+    wo0 = twi * TW;
+  };
+  auto patch_load = [&](int t) {   // ITEMS x 2 loads in flight per thread; pixels outside the image read zeros (= the padding)
+    int n, ho0, wo0;
+    tile_origin(t, n, ho0, wo0);
+    const int hi0 = ho0 * S - a.pad_h, wi0 = wo0 * S - a.pad_w;
 #pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {  // all loads first, then the conversions: ITEMS x 2 loads in flight per thread
-    const int pix = it * 256 + tid;
-    const int py = pix / PW, px = pix - py * PW;
-    const int hy = hi0 + py, wx = wi0 + px;
-    const bool ok = pix < NPIX && (unsigned)hy < (unsigned)a.H && (unsigned)wx < (unsigned)a.W;
-    const int off = ok ? (((n * a.H + hy) * a.W + wx) * a.in_cstride) * 4 : -1;
-    lo[it] = buf_load16(rx, off, 0);
-    hi[it] = buf_load16(rx, ok ? off + 16 : -1, 0);
-  }
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const int pix = it * 256 + tid;
-    if (pix < NPIX) {
-      const bf16x4 l = to_bf16x4(lo[it]), h = to_bf16x4(hi[it]);
-      bf16x8 v = {l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
-      patch[pix] = v;
+    for (int it = 0; it < ITEMS; ++it) {
+      const int pix = it * 512 + tid;
+      const int py = pix / PW, px = pix - py * PW;
+      const int hy = hi0 + py, wx = wi0 + px;
+      const bool ok = pix < NPIX && (unsigned)hy < (unsigned)a.H && (unsigned)wx < (unsigned)a.W;
+      const int off = ok ? (((n * a.H + hy) * a.W + wx) * a.in_cstride) * 4 : -1;
+      lo[it] = buf_load16(rx, off, 0);
+      hi[it] = buf_load16(rx, ok ? off + 16 : -1, 0);
     }
-  }
+  };
+  auto patch_store = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int pix = it * 512 + tid;
+      if (pix < NPIX) {
+        const bf16x4 l = to_bf16x4(lo[it]), h = to_bf16x4(hi[it]);
+        bf16x8 v = {l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+        patch[buf * NPIX + pix] = v;
+      }
+    }
+  };
   const int frow = lane & 31, khalf = lane >> 5;
   const int p = wave * 32 + frow;               // output pixel = this lane's B column inside the block
   const int ty = p / TW, tx = p - ty * TW;
-  const bf16x8* abase = &patch[(ty * S) * PW + tx * S];
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
-  // weight fragment of pair i, output-channel tile j: 16 bytes at (((i / 2) * 64 + 32 j + frow) * 32 + (i % 2) * 16 + 8 khalf) bf16 elements
-  const int w_voff = (frow * 32 + 8 * khalf) * 2;
-  auto load_w = [&](int i, bf16x8& w0, bf16x8& w1) {
-    const int soff = ((i >> 1) * 64 * 32 + (i & 1) * 16) * 2;
-    const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff, soff, 0);
-    const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff + 32 * 32 * 2, soff, 0);
-    w0 = *reinterpret_cast<const bf16x8*>(&r0);
-    w1 = *reinterpret_cast<const bf16x8*>(&r1);
-  };
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-  bf16x8 w0, w1, nw0, nw1;
-  load_w(0, w0, w1);
+  const int b_off = (ty * S) * PW + tx * S;
+  const __bf16* wbase = sw + frow * WROW + 8 * khalf;
+
+  patch_load(t_begin);
+  patch_store(0);
   __syncthreads();
+  int buf = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    const bool more = t + 1 < t_end;
+    if (more) patch_load(t + 1);
+    const bf16x8* pb = patch + buf * NPIX + b_off;
+    f32x16 acc0, acc1;
 #pragma unroll
-  for (int i = 0; i < NPAIR; ++i) {
-    load_w(i + 1 < NPAIR ? i + 1 : 0, nw0, nw1);   // one pair ahead (the one past the end re-reads pair 0: in range, unused)
-    const int t0 = 2 * i, t1 = (2 * i + 1 < NT) ? 2 * i + 1 : NT - 1;
-    const int o0 = (t0 / KW) * PW + t0 % KW, o1 = (t1 / KW) * PW + t1 % KW;   // constants after unrolling
-    const bf16x8 px = abase[khalf ? o1 : o0];
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, px, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, px, acc1, 0, 0, 0);
-    w0 = nw0;
-    w1 = nw1;
-  }
-  // ---- epilogue: as conv1_halo_kernel.  D layout: col = lane & 31 -> pixel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> output channel
-  const int oy = ho0 + ty, ox = wo0 + tx;
-  if (oy < a.Ho && ox < a.Wo) {
-    float* o = a.y + a.out_coff + ((long)(n * a.Ho + oy) * a.Wo + ox) * a.out_cstride + 4 * khalf;
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
-      if (a.has_bias) {  // scalar loads: the bias may be a 4-byte-aligned slice of a flat parameter vector
-        const float* b0p = a.bias + 8 * g + 4 * khalf;
-        bv0 = make_float4(b0p[0], b0p[1], b0p[2], b0p[3]);
-        bv1 = make_float4(b0p[32], b0p[33], b0p[34], b0p[35]);
-      }
-      float4 v0 = make_float4(acc0[4 * g] + bv0.x, acc0[4 * g + 1] + bv0.y, acc0[4 * g + 2] + bv0.z, acc0[4 * g + 3] + bv0.w);
-      float4 v1 = make_float4(acc1[4 * g] + bv1.x, acc1[4 * g + 1] + bv1.y, acc1[4 * g + 2] + bv1.z, acc1[4 * g + 3] + bv1.w);
-      v0.x = v0.x > 0.f ? v0.x : v0.x * a.slope; v0.y = v0.y > 0.f ? v0.y : v0.y * a.slope;
-      v0.z = v0.z > 0.f ? v0.z : v0.z * a.slope; v0.w = v0.w > 0.f ? v0.w : v0.w * a.slope;
-      v1.x = v1.x > 0.f ? v1.x : v1.x * a.slope; v1.y = v1.y > 0.f ? v1.y : v1.y * a.slope;
-      v1.z = v1.z > 0.f ? v1.z : v1.z * a.slope; v1.w = v1.w > 0.f ? v1.w : v1.w * a.slope;
-      *reinterpret_cast<float4*>(o + 8 * g) = v0;
-      *reinterpret_cast<float4*>(o + 32 + 8 * g) = v1;
+    for (int i = 0; i < NPAIR; ++i) {
+      const int t0 = 2 * i, t1 = (2 * i + 1 < NT) ? 2 * i + 1 : NT - 1;
+      const int o0 = (t0 / KW) * PW + t0 % KW, o1 = (t1 / KW) * PW + t1 % KW;   // constants after unrolling
+      const bf16x8 px = pb[khalf ? o1 : o0];
+      const __bf16* wr = wbase + ((i >> 1) * 64) * WROW + (i & 1) * 16;
+      const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wr);
+      const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wr + 32 * WROW);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, px, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, px, acc1, 0, 0, 0);
     }
+    // ---- epilogue: as conv1_halo_kernel.  D layout: col = lane & 31 -> pixel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> channel
+    int n, ho0, wo0;
+    tile_origin(t, n, ho0, wo0);
+    const int oy = ho0 + ty, ox = wo0 + tx;
+    if (oy < a.Ho && ox < a.Wo) {
+      float* o = a.y + a.out_coff + ((long)(n * a.Ho + oy) * a.Wo + ox) * a.out_cstride + 4 * khalf;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
+        if (a.has_bias) {  // scalar loads: the bias may be a 4-byte-aligned slice of a flat parameter vector
+          const float* b0p = a.bias + 8 * g + 4 * khalf;
+          bv0 = make_float4(b0p[0], b0p[1], b0p[2], b0p[3]);
+          bv1 = make_float4(b0p[32], b0p[33], b0p[34], b0p[35]);
+        }
+        float4 v0 = make_float4(acc0[4 * g] + bv0.x, acc0[4 * g + 1] + bv0.y, acc0[4 * g + 2] + bv0.z, acc0[4 * g + 3] + bv0.w);
+        float4 v1 = make_float4(acc1[4 * g] + bv1.x, acc1[4 * g + 1] + bv1.y, acc1[4 * g + 2] + bv1.z, acc1[4 * g + 3] + bv1.w);
+        v0.x = v0.x > 0.f ? v0.x : v0.x * a.slope; v0.y = v0.y > 0.f ? v0.y : v0.y * a.slope;
+        v0.z = v0.z > 0.f ? v0.z : v0.z * a.slope; v0.w = v0.w > 0.f ? v0.w : v0.w * a.slope;
+        v1.x = v1.x > 0.f ? v1.x : v1.x * a.slope; v1.y = v1.y > 0.f ? v1.y : v1.y * a.slope;
+        v1.z = v1.z > 0.f ? v1.z : v1.z * a.slope; v1.w = v1.w > 0.f ? v1.w : v1.w * a.slope;
+        typedef float nt4 __attribute__((ext_vector_type(4)));
+        const nt4 s0 = {v0.x, v0.y, v0.z, v0.w}, s1 = {v1.x, v1.y, v1.z, v1.w};
+        __builtin_nontemporal_store(s0, reinterpret_cast<nt4*>(o + 8 * g));   // written once, read by the next layer from HBM anyway
+        __builtin_nontemporal_store(s1, reinterpret_cast<nt4*>(o + 32 + 8 * g));
+      }
+    }
+    if (more) patch_store(buf ^ 1);   // the other buffer: its last readers passed the barrier that ended the previous block
+    __syncthreads();
+    buf ^= 1;
   }
 }
 
@@ -1843,10 +1872,23 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
     const int tiles = N * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
     DIM_REQUIRE(a.out_cstride % 4 == 0 && a.out_coff % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
                 "tile 6 stores float4: output channel stride / offset must be multiples of 4 and y 16-byte aligned");
-    if (a.bf16)
-      hipLaunchKernelGGL((conv1_halo_bf16_kernel<7, 7>), dim3(tiles), dim3(256), 0, st, a);
-    else
+    if (a.bf16) {  // persistent: one 8-wave workgroup per CU walks a contiguous range of 16 x 16 blocks
+      const int tiles16 = N * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);
+      static const int n_cu = [] {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+      }();
+      const int wgs = tiles16 < n_cu ? tiles16 : n_cu;
+      const int per_wg = (tiles16 + wgs - 1) / wgs;
+      constexpr size_t lds = (size_t)13 * 64 * 40 * 2 + 2 * (size_t)37 * 37 * 16;
+      static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_halo_bf16_kernel<7, 7>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      DIM_REQUIRE(attr_ok, "cannot reserve %zu bytes of LDS for the first-layer kernel", lds);
+      hipLaunchKernelGGL((conv1_halo_bf16_kernel<7, 7>), dim3((tiles16 + per_wg - 1) / per_wg), dim3(512), lds, st, a, tiles16, per_wg);
+    } else {
       hipLaunchKernelGGL((conv1_halo_kernel<7, 7>), dim3(tiles), dim3(256), 0, st, a);
+    }
     return check_launch("conv1_halo");
   }
   DIM_REQUIRE((tile != 1 && tile != 4) || Cout % 128 == 0, "tile 128x128 needs Cout %% 128 == 0");

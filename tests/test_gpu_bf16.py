@@ -50,11 +50,12 @@ FWD_CASES = [
     # N, H, W, Cin, Cout, k, s, p, tile, splits
     (2, 60, 80, 8, 64, 7, 2, 3, 3, 1),
     (1, 37, 53, 8, 64, 7, 2, 3, 2, 1),
-    # tile 6: the LDS-halo first-layer kernel on the bf16 pipe (8 x 16 output blocks, two taps per MFMA; whole blocks / partial blocks on
-    # both edges / a map smaller than one block)
+    # tile 6: the persistent first-layer kernel on the bf16 pipe (16 x 16 output blocks, two taps per MFMA; whole blocks / partial blocks
+    # on both edges / a map smaller than one block / more blocks than CUs, so that workgroups walk several blocks through both buffers)
     (2, 64, 96, 8, 64, 7, 2, 3, 6, 1),
     (1, 37, 53, 8, 64, 7, 2, 3, 6, 1),
     (3, 9, 13, 8, 64, 7, 2, 3, 6, 1),
+    (5, 290, 420, 8, 64, 7, 2, 3, 6, 1),
     (2, 30, 40, 64, 128, 5, 2, 2, 4, 1),
     (1, 23, 31, 64, 128, 5, 2, 2, 3, 1),
     (2, 15, 20, 256, 256, 3, 1, 1, 4, 1),

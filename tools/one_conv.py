@@ -25,7 +25,7 @@ wt = torch.randn((cout, c, k, k), device="cuda:0") * 0.01
 if os.environ.get("ZERO_DATA"):  # power / clock experiment: all-zero operands draw far less MFMA power
     x.zero_()
     wt.zero_()
-wp = ops.conv2d_pack_weight(wt)
+wp = ops.conv2d_pack_weight(wt, as_bf16=bool(os.environ.get("BF16")))   # BF16=1: the bf16 pipe
 bias = torch.zeros(cout, device="cuda:0")
 ho, wo = ops.conv_out_hw(h, w, k, k, s, p)
 flops = 2.0 * B * ho * wo * cout * c * k * k
