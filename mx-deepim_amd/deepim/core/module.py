@@ -219,24 +219,15 @@ class MutableModule(object):
                     need = max(need, ops.lib().dim_conv2d_wgrad_winograd_workspace_floats(B, h, w, c, cout, S, sp))
                 h, w, c = ho, wo, cout
             self.wino_wgrad_ws = torch.empty(need, dtype=torch.float32, device=d)
-        self.pack_overlap = os.environ.get("DIM_PACK_OVERLAP", "1") != "0"
-        self._pack_stream, self._packs_done = None, None
-        net.before_fc6 = self.sync_packs
         self.repack(forward=False)
 
     # ------------------------------------------------------------------------------------------------------------
-    def repack(self, forward=True, overlap=False):
+    def repack(self, forward=True):
         """master (MXNet layout) -> the kernels' packed copies: forward layouts (FlowNetHip.packed) and dgrad layouts
-        (bf16 mode: bf16 images of the same packed arrays).
-
-        overlap (update() passes it): only the encoder's forward layouts are needed right away.  Everything else -- fc6 (84 MB), the
-        decoder and head layouts, every input-gradient layout: two thirds of the bytes -- is packed on a second stream behind an event
-        recorded after the optimizer step, while the next forward's encoder runs; the compute stream waits for that stream just
-        before fc6 (FlowNetHip.before_fc6).  The packers are HBM-bound, the bf16 encoder is not.  Old and new buffers: a packed
-        array replaced here was last read by the backward pass that precedes the optimizer step on the compute stream, and the
-        second stream starts behind that step."""
+        (bf16 mode: bf16 images of the same packed arrays).  (Measured and dropped in round 3: packing everything that is first read
+        at fc6 or later on a second stream behind the optimizer step, overlapped with the next encoder forward -- 6.40 vs 6.41 ms per
+        bf16 iteration: the packers and the now HBM-bound first layers want the same bytes per second.)"""
         net, w = self.net, self.w
-        self.sync_packs()   # a previous overlapped repack still writing the arrays about to be replaced
         for name, cout, k, s, p in ENCODER:
             if forward:
                 if name in net.wino:   # 3x3 / stride-1 layers run their forward through Winograd: re-transform the weights
@@ -252,24 +243,6 @@ class MutableModule(object):
                         net.packed["flow_conv1_masks"] = net.pack_conv(self.w1_lanes[1])
                 else:
                     net.packed[name] = net.pack_conv(w[name + "_weight"])
-        if overlap and self.pack_overlap:
-            if self._pack_stream is None:
-                self._pack_stream = torch.cuda.Stream(device=self.device)
-            main = torch.cuda.current_stream(self.device)
-            after_step = torch.cuda.Event()
-            after_step.record(main)
-            with torch.cuda.stream(self._pack_stream):
-                self._pack_stream.wait_event(after_step)
-                self._repack_late(forward)
-                self._packs_done = torch.cuda.Event()
-                self._packs_done.record(self._pack_stream)
-        else:
-            self._repack_late(forward)
-
-    def _repack_late(self, forward):
-        """the layouts first read at fc6 or later (see repack)"""
-        net, w = self.net, self.w
-        for name, cout, k, s, p in ENCODER:
             if name in net.wino:
                 self.wino_dgrad[name] = ops.winograd_dgrad_pack_weight(w[name + "_weight"], m=net.wino_m[name])
             elif name in net.wino5:  # 5x5 / stride-2 layers: input gradient through Winograd too (four phase images of dX)
@@ -289,13 +262,6 @@ class MutableModule(object):
             # deconv dgrad = a plain stride-2 convolution of the output gradient with the deconv weight read as (O=Cin, I=Cout, 4, 4)
             self.dgrad_packed["deconv5"] = ops.conv2d_pack_weight_padded(w["deconv5_weight"], 1024, as_bf16=self.bf16)
             self.dgrad_packed["deconv4"] = ops.conv2d_pack_weight_padded(w["deconv4_weight"], ops.pad64(1026), as_bf16=self.bf16)
-
-    def sync_packs(self):
-        """compute stream waits for the packers of an overlapped repack (no-op when none is in flight).  FlowNetHip.encoder calls it
-        before fc6; call it yourself before reading FlowNetHip.packed / dgrad layouts any other way after update()."""
-        if self._packs_done is not None:
-            torch.cuda.current_stream(self.device).wait_event(self._packs_done)
-            self._packs_done = None
 
     # ------------------------------------------------------------------------------------------------------------
     def forward(self, batch):
@@ -351,7 +317,6 @@ class MutableModule(object):
             if work is not None:
                 work.wait()
         self._pending, self._next_bucket = [], 0
-        self.sync_packs()   # normally consumed by forward() already
         ops.fill(self.loss_sums, 0.0)
         # ---------------- loss gradients (get_loss :344-357, :446-499, :531-536)
         if self.pred_flow:
@@ -633,7 +598,7 @@ class MutableModule(object):
             mom, wd = float(cfg.TRAIN.momentum), float(cfg.TRAIN.wd)
             for a, b, decay in seg:
                 ops.sgd_momentum(self.flat_w[a:b], self.flat_g[a:b], self.flat_m[a:b], lr, mom, wd if decay else 0.0, 1.0)
-        self.repack(forward=True, overlap=True)
+        self.repack(forward=True)
 
     def world_size(self):
         import torch.distributed as dist

@@ -212,7 +212,6 @@ class FlowNetHip(object):
             w1 = self.params["flow_conv1_weight"]
             self.params["flow_conv1_weight"] = torch.cat([w1, torch.zeros((w1.shape[0], 2) + tuple(w1.shape[2:]), device=d)], dim=1).contiguous()
         self.packed = {}
-        self.before_fc6 = None   # optional callable run before fc6 (MutableModule: wait for the second-stream packers)
         if self.input_mode == 3:  # 10 input channels: [:, :8] for the images + depth group, [:, 8:10] (+ 6 zero lanes) for the mask group
             w1 = self.params["flow_conv1_weight"]
             assert w1.shape[1] == 10, w1.shape
@@ -408,8 +407,6 @@ class FlowNetHip(object):
             if first10:   # + the mask group's convolution, then the activation (y *= y > 0 ? 1 : 0.1 is what dim_lrelu_bwd does with dy = y)
                 ops.conv2d_fwd_ex(self.X2, 0, 8, self.packed["flow_conv1_masks"], None, x, 0, cout, k, k, s, p, slope=1.0, tile=3, accumulate=True)
                 ops.lrelu_bwd(x, x, cout, slope=0.1)
-        if self.before_fc6 is not None:   # training: the layouts from fc6 on are packed on a second stream (MutableModule.repack)
-            self.before_fc6()
         # fc6: a pure weight stream at these batch sizes (84 MB per forward) -> its own kernel instead of the 8x10 "convolution"
         ops.fc_fwd(x, self.packed["fc6"], self.params["fc6_bias"], 256, slope=0.1, out=self.fc6, workspace=self.workspace,
                    events=None if events is None else events.setdefault("fc6", []))

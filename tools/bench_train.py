@@ -32,7 +32,7 @@ def timed(fn, n=3):
     return e0.elapsed_time(e1) / n
 import json
 res = {"B": B, "forward_ms": timed(lambda: mod.forward(batch)), "backward_ms": timed(lambda: mod.backward(batch)),
-       "update_repack_ms": timed(lambda: (mod.update(0.0), mod.sync_packs()))}
+       "update_repack_ms": timed(lambda: mod.update(0.0))}
 preds = mod.forward(batch)
 res["batch_updater_ms"] = timed(lambda: upd.forward(batch, preds))
 t = timed(lambda: (mod.forward_backward(batch), mod.update(1e-4)))
