@@ -342,6 +342,15 @@ int dim_conv2d_wgrad_oihw(const float* x, const float* dz, float* dw_oihw, float
  * 9 = stride-1 patch kernel (16 x 16 pixels x 128 or 64 channels, KH, KW <= 3 with 2 .. 9 taps, Cin % 32 == 0, Cout % 64 == 0, dense or
  * scattered output, batched phases); dim_conv2d_dgrad_bf16 with tile 9 applies it to every phase of a strided gradient that has >= 2
  * taps and runs the single-tap phase on the gathered-tap kernel. */
+/* The input gradient of a layer whose INPUT is another layer's LeakyReLU output, with that LeakyReLU' and the lower layer's bias
+ * gradient folded into the epilogue (tile 9, the bf16 patch kernel: 3x3 / stride 1 and 5x5 / stride 2 layers on maps of >= 1200 pixels):
+ * dz (N,H,W,Cin) = dX * (y_act > 0 ? 1 : slope), db[Cin] (+)= column sums of dz.  y_act (N,H,W,Cin) is the stored activation; Cin % 64 == 0.
+ * Same dz bits as dim_conv2d_dgrad_bf16(tile 9) followed by dim_lrelu_bwd_bias_grad; db differs in summation order only.  Replaces one
+ * 12-bytes-per-element pass over the gradient per layer (deepim/core/module.py:1205-1213 runs it inside MXNet's backward). */
+long dim_conv2d_dgrad_lrelu_workspace_floats(int N, int H, int W, int Cin, int stride);
+int dim_conv2d_dgrad_bf16_lrelu(const float* dy, const void* w_dgrad_packed_bf16, float* dz, const float* y_act, float slope, float* db,
+                                float* workspace, int N, int H, int W, int Cin, int dx_cstride, int Ho, int Wo, int Cout, int dy_cstride,
+                                int KH, int KW, int stride, int pad, int accumulate_db, void* stream);
 int dim_f32_to_bf16(const float* src, void* dst_bf16, long n, void* stream);
 int dim_bf16_to_f32(const void* src_bf16, float* dst, long n, void* stream);
 /* The packers with the rounding folded in: each writes exactly dim_f32_to_bf16 of its f32 twin's output (same element count, same

@@ -55,6 +55,13 @@ struct ConvArgs {
   int bf16;          // weights are packed bf16, products on v_mfma_f32_32x32x16_bf16 (conv_bf16_kernel)
   int slab_full;     // split-K slabs are whole copies of the OUTPUT tensor (its channel stride, offset and scatter): the partial
                      // results of a strided / scattered launch (input-gradient phases) land where the final values go, slab by slab
+  // tile 9 as the input gradient of a layer whose INPUT went through LeakyReLU: out = v * (mask > 0 ? 1 : mask_slope) with `mask` laid
+  // out like the output (the stored activation), and every wave's column sums over its pixels -> colsum[(colsum_row0 + 2 block + wm)]
+  // [Cout] (the bias gradient of that layer after one small reduce): the separate LeakyReLU' + bias-gradient pass folded in
+  const float* mask;
+  float mask_slope;
+  float* colsum;
+  int colsum_row0;
 };
 
 // Epilogue of the gathered-tap kernels (f32 and bf16): bias + LeakyReLU (+ accumulate) and the store of a wave's TM x TN accumulator
@@ -1168,7 +1175,36 @@ __global__ __launch_bounds__(256) void conv_bf16_patch_kernel(ConvArgs a) {
   float bv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) bv[j] = a.has_bias ? a.bias[n0 + (BN / 2) * wn + 32 * j + frow] : 0.f;
-  if (a.accumulate) {   // wave-uniform: out += result (gradients that meet in one buffer)
+  if (a.mask) {   // wave-uniform: the LeakyReLU' of the layer below and its bias gradient, folded in (see ConvArgs.mask)
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask) + (long)blockIdx.y * a.by, 0, a.y_bytes, 0x00020000);
+    float cs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      cs[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < TMW; ++i) {
+        float mk[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, voff[i][r], 128 * j, 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv[j];
+          v = v > 0.f ? v : v * a.slope;
+          v *= mk[r] > 0.f ? 1.f : a.mask_slope;
+          cs[j] += voff[i][r] != -1 ? v : 0.f;   // a pixel slot outside the output is not stored and must not count
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff[i][r], 128 * j, 0);
+        }
+      }
+    }
+    // the two lane halves hold different pixels of the same channel; then one plain store per (block, wave row, channel): no atomics,
+    // the reduce over blocks sums in a fixed order
+    float* crow = a.colsum + ((long)a.colsum_row0 + 2L * (blockIdx.x / ntn) + wm) * a.Cout + n0 + (BN / 2) * wn + frow;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float tot = cs[j] + __shfl_xor(cs[j], 32);
+      if (khalf == 0) crow[32 * j] = tot;
+    }
+  } else if (a.accumulate) {   // wave-uniform: out += result (gradients that meet in one buffer)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -1724,6 +1760,10 @@ struct ConvEx {
   int boy = 0, box = 0;  // scattered output: per-problem offset increments (see ConvArgs)
   int bf16 = 0;          // w_packed holds bf16 (dim_f32_to_bf16 of the f32 packed array): run on the bf16 matrix pipe
   int slab_full = 0;     // split-K into output-shaped slabs (ConvArgs.slab_full): the caller sums them (slab_sum_rows)
+  const float* mask = nullptr;   // tile 9 only: LeakyReLU' of the layer below + its bias-gradient partial sums (ConvArgs.mask)
+  float mask_slope = 1.f;
+  float* colsum = nullptr;
+  int colsum_row0 = 0;
 };
 
 static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
@@ -1770,6 +1810,11 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
   splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
   DIM_REQUIRE(splits == 1 || workspace, "split-K needs a workspace (dim_conv2d_workspace_floats)");
   a.slab_full = (ex && ex->slab_full && splits > 1) ? 1 : 0;
+  a.mask = ex ? ex->mask : nullptr;
+  a.mask_slope = ex ? ex->mask_slope : 1.f;
+  a.colsum = ex ? ex->colsum : nullptr;
+  a.colsum_row0 = ex ? ex->colsum_row0 : 0;
+  DIM_REQUIRE(!a.mask || (tile == 9 && a.colsum && !a.accumulate && splits == 1), "the LeakyReLU' / bias-gradient fold exists in tile 9 only");
   DIM_REQUIRE(splits == 1 || !ex || a.slab_full || (a.dense_out && a.out_cstride == Cout && a.out_coff == 0),
               "split-K writes a dense [M][Cout] result: not available with a strided / scattered output");
   DIM_REQUIRE(!a.slab_full || (a.bf16 && (tile == 3 || tile == 4) && (!ex || ex->batch == 1)),
@@ -2122,10 +2167,24 @@ __global__ __launch_bounds__(256) void slab_sum_rows_kernel(const float* __restr
   *reinterpret_cast<float4*>(dst + o) = s;
 }
 
+// rows of the bias-gradient partial sums one folded input gradient writes: 2 per 16 x 16 block of every phase image
+static long dgrad_fold_rows(int N, int H, int W, int stride) {
+  long rows = 0;
+  const int nph = stride == 1 ? 1 : 2;
+  for (int py = 0; py < nph; ++py)
+    for (int px = 0; px < nph; ++px) {
+      const int Th = stride == 1 ? H : (H - py + 1) / 2, Tw = stride == 1 ? W : (W - px + 1) / 2;
+      if (Th > 0 && Tw > 0) rows += 2L * N * ((Th + 15) / 16) * ((Tw + 15) / 16);
+    }
+  return rows;
+}
+
 static int conv2d_dgrad_impl(const float* dy, const float* w_dgrad_packed, float* dx, int N, int H, int W, int Cin, int dx_cstride, int Ho,
                              int Wo, int Cout, int dy_cstride, int KH, int KW, int stride, int pad, int accumulate, int tile, int bf16,
-                             void* stream, float* workspace = nullptr, int splits = 1) {
+                             void* stream, float* workspace = nullptr, int splits = 1, const float* mask = nullptr, float mask_slope = 1.f,
+                             float* colsum = nullptr) {
   if (N == 0) return DIM_OK;
+  long fold_row = 0;
   // split-K (bf16, gathered-tap tiles): the small maps give 80-600 workgroups to 1280 resident slots and every workgroup walks
   // K = 4608 .. 9216 alone on its CU; `splits` K ranges write output-shaped slabs (every phase of a strided gradient into the same
   // slabs, each to its own pixels) and ONE pass sums them into dx
@@ -2149,11 +2208,18 @@ static int conv2d_dgrad_impl(const float* dy, const float* w_dgrad_packed, float
         ex.accumulate = split ? 0 : accumulate;
         ex.bf16 = bf16;
         ex.slab_full = split ? 1 : 0;
+        ex.mask = mask;
+        ex.mask_slope = mask_slope;
+        ex.colsum = colsum;
+        ex.colsum_row0 = (int)fold_row;
+        fold_row += 2L * N * ((Th + 15) / 16) * ((Tw + 15) / 16);
         if (total > 0) {
           // tile 9 (bf16 patch kernel) takes the phases with 2 .. 9 taps; a single-tap phase is a 1x1 convolution: gathered-tap kernel
           int ptile = tile;
           if (tile == 9 && !(bf16 && ah.ntaps <= 3 && aw.ntaps <= 3 && ah.ntaps * aw.ntaps >= 2))
             ptile = CinPad % 128 == 0 ? 4 : 3;
+          DIM_REQUIRE(!mask || ptile == 9, "folded input gradient: phase (%d,%d) has %d x %d taps, which the patch kernel does not take", py, px,
+                      ah.ntaps, aw.ntaps);
           // every slab of every phase must be written: the phase's K chunks have to make exactly `splits` non-empty ranges
           const int nch = ah.ntaps * aw.ntaps * (Cout / 32);
           const int psplits = split ? splits : 1;
@@ -2163,7 +2229,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w_dgrad_packed, float
                                             : w_dgrad_packed + off, nullptr, dx, split ? workspace : nullptr, N, Ho, Wo, Cout, CinPad,
                                    ah.ntaps, aw.ntaps, 1, -ah.emin, 1.0f, psplits, ptile, 0, stream, &ex);
           if (rc != DIM_OK) return rc;
-        } else if (!accumulate) {
+        } else if (!accumulate || mask) {
           return set_err(DIM_ERR_ARG, "phase (%d,%d) has no taps: dX rows of that phase would stay unwritten", py, px);
         }
       }
@@ -2203,6 +2269,27 @@ int dim_conv2d_dgrad_bf16_splitk(const float* dy, const void* w_dgrad_packed_bf1
               "split-K input gradient: dx / workspace 16-byte aligned, channel stride a multiple of 4");
   return conv2d_dgrad_impl(dy, reinterpret_cast<const float*>(w_dgrad_packed_bf16), dx, N, H, W, Cin, dx_cstride, Ho, Wo, Cout, dy_cstride,
                            KH, KW, stride, pad, accumulate, tile, 1, stream, workspace, splits);
+}
+
+long dim_conv2d_dgrad_lrelu_workspace_floats(int N, int H, int W, int Cin, int stride) {
+  const long rows = dgrad_fold_rows(N, H, W, stride);
+  const int CinPad = (Cin + 63) / 64 * 64;
+  return rows * CinPad + dim_bias_grad_workspace_floats(rows, CinPad);
+}
+
+// dz = dX * LeakyReLU'(y_act) and db = column sums of dz, both inside the input gradient's epilogue (tile 9) + one small reduce
+int dim_conv2d_dgrad_bf16_lrelu(const float* dy, const void* w_dgrad_packed_bf16, float* dz, const float* y_act, float slope, float* db,
+                                float* workspace, int N, int H, int W, int Cin, int dx_cstride, int Ho, int Wo, int Cout, int dy_cstride,
+                                int KH, int KW, int stride, int pad, int accumulate_db, void* stream) {
+  if (N == 0) return DIM_OK;
+  DIM_REQUIRE(y_act && db && workspace, "null pointer");
+  const int CinPad = (Cin + 63) / 64 * 64;
+  DIM_REQUIRE(Cin == CinPad && dx_cstride == Cin, "folded input gradient: dz and the stored activation must both be dense (N, H, W, Cin %% 64 == 0)");
+  const long rows = dgrad_fold_rows(N, H, W, stride);
+  int rc = conv2d_dgrad_impl(dy, reinterpret_cast<const float*>(w_dgrad_packed_bf16), dz, N, H, W, Cin, dx_cstride, Ho, Wo, Cout, dy_cstride, KH,
+                             KW, stride, pad, 0, 9, 1, stream, nullptr, 1, y_act, slope, workspace);
+  if (rc != DIM_OK) return rc;
+  return dim_bias_grad(workspace, db, workspace + rows * CinPad, rows, CinPad, CinPad, 0, accumulate_db, stream);
 }
 
 int dim_conv2d_fwd_partial(const float* x, const float* w_packed, float* workspace, int N, int H, int W, int Cin, int Cout, int KH,

@@ -24,6 +24,7 @@ from lib.utils.dist_utils import allreduce_sum_
 from deepim.symbols.deepIM_flownet import bf16_tile, BF16_PATCH, ENCODER, FlowNetHip, deepIM_flownet
 
 FUSED_UNPACK = os.environ.get("DIM_WGRAD_FUSED_UNPACK", "1") != "0"   # encoder weight gradients through dim_conv2d_wgrad_oihw
+FOLD_LRELU = os.environ.get("DIM_BF16_FOLD_LRELU", "1") != "0"         # bf16: LeakyReLU' + bias gradient inside the input-gradient epilogue
 FROZEN = ("upsampling_weight", "mask_upsampling_weight")  # attr lr_mult 0.0 (deepIM_flownet.py:334, :520)
 
 # Order in which backward() finishes the weight gradients: heads, decoder, pose head, fc6, then the encoder top down.  The flat
@@ -188,6 +189,15 @@ class MutableModule(object):
             h, w = ops.conv_out_hw(h, w, k, k, s, p)
             need_b = max(need_b, ops.lib().dim_lrelu_bwd_bias_grad_workspace_floats(B * h * w, cout))
         self.bias_ws = torch.empty(need_b, dtype=torch.float32, device=d)
+        self.fold_ws = None
+        if self.bf16 and FOLD_LRELU:   # partial column sums of the folded input gradients (backward)
+            need_f, h, w, c = 4, 480, 640, 8
+            for name, cout, k, s, p in ENCODER:
+                if c % 64 == 0:
+                    need_f = max(need_f, ops.lib().dim_conv2d_dgrad_lrelu_workspace_floats(B, h, w, c, s))
+                h, w = ops.conv_out_hw(h, w, k, k, s, p)
+                c = cout
+            self.fold_ws = torch.empty(need_f, dtype=torch.float32, device=d)
         # dgrad-layout weights (refreshed by repack())
         self.dgrad_packed = {}
         self.wino_dgrad = {}
@@ -364,13 +374,15 @@ class MutableModule(object):
         for name, cout, k, s, p in ENCODER:
             cin[name] = c
             c = cout
+        dz_done = set()
         for name, cout, k, s, p in reversed(ENCODER):
             dy = self.dacts[name]
             if name == "conv5_1" and self.has_decoder:
                 ops.copy_nhwc_channels(dy, 0, self.dconcat2, 0, 512, add=True)   # skip connection into Concat2
             if name == "conv4_1" and self.has_decoder:
                 ops.copy_nhwc_channels(dy, 0, self.dconcat3, 0, 512, add=True)   # skip connection into Concat3
-            ops.lrelu_bwd_bias_grad(msk.acts[name], dy, cout, g[name + "_bias"], workspace=self.bias_ws)   # dz in place + bias gradient
+            if name not in dz_done:   # else: the layer above already delivered dz and the bias gradient (folded input gradient, below)
+                ops.lrelu_bwd_bias_grad(msk.acts[name], dy, cout, g[name + "_bias"], workspace=self.bias_ws)   # dz in place + bias gradient
             x = net.acts[prev[name]] if prev[name] else net.X
             if name in self.wino_wgrad:
                 S, sp = self.wino_wgrad[name]
@@ -410,6 +422,15 @@ class MutableModule(object):
                     if self.bf16 and BF16_PATCH and k in (3, 5) and dy.shape[1] * dy.shape[2] >= 1200:
                         dg_tile = 9   # stride-1 patch kernel: the gradient itself (stride 1) or its four phase convolutions (stride 2)
                     ksp = self._dgrad_splits(dg_tile, dy.shape[0] * dy.shape[1] * dy.shape[2], ops.pad64(cin[name]), cout) if self.bf16 else 1
+                    if FOLD_LRELU and dg_tile == 9 and ksp == 1 and ((k == 5 and s == 2) or (k == 3 and s == 1)) and cin[name] % 64 == 0 and not (
+                            self.has_decoder and prev[name] in ("conv4_1", "conv5_1")):
+                        # every phase runs on the patch kernel and this is the only gradient that reaches the layer below: its
+                        # LeakyReLU' and bias gradient ride in the epilogue instead of a 12-bytes-per-element pass of their own
+                        # (flow_conv1, conv2, conv3, conv4: 80 % of the encoder's activation elements)
+                        ops.conv2d_dgrad_lrelu(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], msk.acts[prev[name]], cin[name], k, k, s, p,
+                                               g[prev[name] + "_bias"], workspace=self.fold_ws)
+                        dz_done.add(prev[name])
+                        continue
                     ops.conv2d_dgrad(dy, cout, self.dgrad_packed[name], self.dacts[prev[name]], cin[name], k, k, s, p, accumulate=False,
                                      tile=dg_tile, splits=ksp, workspace=self.ws if ksp > 1 else None)
         self._bucket_ready(None)

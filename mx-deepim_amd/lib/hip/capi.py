@@ -123,6 +123,8 @@ SIGNATURES = {
     "dim_conv2d_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_conv2d_wgrad_workspace_floats": (L, [I, I, I, I, I]),
     "dim_conv2d_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dim_conv2d_dgrad_lrelu_workspace_floats": (L, [I, I, I, I, I]),
+    "dim_conv2d_dgrad_bf16_lrelu": (I, [P, P, P, P, F, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_conv2d_wgrad_oihw": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
     "dim_bias_grad_workspace_floats": (L, [I, I]),
     "dim_bias_grad": (I, [P, P, P, I, I, I, I, I, P]),

@@ -595,6 +595,23 @@ def conv2d_dgrad_pack_weight(w_oihw, stride, pad, as_bf16=False):
     return wp
 
 
+def conv2d_dgrad_lrelu(dy_nhwc, Cout, w_dgrad_packed_bf16, dz_nhwc, y_act_nhwc, Cin, KH, KW, stride, pad, db, slope=0.1, workspace=None,
+                       accumulate_db=False):
+    """dz = dgrad(dy) * LeakyReLU'(y_act), db (+)= column sums of dz -- the lower layer's activation gradient pass folded into this
+    layer's input gradient (dim_conv2d_dgrad_bf16_lrelu: bf16 patch kernel only).  dz, y_act: dense (N, H, W, Cin)."""
+    N, Ho, Wo, dy_cs = dy_nhwc.shape
+    _, H, W, dx_cs = dz_nhwc.shape
+    assert w_dgrad_packed_bf16.dtype == bf16 and tuple(y_act_nhwc.shape) == tuple(dz_nhwc.shape) == (N, H, W, Cin)
+    assert dz_nhwc.is_contiguous() and y_act_nhwc.is_contiguous() and db.numel() == Cin
+    need = lib().dim_conv2d_dgrad_lrelu_workspace_floats(N, H, W, Cin, stride)
+    if workspace is None or workspace.numel() < need:
+        workspace = _new((need,), dz_nhwc)
+    check(lib().dim_conv2d_dgrad_bf16_lrelu(dptr(dy_nhwc, f32), dptr(w_dgrad_packed_bf16, bf16), dptr(dz_nhwc, f32), dptr(y_act_nhwc, f32),
+                                            float(slope), dptr(db, f32), dptr(workspace, f32), N, H, W, Cin, dx_cs, Ho, Wo, Cout, dy_cs, KH, KW,
+                                            stride, pad, int(accumulate_db), current_stream()))
+    return dz_nhwc
+
+
 def conv2d_dgrad(dy_nhwc, Cout, w_dgrad_packed, dx_nhwc, Cin, KH, KW, stride, pad, accumulate=False, tile=3, splits=1, workspace=None):
     """dx[..., :Cin] (+)= dgrad(dy[..., :Cout]); dx / dy may be wider concat buffers.
     splits > 1 (bf16 weights, tile 3 / 4): split-K through output-shaped slabs in `workspace` (small maps: too few tiles for the chip)"""

@@ -183,6 +183,43 @@ def test_dgrad_wgrad_bf16(ops, case):
     assert torch.equal(f32_one, ops.conv2d_unpack_weight(f32_two, torch.empty_like(one)))
 
 
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin (of dX / the activation below), Cout (of dy), k, s, p
+    (2, 60, 80, 64, 128, 5, 2, 2),      # the four phase images of a 5x5 / stride-2 gradient, 64-channel tile
+    (1, 47, 61, 128, 256, 5, 2, 2),     # odd map: phases of different sizes, partial 16 x 16 blocks
+    (2, 30, 40, 256, 256, 3, 1, 1),     # 3x3 / stride 1
+    (1, 37, 53, 128, 128, 3, 1, 1),
+])
+def test_dgrad_with_lrelu_and_bias_gradient_folded_in(ops, case):
+    """dim_conv2d_dgrad_bf16_lrelu == dim_conv2d_dgrad_bf16 (tile 9) followed by dim_lrelu_bwd_bias_grad: dz bit for bit, db up to the
+    summation order; and both against float64 on the bf16-rounded operands"""
+    N, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    w = torch.randn((Cout, Cin, k, k), generator=g, dtype=torch.float64) / np.sqrt(Cout * k * k)
+    dy = torch.randn((N, Cout, Ho, Wo), generator=g, dtype=torch.float64)
+    y_act = torch.randn((N, Cin, H, W), generator=g)
+    y_act[0, :, :2, :3] = 0.0                                  # exact zeros take the slope branch (y > 0 ? 1 : slope)
+    wd = ops.to_bf16(ops.conv2d_dgrad_pack_weight(w.float().to(DEV), s, p))
+    two = torch.empty((N, H, W, Cin), device=DEV)
+    ops.conv2d_dgrad(nhwc(dy.float()), Cout, wd, two, Cin, k, k, s, p, accumulate=False, tile=9)
+    db_two = torch.zeros(Cin, device=DEV)
+    ops.lrelu_bwd_bias_grad(nhwc(y_act), two, Cin, db_two)
+    one = torch.full((N, H, W, Cin), 9.0, device=DEV)
+    db_one = torch.full((Cin,), 5.0, device=DEV)
+    ops.conv2d_dgrad_lrelu(nhwc(dy.float()), Cout, wd, one, nhwc(y_act), Cin, k, k, s, p, db_one)
+    assert torch.equal(one, two)
+    scale = db_two.abs().max().item()
+    assert (db_one - db_two).abs().max().item() <= 2e-5 * scale + 1e-6
+    ops.conv2d_dgrad_lrelu(nhwc(dy.float()), Cout, wd, one, nhwc(y_act), Cin, k, k, s, p, db_one, accumulate_db=True)
+    assert (db_one - 2 * db_two).abs().max().item() <= 4e-5 * scale + 2e-6
+    dx_ref = torch.nn.grad.conv2d_input((N, Cin, H, W), r16(w), r16(dy), stride=s, padding=p)
+    dz_ref = dx_ref * torch.where(y_act.double() > 0, 1.0, 0.1)
+    got = one.permute(0, 3, 1, 2).cpu().double()
+    assert (got - dz_ref).abs().max().item() <= 1e-4 * dz_ref.abs().max().item() + 1e-5
+    assert (db_two.cpu().double() - dz_ref.sum((0, 2, 3))).abs().max().item() <= 1e-4 * dz_ref.sum((0, 2, 3)).abs().max().item() + 1e-3
+
+
 def test_wgrad_bf16_first_layer_cin8_and_fc6(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn((2, 8, 33, 41), generator=g, dtype=torch.float64)
