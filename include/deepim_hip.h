@@ -342,23 +342,6 @@ int dim_conv2d_wgrad_oihw(const float* x, const float* dz, float* dw_oihw, float
  * 9 = stride-1 patch kernel (16 x 16 pixels x 128 or 64 channels, KH, KW <= 3 with 2 .. 9 taps, Cin % 32 == 0, Cout % 64 == 0, dense or
  * scattered output, batched phases); dim_conv2d_dgrad_bf16 with tile 9 applies it to every phase of a strided gradient that has >= 2
  * taps and runs the single-tap phase on the gathered-tap kernel. */
-/* Recorded packing: the training executor re-packs ~25 weight arrays after every update (deepim/core/module.py:666-688 ends in the same
- * need: new weights for the next forward), each a layout-converter launch of 4.5-22 us that is mostly ramp and tail.  Between
- * dim_wtile_record_begin() and dim_wtile_record_end() (same host thread) every tiled rows -> packed launch of dim_conv2d_pack_weight[_bf16 /
- * _padded], dim_conv2d_dgrad_pack_weight[_bf16], dim_deconv4x4s2_pack_weight[_bf16], dim_fc_pack_weight and
- * dim_fc_dgrad_pack_weight[_bf16] is appended to a job list INSTEAD of being launched (their source and destination pointers must
- * stay valid and in place); record_end copies the table to device and host memory (dim_wtile_job_bytes() bytes per job) and dim_wtile_run
- * executes all jobs as one launch, bit for bit what the separate launches write.  Launches that are not tiled converters (8-channel
- * first layer, small-Cout heads, Winograd transforms) run as usual during the recording. */
-long dim_wtile_job_bytes(void);
-int dim_wtile_record_begin(void);
-int dim_wtile_record_end(void* table_dev, void* table_host, long capacity_bytes, int* n_jobs, int* n_blocks, int* lds_bytes);
-int dim_wtile_run(const void* table_dev, int n_jobs, int n_blocks, int lds_bytes, void* stream);
-/* Later updates: the caller makes the SAME packer calls between dim_wtile_replay_begin(table_host, n_jobs) and dim_wtile_replay_end();
- * each tiled call is compared with the next recorded job (source, destination, element type, grid) and skipped, the others launch as
- * usual; replay_end returns an error unless every job was met exactly once in order -- then dim_wtile_run does the work. */
-int dim_wtile_replay_begin(const void* table_host, int n_jobs);
-int dim_wtile_replay_end(void);
 /* The input gradient of a layer whose INPUT is another layer's LeakyReLU output, with that LeakyReLU' and the lower layer's bias
  * gradient folded into the epilogue (tile 9, the bf16 patch kernel: 3x3 / stride 1 and 5x5 / stride 2 layers on maps of >= 1200 pixels):
  * dz (N,H,W,Cin) = dX * (y_act > 0 ? 1 : slope), db[Cin] (+)= column sums of dz.  y_act (N,H,W,Cin) is the stored activation; Cin % 64 == 0.

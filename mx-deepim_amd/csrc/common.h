@@ -101,10 +101,12 @@ struct WTileArgs {
   long jbase[32], jx[32];
 };
 template <bool TO_PACKED, typename PT>
-__device__ __forceinline__ void weight_tile_body(const WTileArgs& a, const int bx, const int by, float* wt_tile) {
+__global__ __launch_bounds__(256) void weight_tile_kernel(WTileArgs a) {
+  extern __shared__ float wt_tile[];
   __shared__ int s_jq[32];
   __shared__ long s_jb[32];
   const int G = a.G, Q = a.Q, P = Q | 1, lg = 31 - __builtin_clz(G);  // G is a power of two
+  const int bx = blockIdx.x, by = blockIdx.y;
   const bool table = a.nj > 0;
   const int nj = table ? a.nj : Q;
   if (table && threadIdx.x < a.nj) {
@@ -198,34 +200,6 @@ __device__ __forceinline__ void weight_tile_body(const WTileArgs& a, const int b
 #undef WT_ROWS_BATCH
 #undef WT_ADDR
 }
-template <bool TO_PACKED, typename PT>
-__global__ __launch_bounds__(256) void weight_tile_kernel(WTileArgs a) {
-  extern __shared__ float wt_tile[];
-  weight_tile_body<TO_PACKED, PT>(a, blockIdx.x, blockIdx.y, wt_tile);
-}
-// Many converter jobs as ONE launch (the training executor re-packs ~25 weight arrays after every update: 4.5-22 us each as launches of
-// their own, most of it ramp and tail).  A job = the WTileArgs of one weight_tile_kernel<true, PT> launch + its grid; workgroup b finds
-// its job in the prefix of workgroup counts.  The table lives in device memory (dim_wtile_record_* / dim_wtile_run).
-struct WTileJob {
-  WTileArgs a;
-  int kind;         // 0: rows -> packed bf16, 1: rows -> packed f32
-  int gx, gy;       // the grid of the single launch
-  int block0;       // first workgroup of this job in the joint launch
-};
-template <int UNUSED>   // a template only so that the header may be included by several translation units
-__global__ __launch_bounds__(256) void weight_tile_multi_kernel(const WTileJob* __restrict__ jobs, int njobs) {
-  extern __shared__ float wt_tile[];
-  int lo = 0, hi = njobs - 1;   // last job with block0 <= blockIdx.x (uniform: scalar loads)
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const WTileJob& j = jobs[lo];
-  const int local = (int)blockIdx.x - j.block0;
-  const int by = local / j.gx, bx = local - by * j.gx;
-  if (j.kind == 0) weight_tile_body<true, __bf16>(j.a, bx, by, wt_tile);
-  else weight_tile_body<true, float>(j.a, bx, by, wt_tile);
-}
 inline size_t wtile_lds_bytes(int G, int Q) { return ((size_t)G * 32 * (Q | 1) + 32) * 4; }
 // sub-blocks per workgroup: a power of two <= 8 that divides `count` and keeps the LDS image within 64 KB -- the largest one that
 // still leaves >= 2048 workgroups (`outer` = the other grid dimension), else the smallest; 0 = none fits
@@ -237,15 +211,8 @@ inline int wtile_group(int count, int Q, int outer = 1) {
   }
   return (best && count / best <= 65535 && outer <= 65535) ? best : 0;  // grid.y = count / G
 }
-// recorder (conv.hip): while a recording is open, rows -> packed launches are appended to a job list instead of being launched
-bool wtile_recording();
-int wtile_record(const WTileArgs& a, int kind, int gx, int gy);
 template <bool TO_PACKED, typename PT>
 inline void wtile_launch(const WTileArgs& a, int gx, int gy, hipStream_t st) {
-  if (TO_PACKED && wtile_recording()) {
-    wtile_record(a, sizeof(PT) == 2 ? 0 : 1, gx, gy);
-    return;
-  }
   hipLaunchKernelGGL((weight_tile_kernel<TO_PACKED, PT>), dim3(gx, gy), dim3(256), wtile_lds_bytes(a.G, a.Q), st, a);
 }
 #endif

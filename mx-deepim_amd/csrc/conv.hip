@@ -16,11 +16,8 @@
 // Epilogue: bias + LeakyReLU fused; with gridDim.z > 1 (split-K) raw partials go to a slab
 // and dim_splitk_reduce finishes (deterministic, no atomics).
 #include <cstdlib>
-#include <cstring>
 #include <type_traits>
 #include <utility>
-
-#include <vector>
 
 #include "common.h"
 
@@ -2272,100 +2269,6 @@ int dim_conv2d_dgrad_bf16_splitk(const float* dy, const void* w_dgrad_packed_bf1
               "split-K input gradient: dx / workspace 16-byte aligned, channel stride a multiple of 4");
   return conv2d_dgrad_impl(dy, reinterpret_cast<const float*>(w_dgrad_packed_bf16), dx, N, H, W, Cin, dx_cstride, Ho, Wo, Cout, dy_cstride,
                            KH, KW, stride, pad, accumulate, tile, 1, stream, workspace, splits);
-}
-
-// ---- recorded layout-converter jobs (common.h weight_tile_multi_kernel)
-}  // extern "C"
-namespace dim {
-static thread_local int g_wtile_mode = 0;   // 0: launch, 1: record, 2: replay (check against a recorded table and skip)
-static thread_local std::vector<WTileJob>* g_wtile_jobs = nullptr;
-static thread_local const WTileJob* g_wtile_replay = nullptr;
-static thread_local int g_wtile_replay_n = 0, g_wtile_cursor = 0, g_wtile_mismatch = -1;
-bool wtile_recording() { return g_wtile_mode != 0; }
-int wtile_record(const WTileArgs& a, int kind, int gx, int gy) {
-  if (g_wtile_mode == 2) {
-    const int k = g_wtile_cursor++;
-    const bool same = k < g_wtile_replay_n && g_wtile_replay[k].a.src == a.src && g_wtile_replay[k].a.dst == a.dst &&
-                      g_wtile_replay[k].kind == kind && g_wtile_replay[k].gx == gx && g_wtile_replay[k].gy == gy;
-    if (!same && g_wtile_mismatch < 0) g_wtile_mismatch = k;
-    return DIM_OK;
-  }
-  if (!g_wtile_jobs) g_wtile_jobs = new std::vector<WTileJob>();
-  WTileJob j;
-  j.a = a;
-  j.kind = kind;
-  j.gx = gx;
-  j.gy = gy;
-  j.block0 = g_wtile_jobs->empty() ? 0 : g_wtile_jobs->back().block0 + g_wtile_jobs->back().gx * g_wtile_jobs->back().gy;
-  g_wtile_jobs->push_back(j);
-  return DIM_OK;
-}
-}  // namespace dim
-extern "C" {
-
-long dim_wtile_job_bytes(void) { return (long)sizeof(WTileJob); }
-
-int dim_wtile_record_begin(void) {
-  DIM_REQUIRE(g_wtile_mode == 0, "a converter recording / replay is already open on this thread");
-  if (g_wtile_jobs) g_wtile_jobs->clear();
-  g_wtile_mode = 1;
-  return DIM_OK;
-}
-
-// closes the recording and copies the job table to `table_dev` and `table_host` (capacity in bytes each; the device copy is
-// synchronous: this runs once).  -> number of jobs, workgroups and dynamic LDS bytes of the joint launch
-int dim_wtile_record_end(void* table_dev, void* table_host, long capacity_bytes, int* n_jobs, int* n_blocks, int* lds_bytes) {
-  DIM_REQUIRE(g_wtile_mode == 1, "no converter recording is open on this thread");
-  g_wtile_mode = 0;
-  DIM_REQUIRE(n_jobs && n_blocks && lds_bytes, "null pointer");
-  const size_t n = g_wtile_jobs ? g_wtile_jobs->size() : 0;
-  *n_jobs = (int)n;
-  *n_blocks = 0;
-  *lds_bytes = 0;
-  if (n == 0) return DIM_OK;
-  DIM_REQUIRE(table_dev && table_host && (long)(n * sizeof(WTileJob)) <= capacity_bytes, "job table needs %zu bytes, %ld given",
-              n * sizeof(WTileJob), capacity_bytes);
-  size_t lds = 0;
-  for (const WTileJob& j : *g_wtile_jobs) {
-    const size_t l = wtile_lds_bytes(j.a.G, j.a.Q);
-    if (l > lds) lds = l;
-  }
-  *n_blocks = g_wtile_jobs->back().block0 + g_wtile_jobs->back().gx * g_wtile_jobs->back().gy;
-  *lds_bytes = (int)lds;
-  memcpy(table_host, g_wtile_jobs->data(), n * sizeof(WTileJob));
-  hipError_t e = hipMemcpy(table_dev, g_wtile_jobs->data(), n * sizeof(WTileJob), hipMemcpyHostToDevice);
-  if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipMemcpy(job table): %s", hipGetErrorString(e));
-  return DIM_OK;
-}
-
-// Replay: between begin and end every tiled rows -> packed launch is compared with the next recorded job (same source, destination,
-// element type and grid) and SKIPPED -- dim_wtile_run does their work; anything else launches as usual.  replay_end fails unless the
-// calls met every job exactly once, in order: a caller whose tensors moved, or whose shapes stopped being tiled, finds out here.
-int dim_wtile_replay_begin(const void* table_host, int n_jobs) {
-  DIM_REQUIRE(g_wtile_mode == 0, "a converter recording / replay is already open on this thread");
-  DIM_REQUIRE(n_jobs == 0 || table_host, "null pointer");
-  g_wtile_replay = reinterpret_cast<const WTileJob*>(table_host);
-  g_wtile_replay_n = n_jobs;
-  g_wtile_cursor = 0;
-  g_wtile_mismatch = -1;
-  g_wtile_mode = 2;
-  return DIM_OK;
-}
-
-int dim_wtile_replay_end(void) {
-  DIM_REQUIRE(g_wtile_mode == 2, "no converter replay is open on this thread");
-  g_wtile_mode = 0;
-  DIM_REQUIRE(g_wtile_mismatch < 0, "replayed packer call %d does not match the recorded job (tensor moved or shape changed)", g_wtile_mismatch);
-  DIM_REQUIRE(g_wtile_cursor == g_wtile_replay_n, "replay met %d packer calls, the table holds %d jobs", g_wtile_cursor, g_wtile_replay_n);
-  return DIM_OK;
-}
-
-int dim_wtile_run(const void* table_dev, int n_jobs, int n_blocks, int lds_bytes, void* stream) {
-  if (n_jobs == 0) return DIM_OK;
-  DIM_REQUIRE(table_dev && n_jobs > 0 && n_blocks > 0 && lds_bytes > 0 && lds_bytes <= 65536, "bad job table description");
-  hipLaunchKernelGGL(weight_tile_multi_kernel<0>, dim3(n_blocks), dim3(256), (size_t)lds_bytes, as_stream(stream),
-                     reinterpret_cast<const WTileJob*>(table_dev), n_jobs);
-  return check_launch("weight_tile_multi");
 }
 
 long dim_conv2d_dgrad_lrelu_workspace_floats(int N, int H, int W, int Cin, int stride) {

@@ -24,7 +24,6 @@ from lib.utils.dist_utils import allreduce_sum_
 from deepim.symbols.deepIM_flownet import bf16_tile, BF16_PATCH, ENCODER, FlowNetHip, deepIM_flownet
 
 FUSED_UNPACK = os.environ.get("DIM_WGRAD_FUSED_UNPACK", "1") != "0"   # encoder weight gradients through dim_conv2d_wgrad_oihw
-PACK_TABLE = os.environ.get("DIM_PACK_TABLE", "1") != "0"               # tiled weight packers of an update as one launch (repack)
 FOLD_LRELU = os.environ.get("DIM_BF16_FOLD_LRELU", "1") != "0"         # bf16: LeakyReLU' + bias gradient inside the input-gradient epilogue
 FROZEN = ("upsampling_weight", "mask_upsampling_weight")  # attr lr_mult 0.0 (deepIM_flownet.py:334, :520)
 
@@ -230,35 +229,15 @@ class MutableModule(object):
                     need = max(need, ops.lib().dim_conv2d_wgrad_winograd_workspace_floats(B, h, w, c, cout, S, sp))
                 h, w, c = ho, wo, cout
             self.wino_wgrad_ws = torch.empty(need, dtype=torch.float32, device=d)
-        self.pack_table, self.use_pack_table = None, PACK_TABLE   # tests switch use_pack_table off on a twin executor
         self.repack(forward=False)
 
     # ------------------------------------------------------------------------------------------------------------
     def repack(self, forward=True):
         """master (MXNet layout) -> the kernels' packed copies: forward layouts (FlowNetHip.packed) and dgrad layouts
-        (bf16 mode: bf16 images of the same packed arrays).
-
-        The ~25 tiled packers run as ONE launch (ops.PackTable): the first full repack records them, every later one replays -- the same
-        calls with the previous results as destinations are checked against the table and skipped (a tensor that moved, or a shape that is
-        not tiled, makes the replay fail loudly instead of training on stale layouts), then the table runs.  Launches of their own:
-        376 us per update; one launch: see DESIGN section 3c.  DIM_PACK_TABLE=0: separate launches.
-        (Measured and dropped in round 3: packing everything that is first read at fc6 or later on a second stream behind the
-        optimizer step, overlapped with the next encoder forward -- 6.40 vs 6.41 ms per bf16 iteration.)"""
-        if not (self.use_pack_table and forward):
-            self._repack_calls(forward)
-            return
-        if self.pack_table is None:
-            self.pack_table = ops.PackTable(self.device)
-            with self.pack_table.recording():
-                self._repack_calls(True)
-        else:
-            with self.pack_table.replaying():
-                self._repack_calls(True)
-        self.pack_table.run()
-
-    def _repack_calls(self, forward):
+        (bf16 mode: bf16 images of the same packed arrays).  (Measured and dropped in round 3: packing everything that is first read
+        at fc6 or later on a second stream behind the optimizer step, overlapped with the next encoder forward -- 6.40 vs 6.41 ms per
+        bf16 iteration: the packers and the now HBM-bound first layers want the same bytes per second.)"""
         net, w = self.net, self.w
-        fp, dp = net.packed, self.dgrad_packed   # destinations: previous results are rewritten in place (stable pointers)
         for name, cout, k, s, p in ENCODER:
             if forward:
                 if name in net.wino:   # 3x3 / stride-1 layers run their forward through Winograd: re-transform the weights
@@ -268,31 +247,31 @@ class MutableModule(object):
                 elif name == "flow_conv1" and net.cin != 8:
                     # 6 input channels (no masks in the Concat) or 10 (depth planes and masks): the kernels take 8-lane groups
                     ops.copy_channels(self.w1_lanes[0], 0, w[name + "_weight"], 0, min(net.cin, 8))
-                    fp[name] = net.pack_conv(self.w1_lanes[0], out=fp.get(name))
+                    net.packed[name] = net.pack_conv(self.w1_lanes[0])
                     if net.input_mode == 3:
                         ops.copy_channels(self.w1_lanes[1], 0, w[name + "_weight"], 8, 2)
-                        fp["flow_conv1_masks"] = net.pack_conv(self.w1_lanes[1], out=fp.get("flow_conv1_masks"))
+                        net.packed["flow_conv1_masks"] = net.pack_conv(self.w1_lanes[1])
                 else:
-                    fp[name] = net.pack_conv(w[name + "_weight"], out=fp.get(name))
+                    net.packed[name] = net.pack_conv(w[name + "_weight"])
             if name in net.wino:
                 self.wino_dgrad[name] = ops.winograd_dgrad_pack_weight(w[name + "_weight"], m=net.wino_m[name])
             elif name in net.wino5:  # 5x5 / stride-2 layers: input gradient through Winograd too (four phase images of dX)
                 self.wino5_dgrad[name] = ops.winograd5x5s2_dgrad_pack_weight(w[name + "_weight"])
             elif name != "flow_conv1":
-                dp[name] = ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p, as_bf16=self.bf16, out=dp.get(name))
+                self.dgrad_packed[name] = ops.conv2d_dgrad_pack_weight(w[name + "_weight"], s, p, as_bf16=self.bf16)
         if forward:
-            fp["fc6"] = ops.fc_pack_weight(w["fc6_weight"], 1024, 8, 10, out=fp.get("fc6"))
+            net.packed["fc6"] = ops.fc_pack_weight(w["fc6_weight"], 1024, 8, 10)
             if self.has_decoder:
-                fp["deconv5"] = net.pack_deconv(w["deconv5_weight"], out=fp.get("deconv5"))
-                fp["deconv4"] = net.pack_deconv(w["deconv4_weight"], out=fp.get("deconv4"))
+                net.packed["deconv5"] = net.pack_deconv(w["deconv5_weight"])
+                net.packed["deconv4"] = net.pack_deconv(w["deconv4_weight"])
             for n in ("Convolution1", "Convolution2", "Convolution3", "mask_conv3"):
                 if n + "_weight" in w:
-                    fp[n] = ops.conv_small_cout_pack_weight(w[n + "_weight"])
-        dp["fc6"] = ops.fc_dgrad_pack_weight(w["fc6_weight"], 1024, 8, 10, as_bf16=self.bf16, out=dp.get("fc6"))
+                    net.packed[n] = ops.conv_small_cout_pack_weight(w[n + "_weight"])
+        self.dgrad_packed["fc6"] = ops.fc_dgrad_pack_weight(w["fc6_weight"], 1024, 8, 10, as_bf16=self.bf16)
         if self.has_decoder:
             # deconv dgrad = a plain stride-2 convolution of the output gradient with the deconv weight read as (O=Cin, I=Cout, 4, 4)
-            dp["deconv5"] = ops.conv2d_pack_weight_padded(w["deconv5_weight"], 1024, as_bf16=self.bf16, out=dp.get("deconv5"))
-            dp["deconv4"] = ops.conv2d_pack_weight_padded(w["deconv4_weight"], ops.pad64(1026), as_bf16=self.bf16, out=dp.get("deconv4"))
+            self.dgrad_packed["deconv5"] = ops.conv2d_pack_weight_padded(w["deconv5_weight"], 1024, as_bf16=self.bf16)
+            self.dgrad_packed["deconv4"] = ops.conv2d_pack_weight_padded(w["deconv4_weight"], ops.pad64(1026), as_bf16=self.bf16)
 
     # ------------------------------------------------------------------------------------------------------------
     def forward(self, batch):

@@ -328,12 +328,12 @@ class FlowNetHip(object):
         self.status = torch.zeros((B,), dtype=torch.int32, device=d)
         torch.cuda.synchronize(d)
 
-    def pack_conv(self, w_oihw, out=None):
-        """MXNet (Cout,Cin,kh,kw) -> the forward kernel's packed array (bf16 copy in bf16 mode); out: a previous result, rewritten in place"""
-        return ops.conv2d_pack_weight(w_oihw, as_bf16=self.bf16, out=out)
+    def pack_conv(self, w_oihw):
+        """MXNet (Cout,Cin,kh,kw) -> the forward kernel's packed array (bf16 copy in bf16 mode)"""
+        return ops.conv2d_pack_weight(w_oihw, as_bf16=self.bf16)
 
-    def pack_deconv(self, w_iohw, out=None):
-        return ops.deconv4x4s2_pack_weight(w_iohw, as_bf16=self.bf16, out=out)
+    def pack_deconv(self, w_iohw):
+        return ops.deconv4x4s2_pack_weight(w_iohw, as_bf16=self.bf16)
 
     @staticmethod
     def _wino_tile(cout, tiles):

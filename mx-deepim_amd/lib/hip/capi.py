@@ -125,12 +125,6 @@ SIGNATURES = {
     "dim_conv2d_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dim_conv2d_dgrad_lrelu_workspace_floats": (L, [I, I, I, I, I]),
     "dim_conv2d_dgrad_bf16_lrelu": (I, [P, P, P, P, F, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
-    "dim_wtile_job_bytes": (L, []),
-    "dim_wtile_record_begin": (I, []),
-    "dim_wtile_record_end": (I, [P, P, L, P, P, P]),
-    "dim_wtile_replay_begin": (I, [P, I]),
-    "dim_wtile_replay_end": (I, []),
-    "dim_wtile_run": (I, [P, I, I, I, P]),
     "dim_conv2d_wgrad_oihw": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
     "dim_bias_grad_workspace_floats": (L, [I, I]),
     "dim_bias_grad": (I, [P, P, P, I, I, I, I, I, P]),

@@ -250,18 +250,10 @@ def point_clouds(table, table_off, idx, pose_observed, model, weights, observed)
                                  dptr(weights, f32), dptr(observed, f32), current_stream()))
 
 
-def _packed_out(out, n, like, as_bf16):
-    """a packer's destination: `out` (a previous result of the same call: same size and type, written in place) or a new array"""
-    if out is None:
-        return torch.empty((n,), dtype=bf16 if as_bf16 else f32, device=like.device)
-    assert out.numel() == n and out.dtype == (bf16 if as_bf16 else f32) and out.is_contiguous()
-    return out
-
-
-def conv2d_pack_weight(w_oihw, as_bf16=False, out=None):
+def conv2d_pack_weight(w_oihw, as_bf16=False):
     Cout, Cin, KH, KW = w_oihw.shape
     n = lib().dim_conv2d_packed_weight_floats(Cout, Cin, KH, KW)
-    wp = _packed_out(out, n, w_oihw, as_bf16)
+    wp = torch.empty((n,), dtype=bf16 if as_bf16 else f32, device=w_oihw.device)
     if as_bf16:
         check(lib().dim_conv2d_pack_weight_bf16(dptr(w_oihw.contiguous(), f32), dptr(wp, bf16), Cout, Cout, Cin, KH, KW, current_stream()))
     else:
@@ -269,9 +261,9 @@ def conv2d_pack_weight(w_oihw, as_bf16=False, out=None):
     return wp
 
 
-def fc_pack_weight(w_out_in, C, H, W, out=None):
+def fc_pack_weight(w_out_in, C, H, W):
     Out = w_out_in.shape[0]
-    wp = _packed_out(out, Out * C * H * W, w_out_in, False)
+    wp = _new((Out * C * H * W,), w_out_in)
     check(lib().dim_fc_pack_weight(dptr(w_out_in.contiguous(), f32), dptr(wp, f32), Out, C, H, W, current_stream()))
     return wp
 
@@ -534,10 +526,10 @@ def _new_packed(n, like, as_bf16):
     return torch.empty((n,), dtype=bf16 if as_bf16 else f32, device=like.device)
 
 
-def deconv4x4s2_pack_weight(w_iohw, as_bf16=False, out=None):
+def deconv4x4s2_pack_weight(w_iohw, as_bf16=False):
     """as_bf16: the bf16 image of the packed array in one pass (== to_bf16 of the f32 result); same for the packers below"""
     Cin, Cout = w_iohw.shape[:2]
-    wp = _packed_out(out, lib().dim_deconv4x4s2_packed_weight_floats(Cin, Cout), w_iohw, as_bf16)
+    wp = _new_packed(lib().dim_deconv4x4s2_packed_weight_floats(Cin, Cout), w_iohw, as_bf16)
     if as_bf16:
         check(lib().dim_deconv4x4s2_pack_weight_bf16(dptr(w_iohw.contiguous(), f32), dptr(wp, bf16), Cin, Cout, current_stream()))
     else:
@@ -592,66 +584,15 @@ def pad64(c):
     return (c + 63) // 64 * 64
 
 
-def conv2d_dgrad_pack_weight(w_oihw, stride, pad, as_bf16=False, out=None):
+def conv2d_dgrad_pack_weight(w_oihw, stride, pad, as_bf16=False):
     Cout, Cin, KH, KW = w_oihw.shape
-    wp = _packed_out(out, lib().dim_conv2d_dgrad_packed_weight_floats(Cout, Cin, KH, KW, stride, pad), w_oihw, as_bf16)
+    wp = _new_packed(lib().dim_conv2d_dgrad_packed_weight_floats(Cout, Cin, KH, KW, stride, pad), w_oihw, as_bf16)
     if as_bf16:
         check(lib().dim_conv2d_dgrad_pack_weight_bf16(dptr(w_oihw.contiguous(), f32), dptr(wp, bf16), Cout, Cin, KH, KW, stride, pad,
                                                       current_stream()))
     else:
         check(lib().dim_conv2d_dgrad_pack_weight(dptr(w_oihw.contiguous(), f32), dptr(wp, f32), Cout, Cin, KH, KW, stride, pad, current_stream()))
     return wp
-
-
-class PackTable(object):
-    """The tiled weight packers issued inside `with table.recording():` as ONE launch (dim_wtile_*).  Nothing tiled is packed during the
-    recording itself: call run() afterwards.  When the (in-place updated) source weights change, make the SAME packer calls with
-    out=<their previous results> inside `with table.replaying():` -- each tiled call is checked against the table and skipped, the
-    others launch -- and run() again.  The recorded source and destination tensors must stay alive and in place; the caller holds them."""
-
-    def __init__(self, device, max_jobs=96):
-        import ctypes
-
-        nbytes = max_jobs * lib().dim_wtile_job_bytes()
-        self.table = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        self.host = ctypes.create_string_buffer(nbytes)
-        self.n_jobs = self.n_blocks = self.lds = 0
-
-    def recording(self):
-        import contextlib
-        import ctypes
-
-        @contextlib.contextmanager
-        def ctx():
-            check(lib().dim_wtile_record_begin())
-            nj, nb, lds = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-            try:
-                yield self
-            finally:
-                check(lib().dim_wtile_record_end(self.table.data_ptr(), ctypes.addressof(self.host), self.table.numel(), ctypes.byref(nj),
-                                                 ctypes.byref(nb), ctypes.byref(lds)))
-                self.n_jobs, self.n_blocks, self.lds = nj.value, nb.value, lds.value
-        return ctx()
-
-    def replaying(self):
-        import contextlib
-        import ctypes
-
-        @contextlib.contextmanager
-        def ctx():
-            check(lib().dim_wtile_replay_begin(ctypes.addressof(self.host), self.n_jobs))
-            ok = False
-            try:
-                yield self
-                ok = True
-            finally:
-                rc = lib().dim_wtile_replay_end()
-                if ok:
-                    check(rc)
-        return ctx()
-
-    def run(self):
-        check(lib().dim_wtile_run(self.table.data_ptr(), self.n_jobs, self.n_blocks, self.lds, current_stream()))
 
 
 def conv2d_dgrad_lrelu(dy_nhwc, Cout, w_dgrad_packed_bf16, dz_nhwc, y_act_nhwc, Cin, KH, KW, stride, pad, db, slope=0.1, workspace=None,
@@ -751,9 +692,9 @@ def _p(t, off=0):
     return dptr(t, f32) + 4 * off
 
 
-def conv2d_pack_weight_padded(w_oihw, CoutPad, as_bf16=False, out=None):
+def conv2d_pack_weight_padded(w_oihw, CoutPad, as_bf16=False):
     Cout, Cin, KH, KW = w_oihw.shape
-    wp = _packed_out(out, KH * KW * Cin * CoutPad, w_oihw, as_bf16)
+    wp = _new_packed(KH * KW * Cin * CoutPad, w_oihw, as_bf16)
     if as_bf16:
         check(lib().dim_conv2d_pack_weight_bf16(dptr(w_oihw.contiguous(), f32), dptr(wp, bf16), Cout, CoutPad, Cin, KH, KW, current_stream()))
     else:

@@ -206,39 +206,3 @@ def test_bf16_training_batch16_runs_and_stays_finite(hip_lib):
     assert torch.isfinite(mod.flat_w).all()
     new = mod.get_params()
     assert np.abs(new["conv3_weight"] - params["conv3_weight"]).max() > 0
-
-
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
-def test_recorded_packers_and_folded_passes_leave_the_same_bits(hip_lib, dtype):
-    """The update's ~25 weight packers as ONE recorded launch (ops.PackTable: recorded at the first update, replayed -- every call checked
-    against the table -- at the later ones) write exactly what the separate launches write: two executors, three updates each, every
-    packed array and every weight equal bit for bit.  And a replay whose destination moved must fail instead of training on stale layouts."""
-    from deepim.core.module import MutableModule
-    from deepim.symbols.deepIM_flownet import deepIM_flownet
-    from lib.hip import capi
-
-    cfg = make_train_config()
-    sym = deepIM_flownet()
-    sym.get_symbol(cfg, is_train=True)
-    params = sym.init_weights(cfg, {}, {}, seed=3)
-    B = 2
-    scene = make_train_scene(B=B, seed=7, subdiv=3)
-    batch = {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in scene["blobs"].items()}
-    a = MutableModule(cfg, params, B, compute_dtype=dtype)
-    b = MutableModule(cfg, params, B, compute_dtype=dtype)
-    b.use_pack_table = False
-    for _ in range(3):
-        for m in (a, b):
-            m.forward_backward(batch)
-            m.update(1e-3)
-    assert a.pack_table is not None and a.pack_table.n_jobs >= (20 if dtype == "bf16" else 8) and b.pack_table is None
-    print("jobs", a.pack_table.n_jobs, "workgroups", a.pack_table.n_blocks, "lds", a.pack_table.lds)
-    assert torch.equal(a.flat_w, b.flat_w)
-    for da, db in ((a.net.packed, b.net.packed), (a.dgrad_packed, b.dgrad_packed)):
-        assert set(da) == set(db)
-        for k in da:
-            assert torch.equal(da[k], db[k]), k
-    # a destination that moved: the replay must refuse
-    a.dgrad_packed["conv4"] = a.dgrad_packed["conv4"].clone()
-    with pytest.raises(capi.DeepIMHipError, match="does not match the recorded job"):
-        a.repack(forward=True)
