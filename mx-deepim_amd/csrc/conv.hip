@@ -1382,49 +1382,69 @@ __global__ void pack_deconv4x4s2_weight_kernel(const float* __restrict__ w, PT* 
   wp[idx] = (PT)v;
 }
 
-// Convolution with a handful of output channels (flow / mask heads, Cout <= 2): one wave per output pixel, lanes stride the
-// (tap, channel) products with float4 loads, wave reduction.  HBM/L2-bound on the activations; weights (Cout,Cin,3,3 MXNet
-// layout) are re-packed to [Cout][kh][kw][CinPad].
-template <int COUT>
+// Convolution with a handful of output channels (flow / mask heads, Cout <= 2).  HBM/L2-bound on the activations; weights (Cout,Cin,3,3
+// MXNet layout) are re-packed to [Cout][kh][kw][CinPad].  A wave owns PX horizontally adjacent output pixels; a lane strides the channel
+// quads (float4), and for every quad and kernel row loads the PX + KW - 1 input pixels of the row and the KW x COUT weight quads ONCE
+// for all PX outputs; PX x COUT wave reductions at the end.  History at 16 x 30 x 40 x 770 -> 2 / -> 1: one wave per output pixel (1 + COUT
+// float4 loads per 4 COUT multiply-adds: 55 KB of weights + 28 KB of activations per pixel through the vector L1): 36 / 50 us; four
+// pixels per wave: 34 / 29 us at 60 % of the chip's vector-memory issue rate; the weights staged in LDS per workgroup with eight pixels
+// per wave: 57 / 32 us (60 KB of staging for 32 pixels, two workgroups per CU) -- dropped.
+template <int COUT, int KW, int PX>
 __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                               const float* __restrict__ bias, float* __restrict__ y, int N, int H,
-                                                              int W, int CinPad, int in_cstride, int KH, int KW, int pad,
-                                                              int out_cstride, int out_coff) {
+                                                              int W, int CinPad, int in_cstride, int KH, int pad, int out_cstride,
+                                                              int out_coff) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // XCD-contiguous numbering: the four pixels of the neighbouring workgroups read the same 3x3 rows; in launch order they sit on
-  // eight different L2s
-  const long pix = (long)wg_xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * 4 + wave;
-  if (pix >= (long)N * H * W) return;
-  const int wo = (int)(pix % W);
-  const int ho = (int)((pix / W) % H);
-  const int n = (int)(pix / ((long)W * H));
-  float acc[COUT];
-#pragma unroll
-  for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
   const int c4 = CinPad >> 2;
+  const int segs = (W + PX - 1) / PX;   // pixel groups per row
+  // XCD-contiguous numbering: neighbouring groups read the same input rows; in launch order they sit on eight different L2s
+  const long grp = (long)wg_xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * 4 + wave;
+  if (grp >= (long)N * H * segs) return;
+  const int wo0 = (int)(grp % segs) * PX;
+  const int ho = (int)((grp / segs) % H);
+  const int n = (int)(grp / ((long)segs * H));
+  float acc[PX][COUT];
+#pragma unroll
+  for (int p = 0; p < PX; ++p)
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[p][c] = 0.f;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int kh = 0; kh < KH; ++kh) {
     const int hi = ho - pad + kh;
-    if ((unsigned)hi >= (unsigned)H) continue;
-    for (int kw = 0; kw < KW; ++kw) {
-      const int wi = wo - pad + kw;
-      if ((unsigned)wi >= (unsigned)W) continue;
-      const float4* xs = reinterpret_cast<const float4*>(x + ((long)(n * H + hi) * W + wi) * in_cstride);
-      for (int i = lane; i < c4; i += 64) {
-        float4 v = xs[i];
+    if ((unsigned)hi >= (unsigned)H) continue;   // wave-uniform
+    const float* xrow = x + (long)(n * H + hi) * W * in_cstride;
+    for (int i = lane; i < c4; i += 64) {
+      float4 xv[PX + KW - 1], wv[KW][COUT];
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) {
-          float4 wv = reinterpret_cast<const float4*>(wp + ((long)(c * KH + kh) * KW + kw) * CinPad)[i];
-          acc[c] = fmaf(v.x, wv.x, fmaf(v.y, wv.y, fmaf(v.z, wv.z, fmaf(v.w, wv.w, acc[c]))));
-        }
+      for (int q = 0; q < PX + KW - 1; ++q) {
+        const int wi = wo0 - pad + q;
+        const bool ok = (unsigned)wi < (unsigned)W;   // wave-uniform; clamped address + select keeps the loads branch-free
+        const float4 v = reinterpret_cast<const float4*>(xrow + (long)(ok ? wi : 0) * in_cstride)[i];
+        xv[q] = ok ? v : zero;
       }
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) wv[kw][c] = reinterpret_cast<const float4*>(wp + ((long)(c * KH + kh) * KW + kw) * CinPad)[i];
+#pragma unroll
+      for (int p = 0; p < PX; ++p)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+          for (int c = 0; c < COUT; ++c) {
+            const float4 v = xv[p + kw], w4 = wv[kw][c];
+            acc[p][c] = fmaf(v.x, w4.x, fmaf(v.y, w4.y, fmaf(v.z, w4.z, fmaf(v.w, w4.w, acc[p][c]))));
+          }
     }
   }
 #pragma unroll
-  for (int c = 0; c < COUT; ++c) {
-    float v = acc[c];
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) y[pix * out_cstride + out_coff + c] = v + (bias ? bias[c] : 0.f);
-  }
+  for (int p = 0; p < PX; ++p)
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+      float v = acc[p][c];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0 && wo0 + p < W) y[((long)(n * H + ho) * W + wo0 + p) * out_cstride + out_coff + c] = v + (bias ? bias[c] : 0.f);
+    }
 }
 
 __global__ void pack_small_cout_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int CinPad,
@@ -2394,14 +2414,16 @@ int dim_conv_small_cout_fwd(const float* x, const float* w_packed, const float* 
   DIM_REQUIRE(Cout == 1 || Cout == 2, "small-Cout kernel handles Cout 1 or 2 (got %d)", Cout);
   int CinPad = (Cin + 31) / 32 * 32;
   DIM_REQUIRE(in_cstride >= CinPad && in_cstride % 4 == 0, "in_cstride must cover the padded channel count");
-  long pix = (long)N * H * W;
-  dim3 grid(ceil_div(pix, 4)), block(256);
-  if (Cout == 1)
-    hipLaunchKernelGGL(conv_small_cout_kernel<1>, grid, block, 0, as_stream(stream), x, w_packed, bias, y, N, H, W, CinPad, in_cstride,
-                       KH, KW, pad, out_cstride, out_coff);
-  else
-    hipLaunchKernelGGL(conv_small_cout_kernel<2>, grid, block, 0, as_stream(stream), x, w_packed, bias, y, N, H, W, CinPad, in_cstride,
-                       KH, KW, pad, out_cstride, out_coff);
+  DIM_REQUIRE(KW == 3 || KW == 1, "small-Cout kernel is built for 3- and 1-wide kernels (got KW = %d)", KW);
+  constexpr int PX = 4;   // eight pixels per wave halve the wave count of these small maps: 42 / 31 / 22 / 18 us against 34 / 28 / 17 / 11
+  const long groups = (long)N * H * ((W + PX - 1) / PX);
+  dim3 grid(ceil_div(groups, 4)), block(256);
+#define DIM_SMALL_COUT(CO, KWc)                                                                                                           \
+  hipLaunchKernelGGL((conv_small_cout_kernel<CO, KWc, PX>), grid, block, 0, as_stream(stream), x, w_packed, bias, y, N, H, W, CinPad,     \
+                     in_cstride, KH, pad, out_cstride, out_coff)
+  if (Cout == 1) { if (KW == 3) DIM_SMALL_COUT(1, 3); else DIM_SMALL_COUT(1, 1); }
+  else { if (KW == 3) DIM_SMALL_COUT(2, 3); else DIM_SMALL_COUT(2, 1); }
+#undef DIM_SMALL_COUT
   return check_launch("conv_small_cout");
 }
 

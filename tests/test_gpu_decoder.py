@@ -51,15 +51,17 @@ def test_deconv_tiny_and_small_cout_and_upsample16(ops):
     y = torch.zeros((2, 15, 20, 6), device=DEV)
     ops.deconv4x4s2_tiny_fwd(nhwc(x), 2, w.to(DEV), b.to(DEV), y, 2, crop=1, out_coff=3)
     np.testing.assert_allclose(y[..., 3:5].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), atol=1e-5)
-    # small-Cout conv on a zero-padded concat buffer (770 -> 800 channels)
-    for cout in (1, 2):
-        xc = torch.randn((2, 770, 30, 40), generator=g)
-        wc = torch.randn((cout, 770, 3, 3), generator=g) / 83
+    # small-Cout conv on a zero-padded concat buffer (770 -> 800 channels), and the other two heads' shapes (rows of 20 and 10 pixels:
+    # a wave owns 4 adjacent output pixels, the last group of a 10-pixel row is partial); a 7-pixel row; a 1x1 kernel
+    for cout, cin, cpad, h, w_, k in ((1, 770, 800, 30, 40, 3), (2, 770, 800, 30, 40, 3), (2, 1026, 1056, 15, 20, 3), (2, 1024, 1024, 8, 10, 3),
+                                      (1, 96, 96, 5, 7, 3), (2, 64, 64, 6, 9, 1)):
+        xc = torch.randn((2, cin, h, w_), generator=g)
+        wc = torch.randn((cout, cin, k, k), generator=g) / np.sqrt(cin * k * k)
         bc = torch.randn((cout,), generator=g)
-        refc = F.conv2d(xc.double(), wc.double(), bc.double(), padding=1).float()
-        buf = torch.zeros((2, 30, 40, 800), device=DEV)
-        buf[..., :770] = nhwc(xc)
-        out = ops.conv_small_cout_fwd(buf, 770, ops.conv_small_cout_pack_weight(wc.to(DEV)), bc.to(DEV), cout)
+        refc = F.conv2d(xc.double(), wc.double(), bc.double(), padding=k // 2).float()
+        buf = torch.zeros((2, h, w_, cpad), device=DEV)
+        buf[..., :cin] = nhwc(xc)
+        out = ops.conv_small_cout_fwd(buf, cin, ops.conv_small_cout_pack_weight(wc.to(DEV)), bc.to(DEV), cout, KH=k, KW=k, pad=k // 2)
         np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), refc.numpy(), atol=2e-5, rtol=1e-4)
     # x16 frozen-bilinear deconvolution + Crop(8,8), grouped (flow) and sigmoid (mask)
     f = torch.randn((2, 2, 30, 40), generator=g)
