@@ -276,6 +276,17 @@ int dim_conv2d_dgrad_winograd5x5s2(const float* dy, const float* w_packed, float
 long dim_conv2d_wgrad_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int S, int splits);
 int dim_conv2d_wgrad_winograd(const float* x, const float* dy, float* dw_oihw, float* workspace, int N, int H, int W, int Cin, int in_cstride,
                               int Cout, int dy_cstride, int S, int splits, float scale, int accumulate, void* stream);
+/* 3x3 / stride-2 / pad-1 layers (conv4, conv5: deepim/symbols/deepIM_flownet.py:118-126, 143-151) in the Winograd domain through their
+ * phase images: per axis the even phase meets one tap (F(4,1) = identity), the odd phase two (F(4,2), points {0, 1, -1, 2, inf}): 81
+ * multiplies per 4 x 4 output tile and channel pair against 144, 81 plane GEMMs on the stream-K kernel of the other Winograd layers.
+ * x (N,H,W,in_cstride)[:Cin] -> y (N,Ho,Wo,out_cstride)[out_coff:+Cout], Ho = floor((H - 1) / 2) + 1; Cin % 32 == 0, Cout % 64 == 0.
+ * Same result as dim_conv2d_fwd(3, 3, stride 2, pad 1) up to f32 rounding (1.4e-6 of max |y| at Cin = 256; direct: 3e-7). */
+long dim_winograd3x3s2_packed_weight_floats(int Cout, int Cin);
+long dim_winograd3x3s2_workspace_floats(int N, int H, int W, int Cin, int Cout);
+int dim_winograd3x3s2_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream);
+int dim_conv2d_fwd_winograd3x3s2(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,
+                                 int Cin, int in_cstride, int Cout, int out_cstride, int out_coff, float slope, int tile, void** events4,
+                                 void* stream);
 /* fc6 (deepim/symbols/deepIM_flownet.py:196-198) for the small batches of the refinement loop as a weight stream: y (B,Out) =
  * LeakyReLU_slope(x (B,H,W,C NHWC) . W^T + bias) with W packed by dim_fc_pack_weight.  Every workgroup owns a contiguous range of K
  * chunks and all outputs and writes one partial tile into `workspace` (dim_fc_fwd_workspace_floats floats); a second kernel sums the

@@ -371,6 +371,31 @@ def conv2d_fwd_winograd(x_nhwc, Cin, w_packed, bias, Cout, slope=0.1, tile=0, ou
 
 
 
+def winograd3x3s2_pack_weight(w_oihw):
+    """(Cout,Cin,3,3) of a stride-2 / pad-1 layer -> the 81 transformed weight sets of dim_conv2d_fwd_winograd3x3s2"""
+    Cout, Cin, KH, KW = w_oihw.shape
+    assert KH == 3 and KW == 3
+    out = _new((lib().dim_winograd3x3s2_packed_weight_floats(Cout, Cin),), w_oihw)
+    check(lib().dim_winograd3x3s2_pack_weight(dptr(w_oihw.contiguous(), f32), dptr(out, f32), Cout, Cin, current_stream()))
+    return out
+
+
+def conv2d_fwd_winograd3x3s2(x_nhwc, Cin, w_packed, bias, Cout, slope=0.1, tile=0, out=None, out_coff=0, workspace=None, events=None):
+    """y = LeakyReLU(conv 3x3 / stride 2 / pad 1 + bias) through the phase-image Winograd path (81 plane GEMMs); x (N,H,W,>=Cin) NHWC.
+    events: as conv2d_fwd_winograd."""
+    N, H, W, in_cs = x_nhwc.shape
+    out = out if out is not None else _new((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), x_nhwc)
+    need = lib().dim_winograd3x3s2_workspace_floats(N, H, W, Cin, Cout)
+    if workspace is None or workspace.numel() < need:
+        workspace = _new((need,), x_nhwc)
+    ev_arr, evs = _wino_events(events)
+    check(lib().dim_conv2d_fwd_winograd3x3s2(dptr(x_nhwc, f32), dptr(w_packed, f32), dptr(bias, f32), dptr(out, f32), dptr(workspace, f32),
+                                             N, H, W, Cin, in_cs, Cout, out.shape[-1], out_coff, float(slope), tile, ev_arr, current_stream()))
+    if events is not None:
+        events.extend([("wino_in", evs[0], evs[1]), ("conv", evs[1], evs[2]), ("wino_out", evs[2], evs[3])])
+    return out
+
+
 def winograd5x5s2_pack_weight(w_oihw):
     """(Cout,Cin,5,5) of a stride-2 / pad-2 layer -> the 36 transformed weight sets (K = 4 Cin) of dim_conv2d_fwd_winograd5x5s2"""
     Cout, Cin, KH, KW = w_oihw.shape

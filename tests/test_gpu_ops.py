@@ -738,3 +738,40 @@ def test_copy_add_rows_and_fill(hip_lib):
     assert torch.equal(ops.fill(t, 0.0), torch.zeros_like(t)) and torch.equal(ops.fill(t, 2.5), torch.full_like(t, 2.5))
     ti = torch.ones(17, dtype=torch.int32, device="cuda:0")
     assert torch.equal(ops.fill(ti, -3), torch.full_like(ti, -3))
+
+
+@pytest.mark.parametrize("shape", [(2, 60, 80, 64, 128, 0), (1, 30, 40, 256, 512, 0), (2, 15, 20, 128, 64, 3), (1, 29, 37, 32, 64, 0),
+                                   (3, 9, 11, 96, 192, 4), (2, 8, 8, 64, 256, 5), (5, 16, 24, 32, 128, 0)])
+def test_conv_winograd3x3s2_vs_f64(hip_lib, shape, monkeypatch):
+    """3x3 / stride-2 / pad-1 layers through their phase images (minimal filtering: F(4,1) on the even, F(4,2) on the odd phase; 81 plane
+    GEMMs) vs torch-CPU float64 and vs the direct kernel: odd and even maps (tiles hanging over both edges), padded channel strides, an
+    output channel offset, every GEMM tile, no bias, batch slices"""
+    import torch.nn.functional as F
+    from lib.hip import ops
+
+    N, H, W, Cin, Cout, tile = shape
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    x = torch.where(x > 0, x, 0.1 * x)                           # post-LeakyReLU statistics, as in the network
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / np.sqrt(9 * Cin)
+    b = torch.randn((Cout,), generator=g) * 0.1
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1), 0.1).permute(0, 2, 3, 1).numpy()
+    Ho, Wo = ref.shape[1:3]
+    xd = torch.zeros((N, H, W, Cin + 8), device="cuda:0")
+    xd[..., :Cin] = x.permute(0, 2, 3, 1).to("cuda:0")
+    wp = ops.winograd3x3s2_pack_weight(w.to("cuda:0"))
+    y = torch.full((N, Ho, Wo, Cout + 16), 7.0, device="cuda:0")
+    ops.conv2d_fwd_winograd3x3s2(xd, Cin, wp, b.to("cuda:0"), Cout, slope=0.1, tile=tile, out=y, out_coff=4)
+    got = y.cpu().numpy()
+    tol = 1e-4 * np.abs(ref).max() + 2e-5
+    assert np.abs(got[..., 4:4 + Cout] - ref).max() <= tol
+    assert np.all(got[..., :4] == 7.0) and np.all(got[..., 4 + Cout:] == 7.0)
+    direct = ops.conv2d_fwd(xd[..., :Cin].contiguous(), ops.conv2d_pack_weight(w.to("cuda:0")), b.to("cuda:0"), Cout, 3, 3, 2, 1, slope=0.1, tile=3)
+    assert np.abs(got[..., 4:4 + Cout] - direct.cpu().numpy()).max() <= tol
+    ref0 = F.conv2d(x.double(), w.double(), None, stride=2, padding=1).permute(0, 2, 3, 1).numpy()      # no bias, linear
+    y0 = ops.conv2d_fwd_winograd3x3s2(xd, Cin, wp, None, Cout, slope=1.0, tile=tile)
+    assert np.abs(y0.cpu().numpy() - ref0).max() <= 1e-4 * np.abs(ref0).max() + 2e-5
+    if N >= 3:   # the batch in slices of two images through the same workspace
+        monkeypatch.setenv("DIM_WINO_MAX_SLICE", "2")
+        y2 = ops.conv2d_fwd_winograd3x3s2(xd, Cin, wp, None, Cout, slope=1.0, tile=tile)
+        assert torch.equal(y2, y0)
