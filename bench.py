@@ -609,7 +609,9 @@ def main():
                                    else "FAST_TEST graph (zoom + FlowNetS encoder + FC heads) ")
                                 + "+ SE3 compose + HIP rasteriser ({} triangles) + box_rendered mask update").format(
                                    B, test_iter, models[0][2].shape[0]),
-                   "pairs_per_gpu": B, "global_pairs": B * world, "test_iter": test_iter, "hipgraph": not args.no_graph, "winograd": "off" if args.no_winograd else "F(4x4,3x3): conv3_1 conv4_1 conv5_1 conv6_1; phase images + F(4x4,3x3): conv2 conv3",
+                   "pairs_per_gpu": B, "global_pairs": B * world, "test_iter": test_iter, "hipgraph": not args.no_graph, "winograd": "off" if args.no_winograd else "F(4x4,3x3): {}; phase images + F(4x4,3x3): {}{}".format(
+                       " ".join(net.wino), " ".join(net.wino5),
+                       "; phase images + minimal filtering F(4,1) x F(4,2): " + " ".join(net.wino3s2) if net.wino3s2 else ""),
                    "gflop_per_refinement": round(net.flops_per_forward() * test_iter / B / 1e9, 2), "status_flags": status,
                    "conv_plan": {k: list(v) for k, v in net.conv_plan.items()}},
         "roofline": roofline,

@@ -282,6 +282,7 @@ int dim_conv2d_wgrad_winograd(const float* x, const float* dy, float* dw_oihw, f
  * x (N,H,W,in_cstride)[:Cin] -> y (N,Ho,Wo,out_cstride)[out_coff:+Cout], Ho = floor((H - 1) / 2) + 1; Cin % 32 == 0, Cout % 64 == 0.
  * Same result as dim_conv2d_fwd(3, 3, stride 2, pad 1) up to f32 rounding (1.4e-6 of max |y| at Cin = 256; direct: 3e-7). */
 long dim_winograd3x3s2_packed_weight_floats(int Cout, int Cin);
+int dim_winograd3x3s2_use(int H, int W, int Cin, int Cout);   /* 1: the launch plan sends this layer (input map H x W) through this path */
 long dim_winograd3x3s2_workspace_floats(int N, int H, int W, int Cin, int Cout);
 int dim_winograd3x3s2_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream);
 int dim_conv2d_fwd_winograd3x3s2(const float* x, const float* w_packed, const float* bias, float* y, float* workspace, int N, int H, int W,

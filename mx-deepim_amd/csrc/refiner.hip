@@ -27,7 +27,7 @@ static const Layer kEncoder[10] = {{"flow_conv1", 64, 7, 2, 3}, {"conv2", 128, 5
 // (the launch plans come from dim_conv_auto_plan / dim_winograd_gemm_tile in conv.hip: one copy for this file and for FlowNetHip)
 
 struct LayerPlan {
-  int kind;  // 0 direct, 1 Winograd F(4x4,3x3), 2 phase-image Winograd (5x5 / stride 2)
+  int kind;  // 0 direct, 1 Winograd F(4x4,3x3), 2 phase-image Winograd (5x5 / stride 2), 3 phase-image minimal filtering (3x3 / stride 2)
   int h, w, cin, ho, wo;
   int tile, splits;
   float* w_packed;
@@ -126,6 +126,13 @@ int dim_refiner_create(dim_refiner** out, const dim_refiner_desc* desc, const ch
       TRY(dev_alloc(r, (void**)&P.w_packed, (size_t)dim_winograd5x5s2_packed_weight_floats(ly.cout, c) * 4));
       TRY(dim_winograd5x5s2_pack_weight(wsrc, P.w_packed, ly.cout, c, stream));
       max_ws = std::max(max_ws, dim_winograd5x5s2_workspace_floats(B, h, w, c, ly.cout));
+    } else if (ly.k == 3 && ly.s == 2 && ly.p == 1 && dim_winograd3x3s2_use(h, w, c, ly.cout)) {
+      P.kind = 3;
+      P.tile = dim_winograd_gemm_tile(ly.cout, (long)B * ((P.ho + 3) / 4) * ((P.wo + 3) / 4));
+      P.splits = 1;
+      TRY(dev_alloc(r, (void**)&P.w_packed, (size_t)dim_winograd3x3s2_packed_weight_floats(ly.cout, c) * 4));
+      TRY(dim_winograd3x3s2_pack_weight(wsrc, P.w_packed, ly.cout, c, stream));
+      max_ws = std::max(max_ws, dim_winograd3x3s2_workspace_floats(B, h, w, c, ly.cout));
     } else {
       P.kind = 0;
       const int nchunks = c == 8 ? (ly.k * ly.k + 3) / 4 : ly.k * ly.k * (c / 32);
@@ -217,6 +224,9 @@ int dim_refiner_run(dim_refiner* r, const float* image_observed, const float* im
                                     nullptr, stream));
       } else if (P.kind == 2) {
         TRY(dim_conv2d_fwd_winograd5x5s2(x, P.w_packed, P.bias, P.out, r->workspace, B, P.h, P.w, P.cin, P.cin, ly.cout, ly.cout, 0, 0.1f,
+                                         P.tile, nullptr, stream));
+      } else if (P.kind == 3) {
+        TRY(dim_conv2d_fwd_winograd3x3s2(x, P.w_packed, P.bias, P.out, r->workspace, B, P.h, P.w, P.cin, P.cin, ly.cout, ly.cout, 0, 0.1f,
                                          P.tile, nullptr, stream));
       } else {
         TRY(dim_conv2d_fwd(x, P.w_packed, P.bias, P.out, r->workspace, B, P.h, P.w, P.cin, ly.cout, ly.k, ly.k, ly.s, ly.p, 0.1f, P.splits,

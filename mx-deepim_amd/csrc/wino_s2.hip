@@ -228,6 +228,16 @@ extern "C" {
 
 long dim_winograd3x3s2_packed_weight_floats(int Cout, int Cin) { return (long)kPlanes * Cout * Cin; }
 
+// the one rule for every caller (FlowNetHip, dim_refiner_create): a 3x3 / stride-2 / pad-1 layer takes this path when its OUTPUT map has
+// at least 300 pixels -- conv4 (30 x 40: 0.36 vs 0.40 ms at 16 pairs) and conv5 (15 x 20: 0.20 vs 0.22), not conv6 (8 x 10: its 2 x 3 tiles
+// pad the map by 20 %, 96 GEMM rows fill one 128-row tile, and 170 MB of plane weights replace 19 MB: 0.13-0.15 vs 0.124 direct).
+// DIM_WINO_S2K3=0: never.
+int dim_winograd3x3s2_use(int H, int W, int Cin, int Cout) {
+  static const int on = [] { const char* e = getenv("DIM_WINO_S2K3"); return e ? atoi(e) : 1; }();
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  return on && Cin % 32 == 0 && Cout % 64 == 0 && Ho * Wo >= 300;
+}
+
 long dim_winograd3x3s2_workspace_floats(int N, int H, int W, int Cin, int Cout) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long per = (long)((Ho + 3) / 4) * ((Wo + 3) / 4);

@@ -119,7 +119,7 @@ class MutableModule(object):
     def _init_forward(self, cfg, B):
         net = self.net
         FlowNetHip.__init__(net, cfg, {n: self.w[n].cpu().numpy() for n in self.names}, B, device=str(self.device), winograd=True,
-                            bf16=self.bf16)
+                            bf16=self.bf16, wino_s2=False)   # training keeps conv4 / conv5 on the direct kernel (their packed form is re-made per update)
         net.params = self.w  # the executor reads biases / small weights straight from the master vector
         d = self.device
         H, W = 480, 640

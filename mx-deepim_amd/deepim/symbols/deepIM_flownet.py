@@ -180,10 +180,12 @@ class FlowNetHip(object):
     H, W = 480, 640
 
     def __init__(self, cfg, arg_params, batch_size, device="cuda:0", conv_plan=None, winograd=True, wino_m=None, wino_tile=None,
-                 bf16=False):
+                 bf16=False, wino_s2=True):
         """winograd: run the 3x3 / stride-1 layers (conv3_1, conv4_1, conv5_1, conv6_1) through Winograd F(4x4,3x3) / F(2x2,3x3)
         (same f32 result within 1e-4 relative, 4x / 2.25x fewer multiply-adds) and the 5x5 / stride-2 layers (conv2, conv3) through
         their four phase images and F(4x4,3x3) (2.78x fewer).  False = direct kernel for every layer.
+        wino_s2: with winograd, also the 3x3 / stride-2 layers whose output map has >= 300 pixels (conv4, conv5) through their phase
+        images and minimal filtering (81 plane GEMMs per 4 x 4 tile against 144 multiplies direct; csrc/wino_s2.hip).
         wino_m / wino_tile: optional {layer: output tile edge 2|4} / {layer: GEMM workgroup tile 3|4} overrides.
         bf16: the convolutions and the two large deconvolutions run on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, f32 accumulate;
         activations stay fp32 in HBM, weights are kept as bf16 copies of the packed arrays).  Direct form for every layer -- with the
@@ -221,8 +223,16 @@ class FlowNetHip(object):
         for name, cout, k, s, p in ENCODER:
             self.packed[name] = self.pack_conv(self.params[name + "_weight"])
         self.packed["fc6"] = ops.fc_pack_weight(self.params["fc6_weight"], 1024, 8, 10)
-        self.wino, self.wino_m, self.wino5 = {}, {}, {}
+        self.wino, self.wino_m, self.wino5, self.wino3s2 = {}, {}, {}, {}
         if winograd:
+            hh, ww, cc = self.H, self.W, 8
+            for name, cout, k, s, p in ENCODER:
+                # conv4, conv5: phase images + minimal filtering (81 plane GEMMs); the rule lives in C (dim_winograd3x3s2_use), shared with
+                # dim_refiner_create.  Inference only: the training executor keeps its forward on the direct kernel (wino_s2=False).
+                if wino_s2 and k == 3 and s == 2 and p == 1 and ops.lib().dim_winograd3x3s2_use(hh, ww, cc, cout):
+                    self.wino3s2[name] = ops.winograd3x3s2_pack_weight(self.params[name + "_weight"])
+                hh, ww = ops.conv_out_hw(hh, ww, k, k, s, p)
+                cc = cout
             for name, cout, k, s, p in ENCODER:
                 if k == 5 and s == 2 and p == 2:  # conv2, conv3: four phase images through F(4x4,3x3), 36 GEMMs with K = 4 Cin
                     self.wino5[name] = ops.winograd5x5s2_pack_weight(self.params[name + "_weight"])
@@ -293,6 +303,13 @@ class FlowNetHip(object):
                 wt = (wino_tile or {}).get(name, self._wino_tile(cout, tiles))
                 self.layer_info[name].update(self._wino_info(4, 2, wt, tiles, c, cout, B * h * w * c, B * ho * wo * cout))
                 max_ws = max(max_ws, ops.lib().dim_winograd5x5s2_workspace_floats(B, h, w, c, cout))
+            if name in self.wino3s2:
+                tiles = B * (-(-ho // 4)) * (-(-wo // 4))
+                wt = (wino_tile or {}).get(name, self._wino_tile(cout, tiles))
+                info = self._wino_info(4, 1, wt, tiles, c, cout, B * h * w * c, B * ho * wo * cout, planes=81)
+                info.update(wino_in_kernel="dim::wino_s2_input_kernel", wino_out_kernel="dim::wino_s2_output_kernel")
+                self.layer_info[name].update(info)
+                max_ws = max(max_ws, ops.lib().dim_winograd3x3s2_workspace_floats(B, h, w, c, cout))
             h, w, c = ho, wo, cout
         assert (h, w, c) == (8, 10, 1024)
         tile, splits = self.conv_plan["fc6"]
@@ -341,10 +358,10 @@ class FlowNetHip(object):
         return int(ops.lib().dim_winograd_gemm_tile(int(cout), int(tiles)))
 
     @staticmethod
-    def _wino_info(m, S, tile, tiles, cin, cout, x_floats, y_floats):
+    def _wino_info(m, S, tile, tiles, cin, cout, x_floats, y_floats, planes=None):
         """accounting of one Winograd layer for bench.py: the batched GEMM (planes x [tiles x K] . [K x cout]) and the algorithmic
         bytes of the two transform kernels (read x + write V; read M + write y)"""
-        planes, K = (m + 2) ** 2, cin * S * S
+        planes, K = planes or (m + 2) ** 2, cin * S * S
         return dict(winograd=True, wino_m=m, wino_tile=tile, wino_planes=planes, wino_rows=tiles, wino_k=K,
                     wino_flops=2 * planes * tiles * K * cout, wino_gemm_bytes=4 * planes * (tiles * K + K * cout + tiles * cout),
                     wino_in_bytes=4 * (x_floats + planes * tiles * K), wino_out_bytes=4 * (planes * tiles * cout + y_floats),
@@ -396,6 +413,11 @@ class FlowNetHip(object):
                 continue
             if name in self.wino5:
                 x = ops.conv2d_fwd_winograd5x5s2(x, x.shape[-1], self.wino5[name], self.params[name + "_bias"], cout, slope=0.1,
+                                                 tile=self.layer_info[name]["wino_tile"], out=self.acts[name], workspace=self.workspace,
+                                                 events=None if events is None else events.setdefault(name, []))
+                continue
+            if name in self.wino3s2:
+                x = ops.conv2d_fwd_winograd3x3s2(x, x.shape[-1], self.wino3s2[name], self.params[name + "_bias"], cout, slope=0.1,
                                                  tile=self.layer_info[name]["wino_tile"], out=self.acts[name], workspace=self.workspace,
                                                  events=None if events is None else events.setdefault(name, []))
                 continue

@@ -95,6 +95,7 @@ SIGNATURES = {
     "dim_winograd_pack_weight": (I, [P, P, I, I, I, P]),
     "dim_winograd_dgrad_pack_weight": (I, [P, P, I, I, I, P]),
     "dim_winograd3x3s2_packed_weight_floats": (L, [I, I]),
+    "dim_winograd3x3s2_use": (I, [I, I, I, I]),
     "dim_winograd3x3s2_workspace_floats": (L, [I, I, I, I, I]),
     "dim_winograd3x3s2_pack_weight": (I, [P, P, I, I, P]),
     "dim_conv2d_fwd_winograd3x3s2": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P, P]),
