@@ -439,6 +439,10 @@ int dim_pose_head_bwd(const float* fc6a, const float* fc7, const float* rot_raw,
                       const float* fc7_w, const float* rot_w, const float* trans_w, float* d_rot, float* dz7, float* dz6, int B,
                       void* stream);
 int dim_fc_wgrad(const float* dz, const float* x, float* dW, float* db, int B, int Out, int In, void* stream);
+/* fc6's weight gradient straight in the MXNet layout: dW (Out, C*H*W flattened (c, h, w)) = dz (B, Out)^T . x (B, H, W, C NHWC), for batches
+ * of 1 .. 32 rows, C % 16 == 0, H * W <= 80 (fc6: 8 x 10 x 1024 -> 256).  f32 products, summed over the batch in row order.  Replaces
+ * dim_conv2d_wgrad(KH = H, KW = W) + dim_fc_unpack_weight: one 84 MB write instead of a packed intermediate and its conversion. */
+int dim_fc_wgrad_nhwc(const float* dz, const float* x, float* dW, int B, int Out, int C, int H, int W, void* stream);
 int dim_upsample16_bwd(const float* dout_nchw, const float* w_c1_32_32, float* df_nhwc, int N, int C, int h, int w, int OH, int OW, int crop,
                        float scale, void* stream);
 long dim_conv_small_cout_bwd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW);

@@ -224,6 +224,52 @@ __global__ void fc_wgrad_kernel(const float* __restrict__ A, const float* __rest
   if (i == 0 && db) db[o] = sb;
 }
 
+// fc6's weight gradient straight in the MXNet layout: dW[o][c HW + q] = sum_b dz[b][o] x[b][q][c]   (x NHWC: B x HW pixels x C channels;
+// MXNet flattens (c, h, w)).  B is the batch: 16 terms -- there is nothing for a matrix pipe to do, the job is writing 84 MB once.  The
+// general path computed it as an 8 x 10 "convolution" into the packed layout (17.6 us) and converted that (58.8 us at 16 pairs).
+// Workgroup = CB channels x 64 outputs: the x block sits in LDS transposed to [b][c][q] (q fastest, as the gradient rows want it), a
+// thread keeps its CB HW / 256 columns' batch values in registers and walks the outputs; every store is a run of the row.
+template <int CB, int BMAX>
+__global__ __launch_bounds__(256) void fc_wgrad_nhwc_kernel(const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ dW,
+                                                           int B, int Out, int C, int HW) {
+  extern __shared__ float smem[];
+  const int J = CB * HW;                 // contiguous gradient columns of one output row in this block
+  float* xs = smem;                      // [BMAX][J]
+  float* dzs = smem + BMAX * J;          // [BMAX][64]
+  const int c0 = blockIdx.x * CB, o0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < BMAX * J; i += 256) {   // global reads: CB contiguous channels of pixel (b, q)
+    const int c = i % CB, q = (i / CB) % HW, b = i / (CB * HW);
+    xs[b * J + c * HW + q] = b < B ? x[((long)b * HW + q) * C + c0 + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < BMAX * 64; i += 256) {
+    const int o = i & 63, b = i >> 6;
+    dzs[i] = (b < B && o0 + o < Out) ? dz[(long)b * Out + o0 + o] : 0.f;
+  }
+  __syncthreads();
+  constexpr int NJ = 5;                  // columns per thread: CB * HW <= 1280
+  float xv[NJ][BMAX];
+#pragma unroll
+  for (int k = 0; k < NJ; ++k) {
+    const int j = threadIdx.x + 256 * k;
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) xv[k][b] = j < J ? xs[b * J + j] : 0.f;
+  }
+  for (int o = 0; o < 64 && o0 + o < Out; ++o) {
+    float a[BMAX];
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) a[b] = dzs[b * 64 + o];   // broadcast reads
+    float* row = dW + (long)(o0 + o) * C * HW + (long)c0 * HW;
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+      const int j = threadIdx.x + 256 * k;
+      float sacc = 0.f;
+#pragma unroll
+      for (int b = 0; b < BMAX; ++b) sacc = fmaf(a[b], xv[k][b], sacc);
+      if (j < J) row[j] = sacc;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- head backward pieces
 // backward of Deconvolution(k=32, s=16, group=C) + Crop(crop): dF[n,iy,ix,c] = sum_{ky,kx} dOut[n,c,16iy+ky-crop,16ix+kx-crop] wk[c,ky,kx]
 // one wave per output element
@@ -680,6 +726,39 @@ int dim_fc_wgrad(const float* dz, const float* x, float* dW, float* db, int B, i
   DIM_REQUIRE(dz && x && dW, "null pointer");
   hipLaunchKernelGGL(fc_wgrad_kernel, dim3(ceil_div((long)Out * In, 256)), dim3(256), 0, as_stream(stream), dz, x, dW, db, B, Out, In);
   return check_launch("fc_wgrad");
+}
+
+// dW (Out, C*H*W in MXNet's (c, h, w) order) = dz (B, Out)^T . x (B, H, W, C NHWC), batches of up to 32 (see fc_wgrad_nhwc_kernel)
+int dim_fc_wgrad_nhwc(const float* dz, const float* x, float* dW, int B, int Out, int C, int H, int W, void* stream) {
+  DIM_REQUIRE(dz && x && dW, "null pointer");
+  const int HW = H * W;
+  DIM_REQUIRE(B >= 1 && B <= 32, "batch %d: this entry is built for 1 .. 32 rows (use dim_conv2d_wgrad + dim_fc_unpack_weight beyond)", B);
+  DIM_REQUIRE(C % 16 == 0 && HW <= 80 && HW >= 1, "C %% 16 == 0 and H * W <= 80 required");
+  hipStream_t st = as_stream(stream);
+  if (B <= 16) {
+    constexpr int CB = 16, BM = 16;
+    const size_t lds = (size_t)(BM * CB * HW + BM * 64) * 4;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_wgrad_nhwc_kernel<CB, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)((size_t)(BM * CB * 80 + BM * 64) * 4));
+      if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+      attr = true;
+    }
+    hipLaunchKernelGGL((fc_wgrad_nhwc_kernel<CB, BM>), dim3(C / CB, ceil_div(Out, 64)), dim3(256), lds, st, dz, x, dW, B, Out, C, HW);
+  } else {
+    constexpr int CB = 8, BM = 32;
+    const size_t lds = (size_t)(BM * CB * HW + BM * 64) * 4;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_wgrad_nhwc_kernel<CB, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)((size_t)(BM * CB * 80 + BM * 64) * 4));
+      if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+      attr = true;
+    }
+    hipLaunchKernelGGL((fc_wgrad_nhwc_kernel<CB, BM>), dim3(C / CB, ceil_div(Out, 64)), dim3(256), lds, st, dz, x, dW, B, Out, C, HW);
+  }
+  return check_launch("fc_wgrad_nhwc");
 }
 
 int dim_upsample16_bwd(const float* dout_nchw, const float* w_c1_32_32, float* df_nhwc, int N, int C, int h, int w, int OH, int OW, int crop,

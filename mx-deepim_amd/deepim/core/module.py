@@ -360,8 +360,11 @@ class MutableModule(object):
         ops.fc_wgrad(d_t, net.fc7, g["trans_weight"], g["trans_bias"])
         ops.fc_wgrad(self.dz7, fc6a, g["fc7_weight"], g["fc7_bias"])
         dz6 = self.dz6.view(B, 1, 1, 256)
-        ops.conv2d_wgrad(net.acts["conv6_1"], 1024, dz6, 256, 8, 10, 1, 0, self.gpack, bf16_mfma=self.bf16)
-        ops.fc_unpack_weight(self.gpack, g["fc6_weight"], 1024, 8, 10)
+        if B <= 32:   # 16 products per element: one 84 MB write in the MXNet layout (f32) instead of the packed "convolution" + conversion
+            ops.fc_wgrad_nhwc(self.dz6, net.acts["conv6_1"], g["fc6_weight"])
+        else:
+            ops.conv2d_wgrad(net.acts["conv6_1"], 1024, dz6, 256, 8, 10, 1, 0, self.gpack, bf16_mfma=self.bf16)
+            ops.fc_unpack_weight(self.gpack, g["fc6_weight"], 1024, 8, 10)
         self._bucket_ready("fc6_weight")
         ops.bias_grad(dz6, 256, g["fc6_bias"], workspace=self.bias_ws)
         # d(ReLU10) += dz6 * W6  (fc6 dgrad as a 1x1 convolution to 81920 "channels" = the NHWC feature map)

@@ -83,6 +83,7 @@ SIGNATURES = {
     "dim_quat_normalize": (I, [P, P, I, P]),
     "dim_pose_head_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, P]),
     "dim_fc_wgrad": (I, [P, P, P, P, I, I, I, P]),
+    "dim_fc_wgrad_nhwc": (I, [P, P, P, I, I, I, I, I, P]),
     "dim_upsample16_bwd": (I, [P, P, P, I, I, I, I, I, I, I, F, P]),
     "dim_conv_small_cout_bwd_workspace_floats": (L, [I, I, I, I, I, I, I]),
     "dim_conv_small_cout_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),

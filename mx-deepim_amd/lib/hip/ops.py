@@ -739,6 +739,15 @@ def fc_unpack_weight(w_packed, out_w, C, H, W):
     return out_w
 
 
+def fc_wgrad_nhwc(dz, x_nhwc, dW):
+    """dW (Out, C*H*W in MXNet's (c, h, w) order) = dz (B, Out)^T . x (B, H, W, C); B <= 32 (dim_fc_wgrad_nhwc)"""
+    B, H, W, C = x_nhwc.shape
+    Out = dW.shape[0]
+    assert x_nhwc.is_contiguous() and dW.is_contiguous() and dW.numel() == Out * C * H * W and dz.numel() == B * Out
+    check(lib().dim_fc_wgrad_nhwc(dptr(dz, f32), dptr(x_nhwc, f32), dptr(dW, f32), B, Out, C, H, W, current_stream()))
+    return dW
+
+
 def fc_dgrad_pack_weight(w_out_in, C, H, W, out=None, as_bf16=False):
     Out = w_out_in.shape[0]
     out = out if out is not None else _new_packed(Out * C * H * W, w_out_in, as_bf16)

@@ -775,3 +775,19 @@ def test_conv_winograd3x3s2_vs_f64(hip_lib, shape, monkeypatch):
         monkeypatch.setenv("DIM_WINO_MAX_SLICE", "2")
         y2 = ops.conv2d_fwd_winograd3x3s2(xd, Cin, wp, None, Cout, slope=1.0, tile=tile)
         assert torch.equal(y2, y0)
+
+
+@pytest.mark.parametrize("shape", [(16, 256, 1024, 8, 10), (1, 256, 1024, 8, 10), (17, 256, 1024, 8, 10), (32, 70, 32, 3, 5), (3, 64, 48, 1, 1)])
+def test_fc_wgrad_in_mxnet_layout_vs_f64(hip_lib, shape):
+    """fc6's weight gradient written straight in MXNet's (out, c*h*w) layout from the NHWC activation (dim_fc_wgrad_nhwc) vs float64;
+    batches on both sides of 16 (two kernel shapes), an output count that is not a multiple of 64, a 1 x 1 map"""
+    from lib.hip import ops
+
+    B, Out, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn((B, C, H, W), generator=g)
+    dz = torch.randn((B, Out), generator=g)
+    ref = dz.double().t() @ x.double().reshape(B, -1)
+    dW = torch.full((Out, C * H * W), 3.0, device="cuda:0")
+    ops.fc_wgrad_nhwc(dz.to("cuda:0"), x.permute(0, 2, 3, 1).contiguous().to("cuda:0"), dW)
+    assert (dW.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6
