@@ -229,43 +229,60 @@ __global__ void fc_wgrad_kernel(const float* __restrict__ A, const float* __rest
 // general path computed it as an 8 x 10 "convolution" into the packed layout (17.6 us) and converted that (58.8 us at 16 pairs).
 // Workgroup = CB channels x 64 outputs: the x block sits in LDS transposed to [b][c][q] (q fastest, as the gradient rows want it), a
 // thread keeps its CB HW / 256 columns' batch values in registers and walks the outputs; every store is a run of the row.
-template <int CB, int BMAX>
+template <int CB, int BMAX, int OB, int VEC>
 __global__ __launch_bounds__(256) void fc_wgrad_nhwc_kernel(const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ dW,
                                                            int B, int Out, int C, int HW) {
-  extern __shared__ float smem[];
+  typedef float vf __attribute__((ext_vector_type(VEC)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int J = CB * HW;                 // contiguous gradient columns of one output row in this block
   float* xs = smem;                      // [BMAX][J]
-  float* dzs = smem + BMAX * J;          // [BMAX][64]
-  const int c0 = blockIdx.x * CB, o0 = blockIdx.y * 64;
-  for (int i = threadIdx.x; i < BMAX * J; i += 256) {   // global reads: CB contiguous channels of pixel (b, q)
-    const int c = i % CB, q = (i / CB) % HW, b = i / (CB * HW);
-    xs[b * J + c * HW + q] = b < B ? x[((long)b * HW + q) * C + c0 + c] : 0.f;
+  float* dzs = smem + BMAX * J;          // [BMAX][OB]
+  const int c0 = blockIdx.x * CB, o0 = blockIdx.y * OB;
+  // global reads: CB contiguous channels of pixel (b, q); eight loads in flight per thread (one at a time: 40 L2 round trips in series
+  // made the whole kernel 55-62 us whatever the store width)
+  for (int i0 = threadIdx.x; i0 < BMAX * J; i0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + 256 * e;
+      const int c = i % CB, q = (i / CB) % HW, b = i / (CB * HW);
+      v[e] = (i < BMAX * J && b < B) ? x[((long)b * HW + q) * C + c0 + c] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + 256 * e;
+      const int c = i % CB, q = (i / CB) % HW, b = i / (CB * HW);
+      if (i < BMAX * J) xs[b * J + c * HW + q] = v[e];
+    }
   }
-  for (int i = threadIdx.x; i < BMAX * 64; i += 256) {
-    const int o = i & 63, b = i >> 6;
+  for (int i = threadIdx.x; i < BMAX * OB; i += 256) {
+    const int o = i % OB, b = i / OB;
     dzs[i] = (b < B && o0 + o < Out) ? dz[(long)b * Out + o0 + o] : 0.f;
   }
   __syncthreads();
-  constexpr int NJ = 5;                  // columns per thread: CB * HW <= 1280
-  float xv[NJ][BMAX];
+  constexpr int NJ = (CB * 80 / VEC + 255) / 256;   // column groups per thread (HW <= 80)
+  const int JV = J / VEC;
+  vf xv[NJ][BMAX];
 #pragma unroll
   for (int k = 0; k < NJ; ++k) {
     const int j = threadIdx.x + 256 * k;
 #pragma unroll
-    for (int b = 0; b < BMAX; ++b) xv[k][b] = j < J ? xs[b * J + j] : 0.f;
+    for (int b = 0; b < BMAX; ++b) xv[k][b] = j < JV ? *reinterpret_cast<const vf*>(xs + b * J + j * VEC) : (vf)(0.f);
   }
-  for (int o = 0; o < 64 && o0 + o < Out; ++o) {
+#pragma unroll 2
+  for (int o = 0; o < OB; ++o) {
+    if (o0 + o >= Out) break;
     float a[BMAX];
 #pragma unroll
-    for (int b = 0; b < BMAX; ++b) a[b] = dzs[b * 64 + o];   // broadcast reads
+    for (int b = 0; b < BMAX; ++b) a[b] = dzs[b * OB + o];   // broadcast reads
     float* row = dW + (long)(o0 + o) * C * HW + (long)c0 * HW;
 #pragma unroll
     for (int k = 0; k < NJ; ++k) {
       const int j = threadIdx.x + 256 * k;
-      float sacc = 0.f;
+      vf sacc = (vf)(0.f);
 #pragma unroll
-      for (int b = 0; b < BMAX; ++b) sacc = fmaf(a[b], xv[k][b], sacc);
-      if (j < J) row[j] = sacc;
+      for (int b = 0; b < BMAX; ++b) sacc += a[b] * xv[k][b];
+      if (j < JV) *reinterpret_cast<vf*>(row + j * VEC) = sacc;
     }
   }
 }
@@ -733,31 +750,28 @@ int dim_fc_wgrad_nhwc(const float* dz, const float* x, float* dW, int B, int Out
   DIM_REQUIRE(dz && x && dW, "null pointer");
   const int HW = H * W;
   DIM_REQUIRE(B >= 1 && B <= 32, "batch %d: this entry is built for 1 .. 32 rows (use dim_conv2d_wgrad + dim_fc_unpack_weight beyond)", B);
-  DIM_REQUIRE(C % 16 == 0 && HW <= 80 && HW >= 1, "C %% 16 == 0 and H * W <= 80 required");
+  DIM_REQUIRE(C % 8 == 0 && HW <= 80 && HW >= 1, "C %% 8 == 0 and H * W <= 80 required");
   hipStream_t st = as_stream(stream);
-  if (B <= 16) {
-    constexpr int CB = 16, BM = 16;
-    const size_t lds = (size_t)(BM * CB * HW + BM * 64) * 4;
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_wgrad_nhwc_kernel<CB, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)((size_t)(BM * CB * 80 + BM * 64) * 4));
-      if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
-      attr = true;
-    }
-    hipLaunchKernelGGL((fc_wgrad_nhwc_kernel<CB, BM>), dim3(C / CB, ceil_div(Out, 64)), dim3(256), lds, st, dz, x, dW, B, Out, C, HW);
-  } else {
-    constexpr int CB = 8, BM = 32;
-    const size_t lds = (size_t)(BM * CB * HW + BM * 64) * 4;
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_wgrad_nhwc_kernel<CB, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)((size_t)(BM * CB * 80 + BM * 64) * 4));
-      if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
-      attr = true;
-    }
-    hipLaunchKernelGGL((fc_wgrad_nhwc_kernel<CB, BM>), dim3(C / CB, ceil_div(Out, 64)), dim3(256), lds, st, dz, x, dW, B, Out, C, HW);
+#define DIM_FC_WGRAD(CBc, BMc, OBc, VECc)                                                                                               \
+  {                                                                                                                                     \
+    const size_t lds = (size_t)(BMc * CBc * HW + BMc * OBc) * 4;                                                                        \
+    static bool attr = false;                                                                                                           \
+    if (!attr) {                                                                                                                        \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_wgrad_nhwc_kernel<CBc, BMc, OBc, VECc>),                     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)(BMc * CBc * 80 + BMc * OBc) * 4));  \
+      if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));                        \
+      attr = true;                                                                                                                      \
+    }                                                                                                                                   \
+    hipLaunchKernelGGL((fc_wgrad_nhwc_kernel<CBc, BMc, OBc, VECc>), dim3(C / CBc, ceil_div(Out, OBc)), dim3(256), lds, st, dz, x, dW, B, \
+                       Out, C, HW);                                                                                                     \
   }
+  // 8 channels x 32 outputs per workgroup (43 KB of LDS: three workgroups per CU, 1024 workgroups for fc6); 16-byte stores when the
+  // map size allows.  History at fc6, 16 pairs: 16 channels x 64 outputs (86 KB, one workgroup per CU) 58 us; 8 x 32 with 4-byte
+  // stores 55 us; the packed "convolution" + conversion it replaces: 86 us
+  const bool v4 = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(dW) & 15) == 0;
+  if (B <= 16) { if (v4) DIM_FC_WGRAD(8, 16, 64, 4) else DIM_FC_WGRAD(8, 16, 32, 1) }
+  else { if (v4) DIM_FC_WGRAD(8, 32, 32, 4) else DIM_FC_WGRAD(8, 32, 32, 1) }
+#undef DIM_FC_WGRAD
   return check_launch("fc_wgrad_nhwc");
 }
 
