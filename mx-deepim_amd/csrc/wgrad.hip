@@ -361,15 +361,19 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
   __syncthreads();
   // two steps per trip so that the register sets keep their names: LDS buffer 0 holds step st, set A step st + 1
   for (int st = step_begin; st < step_end; st += 2) {
+    // LDS-only barriers (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() also waits for vmcnt(0), i.e. for the loads of step st + 2
+    // issued a few lines above, so every barrier drained the prefetch the second staging set exists for.  Measured after the change:
+    // 6.17 vs 6.17 ms per iteration -- the kernel is bound by the bytes it moves through the vector memory path, not by their latency
+    // (DESIGN.md section 3c); kept because it is what the code means.  The compiler waits for a set's loads where store_step reads them.
     if (!(dbg & 16)) load_step(rzB, rxB, min(st + 2, last), st + 2 < step_end);
     compute(0);
     if (!(dbg & 1)) store_step(rzA, rxA, 1);
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (st + 1 >= step_end) break;
     if (!(dbg & 16)) load_step(rzA, rxA, min(st + 3, last), st + 3 < step_end);
     compute(1);
     if (!(dbg & 1)) store_step(rzB, rxB, 0);
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   // D: col = lane&31 -> kin, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co within the tile's 32
   const int fi = lane & 31, fh = lane >> 5;
