@@ -14,6 +14,7 @@
 #include "common.h"
 
 namespace dim {
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -33,7 +34,8 @@ struct WgradArgs {
   int bf16;  // products on v_mfma_f32_32x32x16_bf16 (conv_wgrad_bf16_kernel); the result is f32 in the same packed layout
   int xcd;   // number the workgroups XCD-contiguously (wgrad_block below)
   int dbg;   // timing-only ablation switches of the bf16 kernel (DIM_WGB_DBG; results are wrong when set): 1 no LDS stores after the
-             // first step, 8 no MFMAs, 16 no global loads after the prologue
+             // first step, 8 no MFMAs, 16 no global loads after the prologue, 32 8-byte instead of 16-byte operand loads (the bytes bf16
+             // operands in HBM would move: DESIGN.md section 6b)
 };
 
 // (chunk tile, output-channel tile, pixel split) of this workgroup.  The hardware deals linear block ids round-robin to the 8 XCDs, so
@@ -277,7 +279,12 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = p0 + zr0 + ZR_STEP * i;
-      rz[i] = buf_load16(rsz, (pf && m < a.M) ? m * (a.dz_cstride * 4) + z_voff : -1, 0);
+      if (a.dbg & 32) {  // timing only: half the bytes per load (what bf16 operands in HBM would move)
+        const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rsz, (pf && m < a.M) ? m * (a.dz_cstride * 4) + z_voff : -1, 0, 0);
+        rz[i] = make_float4(__uint_as_float(h.x), __uint_as_float(h.y), 0.f, 0.f);
+      } else {
+        rz[i] = buf_load16(rsz, (pf && m < a.M) ? m * (a.dz_cstride * 4) + z_voff : -1, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
@@ -291,7 +298,12 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const bool ok = okm && cok[c] && (unsigned)(hb + kh[c]) < (unsigned)a.H && (unsigned)(wb + kw[c]) < (unsigned)a.W;
-        rx[i][c] = buf_load16(rsx, ok ? pix + tapb[c] : -1, 0);
+        if (a.dbg & 32) {
+          const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rsx, ok ? pix + tapb[c] : -1, 0, 0);
+          rx[i][c] = make_float4(__uint_as_float(h.x), __uint_as_float(h.y), 0.f, 0.f);
+        } else {
+          rx[i][c] = buf_load16(rsx, ok ? pix + tapb[c] : -1, 0);
+        }
       }
     }
   };
