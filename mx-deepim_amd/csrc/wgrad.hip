@@ -34,8 +34,8 @@ struct WgradArgs {
   int bf16;  // products on v_mfma_f32_32x32x16_bf16 (conv_wgrad_bf16_kernel); the result is f32 in the same packed layout
   int xcd;   // number the workgroups XCD-contiguously (wgrad_block below)
   int dbg;   // timing-only ablation switches of the bf16 kernel (DIM_WGB_DBG; results are wrong when set): 1 no LDS stores after the
-             // first step, 8 no MFMAs, 16 no global loads after the prologue, 32 8-byte instead of 16-byte operand loads (the bytes bf16
-             // operands in HBM would move: DESIGN.md section 6b)
+             // first step, 8 no MFMAs, 16 no global loads after the prologue, 32 8-byte instead of 16-byte operand loads, 64 half as many 16-byte
+             // loads (two ways of moving the bytes bf16 operands in HBM would move; compile-time twins: DESIGN.md section 6b)
 };
 
 // (chunk tile, output-channel tile, pixel split) of this workgroup.  The hardware deals linear block ids round-robin to the 8 XCDs, so
@@ -225,7 +225,7 @@ __device__ __forceinline__ wbf16x4 wg_to_bf16x4(const float4& v) {
 // + ~35 LDS reads, + ~25 stores, + ~80 global loads on conv3_1), so the co-resident workgroups are what hides them: the launcher's
 // callers size the pixel split so that the whole grid is resident at once, and the global loads run TWO steps ahead (two register
 // sets: the registers are there, occupancy is LDS-bound).
-template <int NW, bool CIN8, int NCH>
+template <int NW, bool CIN8, int NCH, int HALF = 0>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
   constexpr int BP = 32;              // pixels per step = two k-steps of the instruction
   constexpr int BM = 32 * NW;         // output channels per workgroup
@@ -279,7 +279,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = p0 + zr0 + ZR_STEP * i;
-      if (a.dbg & 32) {  // timing only: half the bytes per load (what bf16 operands in HBM would move)
+      if constexpr (HALF == 2) {  // timing only: half as many 16-byte loads (bf16 operands in HBM fetched 8 elements at a time)
+        rz[i] = (i & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : buf_load16(rsz, (pf && m < a.M) ? m * (a.dz_cstride * 4) + z_voff : -1, 0);
+      } else if constexpr (HALF == 1) {  // timing only: half the bytes per load, as many loads
         const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rsz, (pf && m < a.M) ? m * (a.dz_cstride * 4) + z_voff : -1, 0, 0);
         rz[i] = make_float4(__uint_as_float(h.x), __uint_as_float(h.y), 0.f, 0.f);
       } else {
@@ -298,7 +300,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const bool ok = okm && cok[c] && (unsigned)(hb + kh[c]) < (unsigned)a.H && (unsigned)(wb + kw[c]) < (unsigned)a.W;
-        if (a.dbg & 32) {
+        if constexpr (HALF == 2) {
+          rx[i][c] = (c & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : buf_load16(rsx, ok ? pix + tapb[c] : -1, 0);
+        } else if constexpr (HALF == 1) {
           const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rsx, ok ? pix + tapb[c] : -1, 0, 0);
           rx[i][c] = make_float4(__uint_as_float(h.x), __uint_as_float(h.y), 0.f, 0.f);
         } else {
@@ -824,7 +828,15 @@ int wgrad_launch(WgradArgs& a, float* dw_packed, float* workspace, int splits, i
   if (a.bf16) {
     const int nch = a.nchunks >= 4 ? 4 : a.nchunks >= 2 ? 2 : 1;  // chunks (x 32 packed columns) per workgroup sharing one dZ tile
     dim3 gridb(ceil_div(a.nchunks, nch), Cout / (nw4 ? 128 : 64), splits);
-#define DIM_WGB_LAUNCH(NW, C8, NCH) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<NW, C8, NCH>), gridb, dim3(64 * NW), 0, st, a)
+#define DIM_WGB_LAUNCH(NW, C8, NCH)                                                                              \
+  do {                                                                                                           \
+    if ((a.dbg & 32) && NW == 4 && !C8 && NCH == 4)   /* timing-only twin with 8-byte operand loads */           \
+      hipLaunchKernelGGL((conv_wgrad_bf16_kernel<4, false, 4, 1>), gridb, dim3(256), 0, st, a);                  \
+    else if ((a.dbg & 64) && NW == 4 && !C8 && NCH == 4)   /* ... with half as many 16-byte loads */             \
+      hipLaunchKernelGGL((conv_wgrad_bf16_kernel<4, false, 4, 2>), gridb, dim3(256), 0, st, a);                  \
+    else                                                                                                         \
+      hipLaunchKernelGGL((conv_wgrad_bf16_kernel<NW, C8, NCH>), gridb, dim3(64 * NW), 0, st, a);                 \
+  } while (0)
 #define DIM_WGB_NCH(NW, C8) { if (nch == 4) DIM_WGB_LAUNCH(NW, C8, 4); else if (nch == 2) DIM_WGB_LAUNCH(NW, C8, 2); else DIM_WGB_LAUNCH(NW, C8, 1); }
     if (Cin == 8) { if (nw4) DIM_WGB_NCH(4, true) else DIM_WGB_NCH(2, true) }
     else { if (nw4) DIM_WGB_NCH(4, false) else DIM_WGB_NCH(2, false) }
