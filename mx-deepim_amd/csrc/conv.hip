@@ -1517,6 +1517,43 @@ __global__ __launch_bounds__(256) void upsample16_kernel(const float* __restrict
   y[(((long)n * C + c) * OH + oy) * OW + ox] = acc;
 }
 
+// the same for four adjacent output pixels per thread (crop % 4 == 0, OW % 4 == 0, 16-byte aligned rows): they share their 2 x 2 input
+// pixels, the kernel taps are one float4 per (ky, b), the store is one float4.  One output per thread: 32 + 19 us for the two heads at
+// 16 x 480 x 640 (1.2 / 1.0 TB/s of output).
+__global__ __launch_bounds__(256) void upsample16_x4_kernel(const float* __restrict__ x, const float* __restrict__ wk, float* __restrict__ y,
+                                                            int C, int h, int w, int OH, int OW, int crop, float scale, int mode) {
+  const int n = blockIdx.z / C, c = blockIdx.z % C;
+  const int oy = blockIdx.y;
+  const int ox = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (ox >= OW) return;
+  const int fy = oy + crop, fx = ox + crop;   // fx % 4 == 0: fx .. fx + 3 share their 16-block
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int iy = (fy >> 4) - a;
+    const int ky = fy - 16 * iy;  // in [0,32)
+    if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ix = (fx >> 4) - b;
+      const int kx = fx - 16 * ix;   // multiple of 4
+      if ((unsigned)ix >= (unsigned)w) continue;
+      const float xv = x[((long)(n * h + iy) * w + ix) * C + c];
+      const float4 k4 = *reinterpret_cast<const float4*>(wk + ((long)c * 32 + ky) * 32 + kx);
+      acc.x = fmaf(xv, k4.x, acc.x);
+      acc.y = fmaf(xv, k4.y, acc.y);
+      acc.z = fmaf(xv, k4.z, acc.z);
+      acc.w = fmaf(xv, k4.w, acc.w);
+    }
+  }
+  acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+  if (mode == 1) {
+    acc.x = 1.f / (1.f + expf(-acc.x)); acc.y = 1.f / (1.f + expf(-acc.y));
+    acc.z = 1.f / (1.f + expf(-acc.z)); acc.w = 1.f / (1.f + expf(-acc.w));
+  }
+  *reinterpret_cast<float4*>(y + (((long)n * C + c) * OH + oy) * OW + ox) = acc;
+}
+
 // Pose head: fc7 + LeakyReLU + rot (4) + trans (3) + inverse ZoomTrans -> se3 (B,7).
 // deepIM_flownet.py:203-208, :956-971; zoom_trans.py:37-41 (b_inv_zoom: dx*wx, dy*wx).
 __global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict__ fc6, const float* __restrict__ w7,
@@ -2443,8 +2480,12 @@ int dim_upsample16_fwd(const float* x_nhwc, const float* w_c1_32_32, float* y_nc
   DIM_REQUIRE(x_nhwc && w_c1_32_32 && y_nchw, "null pointer");
   DIM_REQUIRE(mode == 0 || mode == 1, "mode 0 (linear) or 1 (sigmoid)");
   DIM_REQUIRE(OH + crop <= 16 * h + 16 && OW + crop <= 16 * w + 16, "crop window outside the deconvolution output");
-  hipLaunchKernelGGL(upsample16_kernel, dim3(ceil_div(OW, 256), OH, N * C), dim3(256), 0, as_stream(stream), x_nhwc, w_c1_32_32,
-                     y_nchw, C, h, w, OH, OW, crop, scale, mode);
+  if (crop % 4 == 0 && OW % 4 == 0 && (reinterpret_cast<uintptr_t>(y_nchw) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_c1_32_32) & 15) == 0)
+    hipLaunchKernelGGL(upsample16_x4_kernel, dim3(ceil_div(OW / 4, 256), OH, N * C), dim3(256), 0, as_stream(stream), x_nhwc, w_c1_32_32,
+                       y_nchw, C, h, w, OH, OW, crop, scale, mode);
+  else
+    hipLaunchKernelGGL(upsample16_kernel, dim3(ceil_div(OW, 256), OH, N * C), dim3(256), 0, as_stream(stream), x_nhwc, w_c1_32_32,
+                       y_nchw, C, h, w, OH, OW, crop, scale, mode);
   return check_launch("upsample16");
 }
 

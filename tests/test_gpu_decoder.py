@@ -67,8 +67,12 @@ def test_deconv_tiny_and_small_cout_and_upsample16(ops):
     f = torch.randn((2, 2, 30, 40), generator=g)
     wk = torch.from_numpy(oflow.bilinear_kernel((2, 1, 32, 32)))
     ref_up = F.conv_transpose2d(f, wk, None, stride=16, groups=2)[:, :, 8:488, 8:648] * 20.0
-    got = ops.upsample16_fwd(nhwc(f), wk.to(DEV), 480, 640, crop=8, scale=20.0)
+    got = ops.upsample16_fwd(nhwc(f), wk.to(DEV), 480, 640, crop=8, scale=20.0)     # four output pixels per thread
     np.testing.assert_allclose(got.cpu().numpy(), ref_up.numpy(), atol=2e-5, rtol=1e-5)
+    ref_odd = F.conv_transpose2d(f, wk, None, stride=16, groups=2)[:, :, 6:477, 6:637] * 20.0   # crop 6, 471 x 631: one pixel per thread
+    got_odd = ops.upsample16_fwd(nhwc(f), wk.to(DEV), 471, 631, crop=6, scale=20.0)
+    np.testing.assert_allclose(got_odd.cpu().numpy(), ref_odd.numpy(), atol=2e-5, rtol=1e-5)
+    assert torch.equal(got[:, :, :400, :600], ops.upsample16_fwd(nhwc(f), wk.to(DEV), 400, 600, crop=8, scale=20.0))
     m = torch.randn((2, 1, 30, 40), generator=g)
     wk1 = torch.from_numpy(oflow.bilinear_kernel((1, 1, 32, 32)))
     ref_m = torch.sigmoid(F.conv_transpose2d(m, wk1, None, stride=16)[:, :, 8:488, 8:648])
