@@ -341,3 +341,22 @@ def test_weight_packers_tiled_and_bf16(ops):
     back = torch.empty_like(wf)
     ops.fc_unpack_weight(ops.fc_pack_weight(wf, 64, 3, 5), back, 64, 3, 5)
     assert torch.equal(back, wf)
+
+
+def test_first_layer_bf16_linear_no_bias_and_padded_wgrad_rows(ops):
+    """two API corners the executor relies on or documents: (i) the persistent first-layer kernel with slope 1 and no bias (the 10-channel
+    input variant adds the mask group's convolution before the activation); (ii) dim_conv2d_wgrad_oihw delivering only the first
+    Cout_rows rows of a channel-padded gradient"""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((2, 8, 50, 70), generator=g)
+    w = torch.randn((64, 8, 7, 7), generator=g) / np.sqrt(8 * 49)
+    ref = F.conv2d(r16(x), r16(w), None, stride=2, padding=3).permute(0, 2, 3, 1).numpy()
+    wp = ops.to_bf16(ops.conv2d_pack_weight(w.to(DEV)))
+    y = ops.conv2d_fwd(nhwc(x), wp, None, 64, 7, 7, 2, 3, slope=1.0, splits=1, tile=6).cpu().numpy()
+    assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max() + 2e-5
+    xx = torch.randn((2, 64, 12, 14), generator=g, dtype=torch.float64)
+    dy = torch.randn((2, 128, 12, 14), generator=g, dtype=torch.float64)
+    full = torch.nn.grad.conv2d_weight(r16(xx), (128, 64, 3, 3), r16(dy), stride=1, padding=1)
+    part = torch.full((100, 64, 3, 3), 4.0, device=DEV)
+    ops.conv2d_wgrad_oihw(nhwc(xx.float()), 64, nhwc(dy.float()), 128, 3, 3, 1, 1, part, splits=2, bf16_mfma=True)
+    assert (part.cpu().double() - full[:100]).abs().max().item() <= 1e-4 * full.abs().max().item() + 1e-5
