@@ -111,3 +111,19 @@ def test_full_graph_not_fast_test_vs_oracle(hip_lib):
     assert mism <= 200, mism  # pixels whose probability sits within float noise of 0.2, or factor last-bit shifts
     fl, rfl = out["flow_est_crop_output"].cpu().numpy(), ref["flow_est_crop"]
     np.testing.assert_allclose(fl, rfl, atol=1e-3 * max(1.0, np.abs(rfl).max()))
+
+
+def test_upsample16_backward_vs_autograd(ops):
+    """backward of the frozen x16 bilinear deconvolution + Crop(8, 8) (flow: 2 grouped channels, mask: 1) vs torch autograd in float64,
+    with a random (not bilinear) kernel so that every tap matters; edge windows hang over the crop on all four sides"""
+    g = torch.Generator().manual_seed(21)
+    for C in (2, 1):
+        wk = torch.randn((C, 1, 32, 32), generator=g)
+        f = torch.zeros((3, C, 30, 40), dtype=torch.float64, requires_grad=True)
+        dout = torch.randn((3, C, 480, 640), generator=g)
+        up = F.conv_transpose2d(f, wk.double(), None, stride=16, groups=C)[:, :, 8:488, 8:648] * 20.0
+        up.backward(dout.double())
+        df = torch.full((3, 30, 40, C), 5.0, device=DEV)
+        ops.upsample16_bwd(dout.to(DEV), wk.to(DEV), df, crop=8, scale=20.0)
+        ref = f.grad.permute(0, 2, 3, 1)
+        assert (df.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-5
