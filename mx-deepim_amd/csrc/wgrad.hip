@@ -379,8 +379,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(WgradArgs a) {
   for (int st = step_begin; st < step_end; st += 2) {
     // LDS-only barriers (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() also waits for vmcnt(0), i.e. for the loads of step st + 2
     // issued a few lines above, so every barrier drained the prefetch the second staging set exists for.  Measured after the change:
-    // 6.17 vs 6.17 ms per iteration -- the kernel is bound by the bytes it moves through the vector memory path, not by their latency
-    // (DESIGN.md section 3c); kept because it is what the code means.  The compiler waits for a set's loads where store_step reads them.
+    // 6.17 vs 6.17 ms per iteration -- the kernel is bound by the NUMBER of vector loads it issues, not by their latency or their bytes
+    // (the compile-time twins below); kept because it is what the code means.  The compiler waits for a set's loads where store_step reads them.
     if (!(dbg & 16)) load_step(rzB, rxB, min(st + 2, last), st + 2 < step_end);
     compute(0);
     if (!(dbg & 1)) store_step(rzA, rxA, 1);
