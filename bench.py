@@ -407,6 +407,7 @@ def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps, progress=None
     from deepim.symbols.deepIM_flownet import deepIM_flownet
     from lib.pair_matching.batch_updater_py_multi import batchUpdaterPyMulti
     from lib.utils import synthetic as syn
+    from lib.utils.dist_utils import gather_floats
 
     fast = cfg.TEST.FAST_TEST
     cfg.TRAIN.lr = 1e-4
@@ -463,13 +464,34 @@ def train_bench(cfg, models, rm, B, dev, rank, world, dist, steps, progress=None
             mod.forward_backward(batch)
             mod.update(1e-4)
         sync()
-        el = time.perf_counter() - t0
+        el = el_own = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         r["iteration_ms"] = el / steps * 1e3
+        r["iteration_ms_per_rank"] = [round(v / steps * 1e3, 3) for v in gather_floats(el_own)]
         r["pair_iterations_per_s"] = B * world * steps / el
+        if dist is not None:
+            # the gradient buckets on their own: bytes that cross the links per rank and the time of a blocking all-reduce(SUM) of
+            # each (no compute beside it), slowest rank; bus GB/s by the ring formula 2 (N-1)/N x bytes / time
+            bk = []
+            for a, b_ in mod.buckets:
+                buf = mod.flat_g16[a:b_] if (mod.bf16 and mod.flat_g16 is not None) else mod.flat_g[a:b_]
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)   # warm
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize()
+                tb = torch.tensor([(time.perf_counter() - t1) / 3.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+                nbytes = buf.numel() * buf.element_size()
+                bk.append({"begin": int(a), "end": int(b_), "bytes": int(nbytes), "dtype": str(buf.dtype).replace("torch.", ""),
+                           "ms": round(float(tb.item()) * 1e3, 3),
+                           "bus_GB/s": round(2.0 * (world - 1) / world * nbytes / float(tb.item()) / 1e9, 1)})
+            r["allreduce_buckets"] = bk
+            r["allreduce_bytes_per_update"] = int(sum(x["bytes"] for x in bk))
         r["finite"] = bool(torch.isfinite(mod.flat_w).all().item())
         if dtype == "bf16":
             # per-layer roofline of the bf16 forward convolutions (HIP events on the launch stream, 3 passes): against the dense bf16
@@ -543,6 +565,11 @@ def main():
         sys.stderr.write("bench.py: rank {} of {} joined (nccl = RCCL, {})\n".format(rank, world, dev))
         sys.stderr.flush()
 
+    # which devices joined: every rank reports the card it drives; two ranks on one card under RCCL is an error, not a slow run
+    from lib.utils.dist_utils import gather_floats, gather_rank_identities, rank_identity
+
+    ranks = gather_rank_identities(rank_identity(dev_index, rank, local_rank), backend=args.dist_backend)
+
     from deepim.config.config import config as cfg, update_config
     from deepim.core.tester import Predictor, Refiner
     from deepim.symbols.deepIM_flownet import deepIM_flownet
@@ -589,6 +616,7 @@ def main():
         refiner.refine()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [round(v / args.steps * 1e3, 3) for v in gather_floats(elapsed)]   # every rank's own clock, next to the MAX
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -615,6 +643,8 @@ def main():
                    "gflop_per_refinement": round(net.flops_per_forward() * test_iter / B / 1e9, 2), "status_flags": status,
                    "conv_plan": {k: list(v) for k, v in net.conv_plan.items()}},
         "roofline": roofline,
+        "ranks": ranks, "ms_per_step_per_rank": per_rank_ms, "dist_backend": args.dist_backend if world > 1 else None,
+        "distinct_devices": len({(r["host"], r["uuid"] or r["pci_bus_id"] or r["device"]) for r in ranks}),
     }
     if world == 1 and not args.no_fresh_batch and not args.no_graph:
         try:

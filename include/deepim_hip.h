@@ -124,6 +124,15 @@ int dim_transform3d_bwd(const float* out_grad, const float* points, const float*
  * device-pointer version of _flow (lib/flow_c/gpu_flow.hpp:1-3): flow (B,2,H,W) in (dy,dx), valid (B,1,H,W). */
 int dim_depth_to_flow(const float* depth_src, const float* depth_tgt, const float* KT, const float* Kinv9, int B, int H, int W,
                       float* flow, float* valid, void* stream);
+/* Test-time flow error of the first forward (deepim/core/tester.py:500-512; calc_EPE_one_pair :719-736 over the [flow, visible, bg]
+ * list of par_generate_gt :706-716).  flow_pred = the network's flow_est_crop_output (B,2,H,W), rounded to float16 first as
+ * tester.py:485-487 stores it; flow_gt (B,2,H,W) / visible (B,1,H,W) = calc_flow's outputs (dim_calc_flow_labels, weight_type 1);
+ * bg = visible == 0 and depth_rendered == 0.  sums (B,5) float64 (device) = {epe_all, epe_viz, epe_vizbg, num_viz, num_vizbg} per
+ * sample (num_all = H W), overwritten or -- accumulate != 0 -- added to.  Float64 arithmetic like numpy's (calc_flow returns
+ * float64); deterministic two-stage sum.  workspace: dim_flow_epe_workspace_bytes(B). */
+long dim_flow_epe_workspace_bytes(int B);
+int dim_flow_epe_sums(const float* flow_pred, const float* flow_gt, const float* visible, const float* depth_rendered, int B, int H,
+                      int W, void* workspace, double* sums, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------- data layer (test batches from raw file pixels)
  * The loader uploads what the image files hold -- obs_bgr / ren_bgr (B,H,W,3) uint8 in B,G,R order (cv2.IMREAD_COLOR), depth_rendered

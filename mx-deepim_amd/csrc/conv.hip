@@ -2286,7 +2286,8 @@ static int conv2d_dgrad_impl(const float* dy, const float* w_dgrad_packed, float
                                             : w_dgrad_packed + off, nullptr, dx, split ? workspace : nullptr, N, Ho, Wo, Cout, CinPad,
                                    ah.ntaps, aw.ntaps, 1, -ah.emin, 1.0f, psplits, ptile, 0, stream, &ex);
           if (rc != DIM_OK) return rc;
-        } else if (!accumulate || mask) {
+        } else if (!accumulate || mask || split) {
+          // (split: the slab rows of a tap-less phase would never be written, and slab_sum_rows_kernel adds every row of every slab)
           return set_err(DIM_ERR_ARG, "phase (%d,%d) has no taps: dX rows of that phase would stay unwritten", py, px);
         }
       }

@@ -3,6 +3,8 @@
 // _flow (:82-148) which cudaMalloc/H2D/D2H/cudaFree on every call.  Same per-pixel arithmetic
 // (float32, same operation order), output flow in (dy, dx) order, valid in {0,1}.
 // HBM-bound: 2 planes read + 3 planes written per sample = 6.144 MB at 480x640.
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace dim {
@@ -45,6 +47,57 @@ __global__ __launch_bounds__(256) void depth_flow_kernel(const float* __restrict
   valid[index] = va;
 }
 
+
+// Test-time flow error (reference deepim/core/tester.py:500-512 accumulation, :719-736 calc_EPE_one_pair, :706-716 the
+// [flow, visible, bg] list of par_generate_gt):  point_diff = sqrt((gt0 - pred0)^2 + (gt1 - pred1)^2) with the prediction
+// stored as float16 first (tester.py:485-487 `.astype("float16")`, round to nearest even) and the arithmetic in float64
+// (calc_flow returns float64, so numpy promotes).  Per sample: sum over all pixels, over visible == 1, over
+// visible or bg (bg = visible == 0 and depth_rendered == 0), and the two pixel counts.
+// Two deterministic stages: every workgroup leaves its five partial sums (fixed tree), one wave per sample adds them in order.
+constexpr int kEpeBlocks = 120;  // workgroups per sample
+__global__ __launch_bounds__(256) void flow_epe_partial_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                               const float* __restrict__ visible, const float* __restrict__ depth_ren,
+                                                               long plane, double* __restrict__ partial) {
+  const int b = blockIdx.y;
+  const float* p0 = pred + (long)b * 2 * plane;
+  const float* g0 = gt + (long)b * 2 * plane;
+  const float* vi = visible + (long)b * plane;
+  const float* dr = depth_ren + (long)b * plane;
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < plane; o += (long)gridDim.x * blockDim.x) {
+    const double q0 = (double)__half2float(__float2half_rn(p0[o])), q1 = (double)__half2float(__float2half_rn(p0[plane + o]));
+    const double d0 = (double)g0[o] - q0, d1 = (double)g0[plane + o] - q1;
+    const double e = sqrt(d0 * d0 + d1 * d1);
+    const float v = vi[o];
+    const bool bg = v == 0.f && dr[o] == 0.f;
+    s[0] += e;
+    if (v == 1.f) s[1] += e;
+    if (v != 0.f || bg) s[2] += e;   // np.logical_or(visible, bg)
+    s[3] += (double)v;               // visible.sum()
+    s[4] += (v != 0.f || bg) ? 1.0 : 0.0;
+  }
+  __shared__ double red[5][256];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) red[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 5) partial[((long)b * gridDim.x + blockIdx.x) * 5 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ void flow_epe_final_kernel(const double* __restrict__ partial, int nblk, double* __restrict__ sums, int accumulate) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  if (k >= 5) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += partial[((long)b * nblk + i) * 5 + k];
+  sums[b * 5 + k] = (accumulate ? sums[b * 5 + k] : 0.0) + s;
+}
+
 }  // namespace dim
 
 using namespace dim;
@@ -56,4 +109,18 @@ extern "C" int dim_depth_to_flow(const float* depth_src, const float* depth_tgt,
   hipLaunchKernelGGL(depth_flow_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, as_stream(stream), depth_src, depth_tgt, KT,
                      Kinv9[0], Kinv9[1], Kinv9[2], Kinv9[3], Kinv9[4], Kinv9[5], H, W, flow, valid);
   return check_launch("depth_to_flow");
+}
+
+extern "C" long dim_flow_epe_workspace_bytes(int B) { return (long)B * kEpeBlocks * 5 * (long)sizeof(double); }
+
+extern "C" int dim_flow_epe_sums(const float* flow_pred, const float* flow_gt, const float* visible, const float* depth_rendered, int B,
+                                 int H, int W, void* workspace, double* sums, int accumulate, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(flow_pred && flow_gt && visible && depth_rendered && workspace && sums, "null pointer");
+  DIM_REQUIRE(H > 0 && W > 0, "empty image");
+  hipLaunchKernelGGL(flow_epe_partial_kernel, dim3(kEpeBlocks, B), dim3(256), 0, as_stream(stream), flow_pred, flow_gt, visible,
+                     depth_rendered, (long)H * W, (double*)workspace);
+  hipLaunchKernelGGL(flow_epe_final_kernel, dim3(B), dim3(64), 0, as_stream(stream), (const double*)workspace, kEpeBlocks, sums,
+                     accumulate);
+  return check_launch("flow_epe_sums");
 }

@@ -178,7 +178,10 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(const float* __rest
     }
   }
   vf bv = (vf)(0.f);
-  if (bias) bv = *reinterpret_cast<const vf*>(bias + co);
+  if (bias) {   // element loads: the bias of a flat parameter blob is only 4-byte aligned (the other convolution paths accept that too)
+#pragma unroll
+    for (int e = 0; e < kVec; ++e) bv[e] = bias[co + e];
+  }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int oy = 4 * (int)ty + a;
@@ -268,8 +271,7 @@ int dim_conv2d_fwd_winograd3x3s2(const float* x, const float* w_packed, const fl
   if (out_cstride == 0) out_cstride = Cout;
   DIM_REQUIRE(in_cstride >= Cin && in_cstride % 2 == 0 && out_cstride >= out_coff + Cout && out_cstride % 2 == 0 && out_coff % 2 == 0,
               "channel strides / offsets must be even and cover the channels");
-  DIM_REQUIRE((reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (!bias || (reinterpret_cast<uintptr_t>(bias) & 7) == 0),
-              "x, y and bias must be 8-byte aligned");
+  DIM_REQUIRE((reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, "x and y must be 8-byte aligned");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int th = (Ho + 3) / 4, tw = (Wo + 3) / 4;
   const long ns = s2_slice_images((long)th * tw, Cin, Cout);

@@ -105,7 +105,12 @@ class PixelCache(object):
         n = dev_tensor.numel() * dev_tensor.element_size()
         if key in self.entries or self.used + n > self.budget:
             return False
-        self.entries[key] = (dev_tensor.clone(), meta)
+        try:
+            copy = dev_tensor.clone()
+        except torch.cuda.OutOfMemoryError:   # a full HBM costs a cache entry, not the training run
+            self.budget = self.used
+            return False
+        self.entries[key] = (copy, meta)
         self.used += n
         return True
 
@@ -549,8 +554,14 @@ class TrainDataLoader(_DeviceLoader):
                     point_cloud_dict[cls] = load_obj_with_normals(os.path.join(cfg.dataset.model_dir, cls + ".obj"))[0].astype(np.float64)
             pts = torch.as_tensor(np.ascontiguousarray(point_cloud_dict[cls], dtype=np.float32)).to(self.device)
             off = 0 if self._table is None else int(self._table.shape[0])
-            self._table = pts if self._table is None else torch.cat([self._table, pts])
-            torch.cuda.current_stream().synchronize()   # (once per class) the table is read on the build stream
+            old_table = self._table
+            if old_table is not None:
+                # (once per class) point_clouds of the previous batch may still be reading the old table on the build stream: it must
+                # not go back to the allocator -- and from there to the training thread -- before that kernel has run
+                self.build_stream.synchronize()
+            self._table = pts if old_table is None else torch.cat([old_table, pts])
+            torch.cuda.current_stream().synchronize()   # the new table is read on the build stream
+            del old_table
             self._point_tables[cls] = (off, int(pts.shape[0]))
         return self._point_tables[cls]
 

@@ -61,6 +61,12 @@ class MutableModule(object):
         self.cfg = cfg
         self.B = batch_size
         self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            # compute units of THIS device, as the library reads them (conv.hip sizes its grids from the same number): the split plans
+            # of the weight and input gradients fill "resident workgroup slots" = a small multiple of it
+            self.n_cu = int(ops.lib().dim_device_info(None, 0))
+        if self.n_cu <= 0:
+            raise RuntimeError("dim_device_info: {}".format(ops.lib().dim_last_error()))
         self.pg = process_group
         d = self.device
         sym = deepIM_flownet()
@@ -169,7 +175,7 @@ class MutableModule(object):
                 # second, nearly empty round in which nothing overlaps the phases of a step.  tools/wgrad_sweep.py at B = 16,
                 # workgroups: us -- conv3_1 756: 155, 1044: 187, 1512: 168; conv2 767: 252, 1027: 318 (the round-2 rule aimed at ~1024
                 # with a ceiling division and overshot the 768 slots on every layer).  One plan function for every caller:
-                sp = ops.lib().dim_conv2d_wgrad_bf16_splits(B, h, w, c, cout, k, k, s, p, 256)
+                sp = ops.lib().dim_conv2d_wgrad_bf16_splits(B, h, w, c, cout, k, k, s, p, self.n_cu)
             self.wgrad_splits[name] = sp
             max_ws = max(max_ws, ops.lib().dim_conv2d_wgrad_workspace_floats(cout, c, k, k, sp + 1))   # + 1: dim_conv2d_wgrad_oihw
             if self.bf16 and c != 8:   # split-K slabs of this layer's input gradient (copies of dX), see _dgrad_splits
@@ -563,8 +569,7 @@ class MutableModule(object):
         ops.conv2d_fwd_ex(dz, dz_coff, cout, self.dgrad_packed[name], None, dx, 0, x_cpad, 4, 4, 2, 1, Ho=h, Wo=wd, accumulate=False,
                           tile=self._bf16_gemm_tile(N * h * wd, x_cpad) if self.bf16 else 3)
 
-    @staticmethod
-    def _dgrad_splits(tile, rows, cols, cout):
+    def _dgrad_splits(self, tile, rows, cols, cout):
         """split-K count of a bf16 input gradient on the gathered-tap kernel: the small maps (conv5 .. conv6_1: 1280-4800 rows per
         launch) make 144-600 tiles of 64 x 64 for the 1280 workgroups that fit the chip (5 per CU), and each walks K = 4608-9216 alone.
         The K range is cut so that the grid fills the slots; every phase of a strided gradient must keep >= splits chunks of 32 dy
@@ -573,7 +578,7 @@ class MutableModule(object):
             return 1
         tiles = -(-rows // 64) * (cols // 64)
         for sp in (8, 4, 2):
-            if sp * tiles <= 1280 and (cout // 32) % sp == 0:
+            if sp * tiles <= 5 * self.n_cu and (cout // 32) % sp == 0:
                 return sp
         return 1
 

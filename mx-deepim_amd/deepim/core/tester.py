@@ -173,6 +173,65 @@ class Refiner(object):
         return self.poses_iter
 
 
+class FlowEPE(object):
+    """Test-time flow error, reference deepim/core/tester.py:500-512 (accumulation), :675-716 (par_generate_gt) and :719-736
+    (calc_EPE_one_pair), active when `PRED_FLOW and not FAST_TEST`: the flow head's output of the FIRST forward of every pair
+    (`rst_iter` is built from predictor.predict before the refinement loop, :476-494) against calc_flow(depth_rendered,
+    pose_rendered, pose_observed, K, depth_gt_observed) of the initial pair.  Labels (dim_calc_flow_labels) and the three masked
+    error sums (dim_flow_epe_sums) stay on the device; ONE (5,) float64 read-out at the end."""
+
+    def __init__(self, config, batch_size, device):
+        self.cfg = config
+        K = np.asarray(config.dataset.INTRINSIC_MATRIX, dtype=np.float64).reshape(3, 3)
+        self.K = K
+        self.Kinv64 = np.linalg.inv(K)
+        B, H, W = batch_size, 480, 640
+        self.flow = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        self.weights = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+        self.sums = torch.zeros((B, 5), dtype=torch.float64, device=device)
+        self.work = torch.empty((ops.lib().dim_flow_epe_workspace_bytes(B) // 8,), dtype=torch.float64, device=device)
+        self.P12 = torch.empty((B, 3, 4), dtype=torch.float64, device=device)
+        self.num_all = 0
+
+    def add(self, batch, flow_est, skip=None):
+        """batch: depth_rendered (B,1,H,W) of the initial render, depth_gt_observed (B,1,H,W) (zero off the object: tester.py:700-704),
+        src_pose, pose_observed; flow_est (B,2,H,W) = flow_est_crop_output of the first forward.  skip: (B,) bool, pairs that are not
+        scored (undetected objects leave the loop before the flow error, :451-475)."""
+        from lib.utils.projection import se3_inverse, se3_mul
+
+        for k in ("depth_rendered", "depth_gt_observed", "pose_observed"):
+            if k not in batch:
+                raise KeyError("test-time flow error (PRED_FLOW and not FAST_TEST) needs the blob '{}' (par_generate_gt reads it from "
+                               "the pair record, tester.py:681-704)".format(k))
+        src = torch.as_tensor(batch["src_pose"]).cpu().numpy().astype(np.float64)
+        tgt = torch.as_tensor(batch["pose_observed"]).cpu().numpy().astype(np.float64)
+        P = np.stack([np.matmul(self.K, se3_mul(tgt[b], se3_inverse(src[b]))) for b in range(src.shape[0])])   # flow.py:31
+        self.P12.copy_(torch.from_numpy(np.ascontiguousarray(P)))
+        dr = torch.as_tensor(batch["depth_rendered"]).to(self.flow.device, torch.float32).contiguous()
+        dg = torch.as_tensor(batch["depth_gt_observed"]).to(self.flow.device, torch.float32).contiguous()
+        ops.calc_flow_labels(dr, dg, self.P12, self.Kinv64, self.flow, self.weights, standard_rep=bool(self.cfg.network.STANDARD_FLOW_REP),
+                             weight_type="viz")
+        per = ops.flow_epe_sums(flow_est, self.flow, self.weights[:, :1].contiguous(), dr, workspace=self.work)
+        if skip is not None and bool(np.any(skip)):
+            per = per * torch.from_numpy(~np.asarray(skip, dtype=bool)).to(per.device, torch.float64)[:, None]
+        self.sums += per
+        self.num_all += int(per.shape[0] - (0 if skip is None else int(np.sum(skip)))) * dr.shape[2] * dr.shape[3]
+
+    def result(self, merge_ranks=True):
+        """-> dict(epe_all, epe_vizbg, epe_viz: the three numbers the reference prints at :656-660; sums and counts next to them)"""
+        import torch.distributed as dist
+
+        t = torch.cat([self.sums.sum(0), torch.tensor([float(self.num_all)], dtype=torch.float64, device=self.sums.device)]).cpu()
+        if merge_ranks and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            parts = [None] * dist.get_world_size()
+            dist.all_gather_object(parts, t.numpy())
+            t = torch.from_numpy(np.sum(parts, axis=0))
+        s_all, s_viz, s_vizbg, n_viz, n_vizbg, n_all = (float(v) for v in t)
+        return {"epe_all": s_all / max(n_all, 1.0), "epe_vizbg": s_vizbg / max(n_vizbg, 1.0), "epe_viz": s_viz / max(n_viz, 1.0),
+                "sum_EPE_all": s_all, "sum_EPE_viz": s_viz, "sum_EPE_vizbg": s_vizbg, "num_inst_all": n_all, "num_inst_viz": n_viz,
+                "num_inst_vizbg": n_vizbg}
+
+
 def pred_eval(config, refiner, batches, evaluator, result_file=None, logger=None, merge_ranks=True):
     """The outer loop of the reference's pred_eval (deepim/core/tester.py:418-676) on device-resident batches.
 
@@ -190,6 +249,8 @@ def pred_eval(config, refiner, batches, evaluator, result_file=None, logger=None
     all_trans_err = [[[] for _ in range(n_it)] for _ in range(n_cls)]
     all_poses_est = [[[] for _ in range(n_it)] for _ in range(n_cls)]
     all_poses_gt = [[[] for _ in range(n_it)] for _ in range(n_cls)]
+    # flow error of the first forward (:500-512): only the full test graph emits the flow head's output
+    epe = FlowEPE(config, refiner.B, refiner.net.device) if (config.network.PRED_FLOW and not config.TEST.FAST_TEST) else None
     for batch in batches:
         refiner.load(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"], batch["src_pose"],
                      batch["class_index"])
@@ -197,6 +258,8 @@ def pred_eval(config, refiner, batches, evaluator, result_file=None, logger=None
         cls = torch.as_tensor(batch["class_index"]).cpu().numpy().astype(int)
         gt = torch.as_tensor(batch["pose_observed"]).cpu().numpy().astype(np.float64)
         src = torch.as_tensor(batch["src_pose"]).cpu().numpy().astype(np.float64)
+        if epe is not None:
+            epe.add(batch, refiner.flow_est_iter[0], skip=np.sum(src.reshape(src.shape[0], -1), axis=1) == -12)
         for b in range(poses.shape[1]):
             # "NO POINT VALID IN INIT POSE" (:419-445): an undetected object comes with pose_rendered = -1 everywhere (sum -12); it is
             # scored with its initial pose and 1000 deg / 1000 m at every iteration instead of being refined
@@ -227,7 +290,15 @@ def pred_eval(config, refiner, batches, evaluator, result_file=None, logger=None
         with open(result_file, "wb") as f:
             pickle.dump([np.array(all_rot_err, dtype=object), np.array(all_trans_err, dtype=object), all_poses_est, all_poses_gt], f,
                         protocol=2)
-    out = {"pose": evaluator.evaluate_pose(config, all_poses_est, all_poses_gt, logger)}
+    out = {}
+    if epe is not None:   # :656-660, before the pose tables like the reference
+        out["epe"] = epe.result(merge_ranks=merge_ranks)
+        for line in ("evaluate flow:", "EPE all: {}".format(out["epe"]["epe_all"]), "EPE ignore unvisible: {}".format(out["epe"]["epe_vizbg"]),
+                     "EPE visible: {}".format(out["epe"]["epe_viz"])):
+            print(line)
+            if logger:
+                logger.info(line)
+    out["pose"] = evaluator.evaluate_pose(config, all_poses_est, all_poses_gt, logger)
     out["add"] = evaluator.evaluate_pose_add(config, all_poses_est, all_poses_gt, output_dir=None, logger=logger)
     out["arp_2d"] = evaluator.evaluate_pose_arp_2d(config, all_poses_est, all_poses_gt, output_dir=None, logger=logger)
     out["all_rot_err"], out["all_trans_err"] = all_rot_err, all_trans_err

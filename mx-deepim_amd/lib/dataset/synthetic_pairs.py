@@ -37,9 +37,11 @@ class SyntheticPairs(object):
         return PoseEvaluator(self.classes, pts, diam)
 
     def test_batches(self):
+        # the full test graph also scores the flow head (tester.py:500-512): its labels need the two depth planes of the pair record
+        with_depth = bool(self.config.network.PRED_FLOW and not self.config.TEST.FAST_TEST)
         for i in self.batch_ids:
             b = syn.build_device_batch(self.render_machine, self.batch_pairs, seed=self.seed + 1000 * (i + 1), n_classes=len(self.classes),
-                                       pixel_means=self.config.network.PIXEL_MEANS, device=self.device)
+                                       pixel_means=self.config.network.PIXEL_MEANS, device=self.device, with_depth=with_depth)
             b["pose_observed"] = b["pose_gt"]
             yield b
 

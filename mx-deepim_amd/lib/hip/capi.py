@@ -37,6 +37,8 @@ SIGNATURES = {
     "dim_transform3d_fwd": (I, [P, P, P, P, P, I, I, I, P, P, P]),
     "dim_transform3d_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P, P]),
     "dim_depth_to_flow": (I, [P, P, P, P, I, I, I, P, P, P]),
+    "dim_flow_epe_workspace_bytes": (L, [I]),
+    "dim_flow_epe_sums": (I, [P, P, P, P, I, I, I, P, P, I, P]),
     "dim_refiner_create": (I, [P, P, P, P, I, P]),
     "dim_refiner_run": (I, [P, P, P, P, P, P, P, P, P, P, P]),
     "dim_refiner_destroy": (I, [P]),

@@ -189,6 +189,21 @@ def depth_to_flow(depth_src, depth_tgt, KT, Kinv, flow=None, valid=None):
     return flow, valid
 
 
+def flow_epe_sums(flow_pred, flow_gt, visible, depth_rendered, sums=None, accumulate=False, workspace=None):
+    """per-sample sums of calc_EPE_one_pair (reference deepim/core/tester.py:719-736): sums (B,5) float64 =
+    [epe_all, epe_viz, epe_vizbg, num_viz, num_vizbg]; flow_pred is rounded to float16 first as tester.py:485-487 stores it"""
+    B, _, H, W = flow_pred.shape
+    assert flow_gt.shape == flow_pred.shape and visible.shape == (B, 1, H, W) and depth_rendered.shape == (B, 1, H, W)
+    if sums is None:
+        assert not accumulate
+        sums = torch.empty((B, 5), dtype=torch.float64, device=flow_pred.device)
+    if workspace is None:
+        workspace = torch.empty((lib().dim_flow_epe_workspace_bytes(B) // 8,), dtype=torch.float64, device=flow_pred.device)
+    check(lib().dim_flow_epe_sums(dptr(flow_pred, f32), dptr(flow_gt, f32), dptr(visible, f32), dptr(depth_rendered, f32), B, H, W,
+                                  dptr(workspace, torch.float64), dptr(sums, torch.float64), int(bool(accumulate)), current_stream()))
+    return sums
+
+
 def box_mask(bbox, mask, bbox_of_mask=None):
     """mask <- filled rectangle of bbox (end-exclusive); bbox_of_mask (B,4) int32: optional bbox of that rectangle"""
     B, _, H, W = mask.shape

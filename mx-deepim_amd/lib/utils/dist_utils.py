@@ -87,3 +87,44 @@ def max_over_ranks(value, device="cpu"):
 def barrier():
     if is_distributed():
         dist.barrier()
+
+
+def rank_identity(device_index, rank=0, local_rank=0):
+    """what makes this rank's line self-proving: host, device ordinal, marketing name, PCI bus id and uuid of the card it drives"""
+    props = torch.cuda.get_device_properties(device_index)
+    pci = None
+    if hasattr(props, "pci_bus_id"):
+        pci = "{:04x}:{:02x}:{:02x}".format(int(getattr(props, "pci_domain_id", 0)), int(props.pci_bus_id), int(getattr(props, "pci_device_id", 0)))
+    return {"rank": int(rank), "local_rank": int(local_rank), "host": socket.gethostname(), "device": int(device_index), "name": str(props.name),
+            "arch": str(getattr(props, "gcnArchName", "")), "pci_bus_id": pci, "uuid": str(getattr(props, "uuid", "")) or None,
+            "cus": int(props.multi_processor_count), "hbm_gb": round(props.total_memory / 2 ** 30, 1), "pid": os.getpid()}
+
+
+def gather_rank_identities(ident, backend="nccl"):
+    """-> [identity of rank 0, rank 1, ...] on every rank.  Under nccl (= RCCL) two ranks on one card are a launch error (they would
+    halve each other's throughput and the line would still say n_gpus = N): raise.  gloo rehearsals share a card on purpose."""
+    if not is_distributed():
+        return [ident]
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, ident)
+    check_distinct_devices(parts, backend)
+    return parts
+
+
+def check_distinct_devices(idents, backend="nccl"):
+    seen = {}
+    for r in idents:
+        key = (r["host"], r["uuid"] or r["pci_bus_id"] or r["device"])
+        if key in seen and backend == "nccl":
+            raise RuntimeError("ranks {} and {} drive the same device {} on {}: one process per GPU".format(seen[key], r["rank"], key[1], key[0]))
+        seen.setdefault(key, r["rank"])
+    return len(seen)
+
+
+def gather_floats(value):
+    """-> [value on rank 0, rank 1, ...] (python floats) on every rank"""
+    if not is_distributed():
+        return [float(value)]
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, float(value))
+    return parts

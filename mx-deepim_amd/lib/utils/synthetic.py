@@ -114,12 +114,13 @@ def perturb_pose(rng, pose, angle_std=15.0, angle_max=45.0, xy_std=0.01, z_std=0
     return out.astype(np.float32)
 
 
-def sample_pairs(seed, B, n_classes=1):
-    """-> class_index (B,) int32, pose_gt (B,3,4), pose_init (B,3,4), background seeds."""
+def sample_pairs(seed, B, n_classes=1, **noise):
+    """-> class_index (B,) int32, pose_gt (B,3,4), pose_init (B,3,4), background seeds.
+    noise: keyword arguments of perturb_pose (angle_std, angle_max, xy_std, z_std) for pairs with another initial error."""
     rng = np.random.default_rng(seed)
     cls = rng.integers(0, n_classes, size=B).astype(np.int32)
     gt = np.stack([sample_gt_pose(rng) for _ in range(B)])
-    init = np.stack([perturb_pose(rng, gt[i]) for i in range(B)])
+    init = np.stack([perturb_pose(rng, gt[i], **noise) for i in range(B)])
     return cls, gt, init
 
 
@@ -154,17 +155,19 @@ def compose_observed(bgr_render, depth_render, rng):
     return np.where(fg, bgr_render, bg).astype(np.uint8)
 
 
-def build_device_batch(render_machine, B, seed, n_classes=1, pixel_means=PIXEL_MEANS, device="cuda:0"):
+def build_device_batch(render_machine, B, seed, n_classes=1, pixel_means=PIXEL_MEANS, device="cuda:0", noise=None, with_depth=False):
     """Synthetic test batch built ON the GPU with the HIP rasteriser (bench / smoke inputs):
     observed = render at the GT pose over seeded uniform noise, uint8-quantised; rendered = render at the
     perturbed pose; mask_rendered = depth > 0.2; mask_observed = bbox rectangle of it (TEST.INIT_MASK box_rendered).
-    Returns dict of CUDA tensors with the reference's blob names + pose_gt."""
+    Returns dict of CUDA tensors with the reference's blob names + pose_gt.
+    with_depth: also depth_gt_observed (the render at the GT pose: zero off the object) and depth_rendered (the render at the initial
+    pose), the two planes par_generate_gt reads for the test-time flow error (deepim/core/tester.py:681-704)."""
     import torch
 
     from lib.hip import ops
 
     d = torch.device(device)
-    cls, gt, init = sample_pairs(seed, B, n_classes)
+    cls, gt, init = sample_pairs(seed, B, n_classes, **(noise or {}))
     H, W = render_machine.height, render_machine.width
     pm = plane_means(pixel_means)
     cls_t = torch.from_numpy(cls).to(d)
@@ -175,6 +178,7 @@ def build_device_batch(render_machine, B, seed, n_classes=1, pixel_means=PIXEL_M
     g.manual_seed(seed)
     noise = torch.randint(0, 256, (B, 3, H, W), generator=g, device=d).float() - torch.from_numpy(pm).to(d).view(1, 3, 1, 1)
     image_observed = torch.where(depth > 0, img, noise).contiguous()
+    depth_gt = depth.clone() if with_depth else None
     image_rendered = torch.empty((B, 3, H, W), device=d)
     mask_rendered = torch.empty((B, 1, H, W), device=d)
     mask_observed = torch.empty((B, 1, H, W), device=d)
@@ -182,19 +186,22 @@ def build_device_batch(render_machine, B, seed, n_classes=1, pixel_means=PIXEL_M
     render_machine.render_batch(cls_t, torch.from_numpy(init).to(d), image=image_rendered, depth=depth, mask=mask_rendered, bbox=bbox,
                                 plane_means=pm)
     ops.box_mask(bbox, mask_observed)
-    return {"image_observed": image_observed, "image_rendered": image_rendered, "mask_observed": mask_observed,
-            "mask_rendered": mask_rendered, "src_pose": torch.from_numpy(init).to(d), "class_index": cls_t,
-            "pose_gt": torch.from_numpy(gt).to(d)}
+    out = {"image_observed": image_observed, "image_rendered": image_rendered, "mask_observed": mask_observed,
+           "mask_rendered": mask_rendered, "src_pose": torch.from_numpy(init).to(d), "class_index": cls_t,
+           "pose_gt": torch.from_numpy(gt).to(d)}
+    if with_depth:
+        out.update(depth_gt_observed=depth_gt, depth_rendered=depth)
+    return out
 
 
-def build_device_train_batch(render_machine, B, seed, models, n_classes=1, pixel_means=PIXEL_MEANS, npts=3000, device="cuda:0"):
+def build_device_train_batch(render_machine, B, seed, models, n_classes=1, pixel_means=PIXEL_MEANS, npts=3000, device="cuda:0", noise=None):
     """build_device_batch + the training blobs/labels (reference names, deepim/core/loader.py:164-193): mask_gt_observed, tgt_pose,
     depth_gt_observed, rot/trans labels, flow/flow_weights (depth->flow kernel), point clouds."""
     import torch
 
     from lib.hip import ops
 
-    b = build_device_batch(render_machine, B, seed, n_classes=n_classes, pixel_means=pixel_means, device=device)
+    b = build_device_batch(render_machine, B, seed, n_classes=n_classes, pixel_means=pixel_means, device=device, noise=noise)
     d = torch.device(device)
     H, W = render_machine.height, render_machine.width
     K = render_machine.K

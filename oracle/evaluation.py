@@ -127,3 +127,35 @@ def evaluate_pose_arp_2d(classes, points, K, est, gt, num_iter):
     count_all, cc, nvalid = _count_loop(classes, est, gt, num_iter, error_of, thr, curve)
     per_class, overall = _accuracies(classes, num_iter, count_all, cc, ("2", "5", "10", "20"), dx, 50.0, nvalid)
     return per_class, overall, cc, count_all
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Test-time flow error (deepim/core/tester.py:500-512, :675-736).  PINNED: tests/golden/epe_golden.npz holds the outputs of the
+# reference's own calc_EPE_one_pair (executed from its file by tests/golden/make_golden.py) on the reference's own calc_flow.
+def flow_gt_list(flow, visible, depth_rendered):
+    """the list par_generate_gt returns under "flow" (tester.py:706-716): [flow_i2r, visible, visible == 0 and depth_rendered == 0]"""
+    return [flow, visible, np.logical_and(visible == 0, depth_rendered == 0)]
+
+
+def calc_EPE_one_pair(flow_pred_list, flow_gt, flow_type="flow"):
+    """tester.py:719-736; flow_pred_list[flow_type] is the (H,W,2) float16 array of tester.py:485-487"""
+    pred = flow_pred_list[flow_type]
+    gt, visible, bg = flow_gt[flow_type][0], flow_gt[flow_type][1], flow_gt[flow_type][2]
+    dx = gt[:, :, 0] - pred[:, :, 0]
+    dy = gt[:, :, 1] - pred[:, :, 1]
+    dist = np.sqrt(np.square(dx) + np.square(dy))
+    either = np.logical_or(visible, bg)
+    return {"epe_all": dist.sum(), "num_all": dist.size, "epe_viz": dist[visible == 1].sum(), "num_viz": visible.sum(),
+            "epe_vizbg": dist[either].sum(), "num_vizbg": either.sum()}
+
+
+def epe_of_batch(flow_est_crop, flow, visible, depth_rendered):
+    """(B,2,H,W) network output + (B,2,H,W) / (B,1,H,W) / (B,1,H,W) labels -> (B,5) [epe_all, epe_viz, epe_vizbg, num_viz, num_vizbg],
+    through the float16 store of tester.py:485-487 (`output.asnumpy().transpose((2, 3, 1, 0))` squeezed: (H,W,2) per sample)"""
+    out = []
+    for b in range(flow_est_crop.shape[0]):
+        cur = {"flow": np.asarray(flow_est_crop[b]).transpose(1, 2, 0).astype("float16")}
+        gt = flow_gt_list(np.asarray(flow[b]).transpose(1, 2, 0), np.asarray(visible[b, 0]), np.asarray(depth_rendered[b, 0]))
+        r = calc_EPE_one_pair(cur, {"flow": gt})
+        out.append([r["epe_all"], r["epe_viz"], r["epe_vizbg"], r["num_viz"], r["num_vizbg"]])
+    return np.array(out, dtype=np.float64)

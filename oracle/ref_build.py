@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-REF_DIR = "/root/reference/lib/flow_c"
+REF_DIR = os.path.join(os.environ.get("DIM_REFERENCE_ROOT", "/root/reference"), "lib", "flow_c")   # where the reference is mounted
 OUT = os.path.join(_HERE, "_ref", "libcpu_flow_ref.so")
 SYMBOL = "_Z8flow_cppPfS_S_S_S_iiii"   # void flow_cpp(float*, float*, float*, float*, float*, int, int, int, int): C++ linkage in the reference
 

@@ -9,6 +9,9 @@ Modules imported from /root/reference:
   lib/pair_matching/flow.py (calc_flow), lib/utils/pose_error.py (add, adi, arp_2d, re, te),
   lib/utils/get_min_rect.py, lib/utils/projection.py (se3_mul, se3_inverse, backproject_camera), lib/utils/mask_dilate.py,
   deepim/core/callback.py (Speedometer)
+One function is EXECUTED without importing its module: calc_EPE_one_pair of deepim/core/tester.py:719-736 (pure numpy; the module
+imports mxnet / cv2 / glumpy at its top and cannot load here) -- epe_vectors() takes that one FunctionDef out of the file with `ast`,
+compiles it in memory and calls it; nothing of it is written anywhere.
 """
 import os
 import sys
@@ -271,7 +274,38 @@ def callback_vectors():
         json.dump(scripts, f, indent=0)
 
 
+def epe_vectors():
+    """Test-time flow error (tester.py:500-512): the reference's own calc_EPE_one_pair (:719-736) on the [flow, visible, bg] list that
+    par_generate_gt (:706-716) builds from the reference's calc_flow, with predictions stored as float16 like tester.py:485-487.
+    Inputs = the depth pairs / poses of flow_golden.npz; the un-rounded float32 predictions are saved so that the code under test does
+    its own float16 rounding."""
+    import ast
+
+    src = open("/root/reference/deepim/core/tester.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "calc_EPE_one_pair"]
+    assert len(fn) == 1
+    ns = {"np": np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "tester.py:calc_EPE_one_pair", "exec"), ns)
+    calc_EPE_one_pair = ns["calc_EPE_one_pair"]
+    g = np.load(os.path.join(HERE, "flow_golden.npz"))
+    rng = np.random.default_rng(29)
+    preds, outs = [], []
+    for i in range(g["depth_src"].shape[0]):
+        d0, d1 = g["depth_src"][i], g["depth_tgt"][i]
+        flow, visible, _ = calc_flow(d0, g["pose_src"][i], g["pose_tgt"][i], g["K"], d1, thresh=3e-3, standard_rep=False)
+        flow_list = [flow, visible, np.logical_and(visible == 0, d0 == 0)]          # tester.py:712-716
+        pred = (flow + rng.normal(size=flow.shape) * rng.uniform(0.05, 3.0) + (rng.uniform(size=flow.shape) < 0.02) * 40.0).astype(np.float32)
+        cur = {"flow": pred.astype("float16")}                                        # tester.py:485-487
+        r = calc_EPE_one_pair(cur, {"flow": flow_list}, "flow")
+        preds.append(pred)
+        outs.append([r["epe_all"], r["num_all"], r["epe_viz"], r["num_viz"], r["epe_vizbg"], r["num_vizbg"]])
+    np.savez_compressed(os.path.join(HERE, "epe_golden.npz"), pred=np.array(preds), out=np.array(outs, dtype=np.float64))
+
+
 if __name__ == "__main__":
+    if "--epe-only" in sys.argv:
+        epe_vectors()
+        sys.exit(0)
     if "--data-only" in sys.argv:
         data_layer_vectors()
         sys.exit(0)
@@ -288,6 +322,7 @@ if __name__ == "__main__":
     min_rect_vectors()
     data_layer_vectors()
     callback_vectors()
+    epe_vectors()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -122,3 +122,45 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env1, stdout=subprocess.PIPE,
                         stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
     assert r1.returncode != 0 and "WORLD_SIZE is 1" in r1.stdout, r1.stdout[-2000:]
+
+
+def _ident_worker(rank, world, port, out_dir):
+    import json
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lib.utils.dist_utils import gather_floats, gather_rank_identities
+
+    # what rank_identity() returns on a GPU box, with a fake card per rank (no GPU here); ranks 0 and 1 share a uuid
+    ident = {"rank": rank, "local_rank": rank, "host": "node0", "device": rank, "name": "AMD Instinct MI355X", "arch": "gfx950", "pci_bus_id": None,
+             "uuid": "GPU-{:02d}".format(min(rank, 1) if world == 3 else rank), "cus": 256, "hbm_gb": 288.0, "pid": os.getpid()}
+    res = {"floats": gather_floats(1.5 + rank)}
+    for backend in ("gloo", "nccl"):
+        try:
+            parts = gather_rank_identities(ident, backend=backend)
+            res[backend] = [p["rank"] for p in parts]
+        except RuntimeError as e:
+            res[backend] = "error: {}".format(e)
+    with open(os.path.join(out_dir, "ident{}.json".format(rank)), "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+def test_rank_identities_are_gathered_and_a_shared_card_is_an_error_under_rccl(tmp_path):
+    """the `ranks` object of the bench line (which devices joined): gathered in rank order on every rank; two ranks on one card are
+    refused when the backend is nccl (= RCCL) and accepted in a gloo rehearsal; the per-rank step times travel the same way"""
+    import json
+
+    for world in (2, 3):
+        d = tmp_path / "w{}".format(world)
+        d.mkdir()
+        mp.spawn(_ident_worker, args=(world, _free_port(), str(d)), nprocs=world, join=True)
+        for rank in range(world):
+            res = json.load(open(str(d / "ident{}.json".format(rank))))
+            assert res["floats"] == [1.5 + r for r in range(world)]
+            assert res["gloo"] == list(range(world))
+            if world == 2:   # distinct cards
+                assert res["nccl"] == [0, 1]
+            else:            # ranks 1 and 2 report the same uuid
+                assert res["nccl"].startswith("error: ranks 1 and 2 drive the same device GPU-01 on node0")
