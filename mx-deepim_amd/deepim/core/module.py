@@ -688,3 +688,25 @@ def fit_batch(module, data_batch, batch_updater, lr):
         if iter_idx != n_iter - 1:
             data_batch = batch_updater.forward(data_batch, preds, cfg)
     return outs
+
+
+def fit_epochs(module, batches, batch_updater, lr, epochs, on_epoch=None):
+    """`epochs` passes of fit_batch over a FIXED list of device-resident training batches (the epoch loop of MutableModule.fit,
+    reference module.py:1170-1260, without a data iterator).  fit_batch rewrites a batch in place (poses, rendered image, labels
+    advance through the inner iterations), so every pass works on a private copy of the pristine blobs.
+    -> history: array (epochs, n_inner_iterations, 5) of the loss sums (flow, point matching, -, rot, trans) over all pairs of an epoch.
+    on_epoch(epoch_index, sums) -> truthy stops early."""
+    hist = []
+    for ep in range(int(epochs)):
+        sums = None
+        for b in batches:
+            work = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}
+            outs = fit_batch(module, work, batch_updater, lr)
+            s = torch.stack([o["loss_sums"] for o in outs])
+            sums = s if sums is None else sums + s
+        hist.append(sums.cpu().numpy().astype(np.float64))
+        if not np.isfinite(hist[-1]).all():
+            raise FloatingPointError("training diverged in epoch {}: loss sums {}".format(ep, hist[-1]))
+        if on_epoch is not None and on_epoch(ep, hist[-1]):
+            break
+    return np.array(hist)

@@ -89,17 +89,10 @@ def check_loop(src_pose, poses_hip, se3_hip, free, forced, pts, diam, tag="", st
 
 
 def oracle_free_and_forced(params, mesh, blobs_b, K, pixel_means, poses_hip_b, test_iter=4, rot_coord="CAMERA", **kw):
-    """the two oracle loops check_loop wants, for one pair: free-running, and teacher-forced onto the HIP loop's poses (T,3,4).
-    Both consume numpy's global RNG identically (lit renderer: one draw per re-render), so the state is rewound in between."""
-    from oracle import refine as orefine
+    """the two oracle loops check_loop wants, for one pair (oracle/loop_check.py, shared with bench.py's checker leg)"""
+    from oracle import loop_check
 
-    z3, o3 = np.zeros(3), np.ones(3)
-    state = np.random.get_state()
-    free = orefine.refine_pair(params, mesh, blobs_b, K, pixel_means, z3, o3, rot_coord, test_iter=test_iter, **kw)
-    np.random.set_state(state)
-    forced = orefine.refine_pair(params, mesh, blobs_b, K, pixel_means, z3, o3, rot_coord, test_iter=test_iter,
-                                 forced_poses=np.asarray(poses_hip_b, np.float64), **kw)
-    return free, forced
+    return loop_check.oracle_free_and_forced(params, mesh, blobs_b, K, pixel_means, poses_hip_b, test_iter=test_iter, rot_coord=rot_coord, **kw)
 
 
 class StaleRenderPose(object):
