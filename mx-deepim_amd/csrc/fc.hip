@@ -7,6 +7,8 @@
 // B fragments straight from the packed [chunk][Out][32] weights (16 KB per wave and chunk in flight, one chunk ahead) and the <= 32
 // activation rows straight from L2 (x is 5 MB) -- no LDS, no barrier -- and writes one partial tile; a second kernel sums the
 // partials in a fixed order (deterministic), adds the bias and applies the activation.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dim {
@@ -82,10 +84,89 @@ __global__ __launch_bounds__(256) void fc_stream_kernel(FcArgs a) {
     }
 }
 
-// y[row0 + r][o] = act(sum_g partial[g][r][o] + bias[o]) for the rows of the batch; workgroup = 8 output quads x 32 partial groups
+// ---- batches of at most 16 rows (the refinement loop: 16 pairs per GPU): v_mfma_f32_16x16x4_f32 instead of the 32-row tile (half of
+// whose rows multiplied zeros), and the activations of the workgroup's whole K range staged ONCE in LDS.  Measured on MI355X
+// (rocprofv3, 84 MB of weights, cold): the 32-row kernel 33 us; this shape with per-chunk activation loads from L2 (every wave fetching
+// the same 2 KB, 16 half-used cache lines per instruction) 23.5 us; timing-only ablations of that: no MFMAs 21.0, activations loaded
+// once 19.4, no stores 22.4, all three 17.9 -- against 14.5-16.4 us for a bare non-temporal read of the same 84 MB
+// (tools/micro/stream_read.hip: 5.1 TB/s; WITHOUT the nt hint the same read takes 33 us behind a kernel that left dirty lines).
+// Two or three chunks of weights in flight instead of one: 33.8 / 36.5 us against 32.9 for the pair of launches -- not latency-bound.
+// Lane (i = lane & 15, kg = lane >> 4) supplies, for the half c of a chunk and k-step s, A[row i][k] and B[k][col i] with
+// k = 16 c + 4 kg + s: 16 consecutive bytes per lane, half and operand; over s and kg every k of the half is summed once.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kFc16Ldk = 36;          // floats per (chunk, row) of the LDS image: ds_read_b128 of 16 rows x 4 k-groups is conflict-free
+constexpr int kFc16MaxChunks = 24;    // chunks of a workgroup's K range (24 x 16 x 36 x 4 B = 55 KB of LDS)
+
+__global__ __launch_bounds__(256) void fc_stream16_kernel(FcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sx[];   // [chunk][16 rows][kFc16Ldk]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  const int n0 = blockIdx.y * 256 + wave * 64;
+  const int c_begin = blockIdx.x * a.chunks_per_wg;
+  const int c_end = min(a.nchunks, c_begin + a.chunks_per_wg);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const int b_voff = ((n0 + li) * 32 + 4 * kg) * 4;
+  const int wchunk_bytes = a.Out * 32 * 4;
+  float4 fb[2][4][2];
+#define FC16_LOAD(SET, KC)                                                                                                     \
+  {                                                                                                                            \
+    const int woff = (KC) * wchunk_bytes;                                                                                      \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) _Pragma("unroll") for (int t = 0; t < 4; ++t)                                \
+      fb[SET][t][c] = buf_load16_nt(rw, b_voff + t * 16 * 32 * 4 + c * 64, woff);                                              \
+  }
+  // the first chunk of weights leaves for HBM before anything else; the activations of the whole range follow (x is L2 / Infinity
+  // Cache resident: conv6_1's output transform has just written it)
+  FC16_LOAD(0, min(c_begin, a.nchunks - 1))
+  const int nloc = c_end - c_begin;
+  for (int idx = threadIdx.x; idx < nloc * 128; idx += 256) {   // 128 float4 per chunk: 16 rows x 8
+    const int j = idx >> 7, row = (idx >> 3) & 15, q = idx & 7;
+    const int kc = c_begin + j;
+    const int cs = kc / a.HW, hw = kc - cs * a.HW;   // chunk = (channel slice, pixel)
+    const float4 v = buf_load16(rx, row < a.B ? ((row * a.HW + hw) * a.C + cs * 32 + q * 4) * 4 : -1, 0);   // rows past the batch: zeros
+    *reinterpret_cast<float4*>(sx + (j * 16 + row) * kFc16Ldk + q * 4) = v;
+  }
+  __syncthreads();
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* sa = sx + li * kFc16Ldk + 4 * kg;
+#define FC16_STEP(SET, KC)                                                                                                     \
+  {                                                                                                                            \
+    FC16_LOAD(1 - SET, min((KC) + 1, a.nchunks - 1))                                                                           \
+    float4 fa[2];                                                                                                              \
+    fa[0] = *reinterpret_cast<const float4*>(sa + ((KC) - c_begin) * 16 * kFc16Ldk);                                           \
+    fa[1] = *reinterpret_cast<const float4*>(sa + ((KC) - c_begin) * 16 * kFc16Ldk + 16);                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                         \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                                            \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb[SET][t][c].x, acc[t], 0, 0, 0); \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb[SET][t][c].y, acc[t], 0, 0, 0); \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].z, fb[SET][t][c].z, acc[t], 0, 0, 0); \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].w, fb[SET][t][c].w, acc[t], 0, 0, 0); \
+    }                                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                         \
+  }
+  for (int kc = c_begin; kc < c_end; kc += 2) {
+    FC16_STEP(0, kc)
+    if (kc + 1 < c_end) FC16_STEP(1, kc + 1)
+  }
+#undef FC16_STEP
+#undef FC16_LOAD
+  // D layout of the 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + r
+  float* out = a.partial + (long)blockIdx.x * 16 * a.Out + n0 + li;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * kg + r;
+      if (row < a.B) out[(long)row * a.Out + 16 * t] = acc[t][r];
+    }
+}
+
+// y[row0 + r][o] = act(sum_g partial[g][r][o] + bias[o]) for the rows of the batch (prow = 16 or 32 rows per partial tile); workgroup = 8 output quads x 32 partial groups
 // (16-byte loads), fixed summation order: per group in g order, then the 32 group sums as a binary tree
 __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
-                                                        float* __restrict__ y, int G, int B, int row0, int Out, float slope) {
+                                                        float* __restrict__ y, int G, int B, int row0, int Out, float slope, int prow) {
   __shared__ float4 red[32][8];
   const int qi = threadIdx.x & 7, part = threadIdx.x >> 3;
   const int q = blockIdx.x * 8 + qi;  // output quad within the pass: (row, 4 outputs)
@@ -94,7 +175,7 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (row0 + r < B)
     for (int g = part; g < G; g += 32) {
-      const float4 v = *reinterpret_cast<const float4*>(partial + ((long)g * 32 + r) * Out + o);
+      const float4 v = *reinterpret_cast<const float4*>(partial + ((long)g * prow + r) * Out + o);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   red[part][qi] = s;
@@ -121,7 +202,9 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
 }
 
 static int fc_num_wgs(int nchunks) {
-  int g = 256;  // measured at B = 16: 256 workgroups 23.4 + 4.7 us (stream + reduce), 512: 25.4 + 6.5, 1024: 31.3 + 9.1
+  static const int g_env = [] { const char* e = getenv("DIM_FC_WGS"); return e ? atoi(e) : 0; }();
+  int g = g_env > 0 ? g_env : 256;  // measured at B = 16 (32-row kernel): 256 workgroups 23.4 + 4.7 us (stream + reduce), 512: 25.4 + 6.5, 1024: 31.3 + 9.1
+  if ((long)g * kFc16MaxChunks < nchunks) g = (nchunks + kFc16MaxChunks - 1) / kFc16MaxChunks;   // the 16-row kernel's LDS image of x
   if (g > nchunks) g = nchunks;
   return g;
 }
@@ -158,12 +241,18 @@ int dim_fc_fwd(const float* x, const float* w_packed, const float* bias, float* 
   a.x_bytes = (unsigned)((long)B * C * H * W * 4);
   a.w_bytes = (unsigned)((long)Out * C * H * W * 4);
   hipStream_t st = as_stream(stream);
+  if (B <= 16) {   // the refinement loop's batch: 16-row MFMA tiles, activations staged once per workgroup (fc_stream16_kernel)
+    a.row0 = 0;
+    hipLaunchKernelGGL(fc_stream16_kernel, dim3(G, Out / 256), dim3(256), (size_t)a.chunks_per_wg * 16 * kFc16Ldk * sizeof(float), st, a);
+    hipLaunchKernelGGL(fc_reduce_kernel, dim3(ceil_div((long)B * (Out / 4), 8)), dim3(256), 0, st, workspace, bias, y, G, B, 0, Out, slope, 16);
+    return check_launch("fc_fwd");
+  }
   for (int row0 = 0; row0 < B; row0 += 32) {  // 32 rows per pass (one MFMA row tile); the weights stream once per pass
     a.row0 = row0;
     hipLaunchKernelGGL(fc_stream_kernel, dim3(G, Out / 256), dim3(256), 0, st, a);
     const int rows = B - row0 < 32 ? B - row0 : 32;
     hipLaunchKernelGGL(fc_reduce_kernel, dim3(ceil_div((long)rows * (Out / 4), 8)), dim3(256), 0, st, workspace, bias, y, G, B, row0, Out,
-                       slope);
+                       slope, 32);
   }
   return check_launch("fc_fwd");
 }

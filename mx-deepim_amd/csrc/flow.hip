@@ -9,6 +9,35 @@
 
 namespace dim {
 
+// one pixel of flow_kernel (gpu_flow_kernel.cu:32-69), arithmetic as written there
+__device__ __forceinline__ void depth_flow_pixel(float d, int w, int h, const float* __restrict__ kt, const float* __restrict__ tgt_b,
+                                                 float i0, float i1, float i2, float i3, float i4, float i5, int H, int W, float& fh,
+                                                 float& fw, float& va) {
+  // no FMA contraction: the CUDA reference compiles these as written only if nvcc does not fuse;
+  // fusing changes results by <= 1 ulp, the oracle comparison tolerates that on `flow` and the
+  // tests exclude pixels within 1e-6 of the 3e-3 / bounds predicates.
+  float x = (w * i0 + h * i1 + i2) * d;
+  float y = (w * i3 + h * i4 + i5) * d;
+  float z = d;
+  fh = 0.f; fw = 0.f; va = 0.f;
+  if (d > 1E-3) {
+    float xp = x * kt[0] + y * kt[1] + z * kt[2] + kt[3];
+    float yp = x * kt[4] + y * kt[5] + z * kt[6] + kt[7];
+    float zp = (float)((double)(x * kt[8] + y * kt[9] + z * kt[10] + kt[11]) + 1E-15);
+    float wp = xp / zp, hp = yp / zp;
+    int wi = (int)round((double)wp), hi = (int)round((double)hp);
+    if (wp >= 0 && wp <= W - 1 && hp >= 0 && hp <= H - 1) {
+      float dt = tgt_b[(long)hi * W + wi];
+      if (fabsf(zp - dt) < 3E-3) {
+        fh = hp - h;
+        fw = wp - w;
+        va = 1.f;
+      }
+    }
+  }
+}
+
+// one thread per pixel (any W)
 __global__ __launch_bounds__(256) void depth_flow_kernel(const float* __restrict__ depth_src, const float* __restrict__ depth_tgt,
                                                          const float* __restrict__ KT, float i0, float i1, float i2, float i3,
                                                          float i4, float i5, int H, int W, float* __restrict__ flow,
@@ -18,35 +47,37 @@ __global__ __launch_bounds__(256) void depth_flow_kernel(const float* __restrict
   if (w >= W) return;
   const long plane = (long)H * W;
   const long index = (long)b * plane + (long)h * W + w;
-  const float* kt = KT + 12 * b;
-  const float d = depth_src[index];
-  // no FMA contraction: the CUDA reference compiles these as written only if nvcc does not fuse;
-  // fusing changes results by <= 1 ulp, the oracle comparison tolerates that on `flow` and the
-  // tests exclude pixels within 1e-6 of the 3e-3 / bounds predicates.
-  float x = (w * i0 + h * i1 + i2) * d;
-  float y = (w * i3 + h * i4 + i5) * d;
-  float z = d;
-  float fh = 0.f, fw = 0.f, va = 0.f;
-  if (d > 1E-3) {
-    float xp = x * kt[0] + y * kt[1] + z * kt[2] + kt[3];
-    float yp = x * kt[4] + y * kt[5] + z * kt[6] + kt[7];
-    float zp = (float)((double)(x * kt[8] + y * kt[9] + z * kt[10] + kt[11]) + 1E-15);
-    float wp = xp / zp, hp = yp / zp;
-    int wi = (int)round((double)wp), hi = (int)round((double)hp);
-    if (wp >= 0 && wp <= W - 1 && hp >= 0 && hp <= H - 1) {
-      float dt = depth_tgt[(long)b * plane + (long)hi * W + wi];
-      if (fabsf(zp - dt) < 3E-3) {
-        fh = hp - h;
-        fw = wp - w;
-        va = 1.f;
-      }
-    }
-  }
+  float fh, fw, va;
+  depth_flow_pixel(depth_src[index], w, h, KT + 12 * b, depth_tgt + (long)b * plane, i0, i1, i2, i3, i4, i5, H, W, fh, fw, va);
   flow[((long)b * 2 + 0) * plane + (long)h * W + w] = fh;
   flow[((long)b * 2 + 1) * plane + (long)h * W + w] = fw;
   valid[index] = va;
 }
 
+// W % 4 == 0 and 16-byte aligned planes: one thread per four consecutive pixels -- one 16-byte load of the source depth, three
+// 16-byte stores (the one-pixel-per-thread form moved 4 bytes per lane and instruction and ran at 3.7 TB/s of its 6.1 MB per pair);
+// the target-depth gather stays one dword per pixel (it lands within a few rows of the source pixel: cache hits)
+__global__ __launch_bounds__(256) void depth_flow_quad_kernel(const float* __restrict__ depth_src, const float* __restrict__ depth_tgt,
+                                                              const float* __restrict__ KT, float i0, float i1, float i2, float i3,
+                                                              float i4, float i5, int H, int W, float* __restrict__ flow,
+                                                              float* __restrict__ valid) {
+  const int b = blockIdx.y;
+  const long plane = (long)H * W;
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // quad index inside the sample
+  const long pix = 4 * q;
+  if (pix >= plane) return;
+  const int h = (int)(pix / W), w0 = (int)(pix - (long)h * W);
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f d4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(depth_src + (long)b * plane + pix));
+  const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+  float fh[4], fw[4], va[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    depth_flow_pixel(d[k], w0 + k, h, KT + 12 * b, depth_tgt + (long)b * plane, i0, i1, i2, i3, i4, i5, H, W, fh[k], fw[k], va[k]);
+  __builtin_nontemporal_store((v4f){fh[0], fh[1], fh[2], fh[3]}, reinterpret_cast<v4f*>(flow + ((long)b * 2 + 0) * plane + pix));
+  __builtin_nontemporal_store((v4f){fw[0], fw[1], fw[2], fw[3]}, reinterpret_cast<v4f*>(flow + ((long)b * 2 + 1) * plane + pix));
+  __builtin_nontemporal_store((v4f){va[0], va[1], va[2], va[3]}, reinterpret_cast<v4f*>(valid + (long)b * plane + pix));
+}
 
 // Test-time flow error (reference deepim/core/tester.py:500-512 accumulation, :719-736 calc_EPE_one_pair, :706-716 the
 // [flow, visible, bg] list of par_generate_gt):  point_diff = sqrt((gt0 - pred0)^2 + (gt1 - pred1)^2) with the prediction
@@ -106,8 +137,13 @@ extern "C" int dim_depth_to_flow(const float* depth_src, const float* depth_tgt,
                                  int W, float* flow, float* valid, void* stream) {
   if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(depth_src && depth_tgt && KT && Kinv9 && flow && valid, "null pointer");
-  hipLaunchKernelGGL(depth_flow_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, as_stream(stream), depth_src, depth_tgt, KT,
-                     Kinv9[0], Kinv9[1], Kinv9[2], Kinv9[3], Kinv9[4], Kinv9[5], H, W, flow, valid);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (W % 4 == 0 && al16(depth_src) && al16(flow) && al16(valid))
+    hipLaunchKernelGGL(depth_flow_quad_kernel, dim3(ceil_div((long)H * W / 4, 256), B), dim3(256), 0, as_stream(stream), depth_src, depth_tgt,
+                       KT, Kinv9[0], Kinv9[1], Kinv9[2], Kinv9[3], Kinv9[4], Kinv9[5], H, W, flow, valid);
+  else
+    hipLaunchKernelGGL(depth_flow_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, as_stream(stream), depth_src, depth_tgt, KT,
+                       Kinv9[0], Kinv9[1], Kinv9[2], Kinv9[3], Kinv9[4], Kinv9[5], H, W, flow, valid);
   return check_launch("depth_to_flow");
 }
 

@@ -160,6 +160,37 @@ def test_depth_to_flow_vs_oracle_and_reference(ops, golden_dir):
         assert both.sum() > 100
 
 
+def test_depth_to_flow_quad_and_pixel_kernels_agree(ops, golden_dir):
+    """dim_depth_to_flow takes four pixels per thread when W % 4 == 0 and the planes are 16-byte aligned, one pixel per thread otherwise:
+    the same bits either way (a source plane placed 4 bytes off alignment forces the one-pixel form), and at 480 x 640"""
+    g = np.load(os.path.join(golden_dir, "flow_golden.npz"))
+    K = g["K"]
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    n = len(g["depth_src"])
+    KT = np.zeros((n, 3, 4), dtype=np.float32)
+    for i in range(n):
+        R, t = ose3.calc_se3(g["pose_src"][i], g["pose_tgt"][i])
+        KT[i] = np.dot(K, np.concatenate([R, t.reshape(3, 1)], axis=1)).astype(np.float32)
+    ds, dt = cu(g["depth_src"][:, None]), cu(g["depth_tgt"][:, None])
+    f_quad, v_quad = ops.depth_to_flow(ds, dt, cu(KT), Kinv)
+    buf = torch.zeros(ds.numel() + 1, device=DEV)
+    ds_off = buf[1:].view(ds.shape)
+    ds_off.copy_(ds)
+    assert ds_off.data_ptr() % 16 == 4
+    f_pix, v_pix = ops.depth_to_flow(ds_off, dt, cu(KT), Kinv)
+    assert torch.equal(f_quad, f_pix) and torch.equal(v_quad, v_pix) and v_quad.sum() > 1000
+    # full size: a plane of the batch tiled up to 480 x 640 (the quad kernel's h / w decode at the real width)
+    big_s = ds[:2].repeat(1, 1, 4, 4).contiguous()
+    big_t = dt[:2].repeat(1, 1, 4, 4).contiguous()
+    assert big_s.shape[2:] == (480, 640)
+    fq, vq = ops.depth_to_flow(big_s, big_t, cu(KT[:2]), Kinv)
+    buf = torch.zeros(big_s.numel() + 1, device=DEV)
+    off = buf[1:].view(big_s.shape)
+    off.copy_(big_s)
+    fp, vp = ops.depth_to_flow(off, big_t, cu(KT[:2]), Kinv)
+    assert torch.equal(fq, fp) and torch.equal(vq, vp)
+
+
 def test_depth_to_flow_empty_and_zero_depth(ops):
     z = torch.zeros((2, 1, 48, 64), device=DEV)
     KT = cu(np.tile(np.eye(3, 4, dtype=np.float32), (2, 1, 1)))
