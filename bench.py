@@ -119,7 +119,8 @@ def encoder_roofline(net, b, test_iter, profile_steps):
             net.head()
     torch.cuda.synchronize()
     per_kernel = {}
-    TILE_SYM = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 128, 2, 4", 5: "128, 256, 2, 4"}
+    TILE_SYM = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 128, 2, 4", 5: "128, 256, 2, 4", 6: "160, 128, 1, 4",
+                7: "96, 128, 1, 4"}
     for name, evs in events.items():
         info = net.layer_info[name]
         for ev in evs:

@@ -236,6 +236,7 @@ struct WGemmArgs {
   int G, BM, BN, tile;  // workgroups of the GEMM launch, its tile shape and id
   int MT;               // row tiles
   int plane_major;      // item order, see wcur_decode
+  int dbg_plain;        // timing-only experiment: every flush a plain store (wrong sums for shared items)
 };
 int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile);
 // zeroed = the shared tiles have been zeroed already (by the transform kernel that ran before): no separate zero launch

@@ -1777,11 +1777,25 @@ int dim_conv_auto_plan(long M, int Cout, int nchunks, int cin, int* tile, int* s
 }
 
 // workgroup tile of a Winograd layer's plane GEMMs (wino_gemm.hip): 5 = 128 rows x 256 output channels (V is streamed once per 256
-// channels: conv3, conv3_1, conv4_1), 4 = 128 x 128 (conv2: Cout = 128), 3 = 64 x 64 for the small maps.  DIM_WINO_BN256=0 keeps the
-// 128 x 128 tile everywhere (A/B timing).
+// channels: conv3, conv3_1, conv4_1), 4 = 128 x 128 (conv2: Cout = 128); for the few-row layers (under 1024 tile rows: conv5 .. conv6_1)
+// the tile that wastes the fewest MFMA cycles on padded rows -- 6 = 160 x 128 (conv5, conv5_1: 320 rows at 16 pairs), 7 = 96 x 128
+// (conv6_1: 96 rows), 3 = 64 x 64 -- weighted by what each reaches of the matrix peak (measured: 0.54 / 0.70 / 0.74).
+// DIM_WINO_BN256=0 keeps the 128 x 128 tile everywhere, DIM_WINO_FEWROW=0 the 64 x 64 tile on the few-row layers (A/B timing).
 int dim_winograd_gemm_tile(int Cout, long tiles) {
   static const int bn256 = [] { const char* e = getenv("DIM_WINO_BN256"); return e ? atoi(e) : 1; }();
-  if (tiles < 1024 || Cout % 128) return 3;
+  static const int fewrow = [] { const char* e = getenv("DIM_WINO_FEWROW"); return e ? atoi(e) : 1; }();
+  if (Cout % 128) return 3;
+  if (tiles < 1024) {
+    if (!fewrow) return 3;
+    const struct { int tile, bm; double eff; } cand[3] = {{3, 64, 0.54}, {7, 96, 0.70}, {6, 160, 0.74}};
+    int best = 3;
+    double best_cost = 1e30;
+    for (const auto& c : cand) {
+      const double cost = (double)((tiles + c.bm - 1) / c.bm * c.bm) / c.eff;
+      if (cost < best_cost) { best_cost = cost; best = c.tile; }
+    }
+    return best;
+  }
   return (Cout % 256 == 0 && bn256) ? 5 : 4;
 }
 

@@ -49,15 +49,20 @@ __device__ __forceinline__ void wcur_advance(WCur& c, const WGemmArgs& a) {
 }
 // BN = 256 (tile 5): every wave owns a 64 x 64 block = four accumulators (64 registers) and twice the B fragments, so it is built
 // for two waves per SIMD = ONE 8-wave workgroup per CU; V is then read once for 256 output channels instead of once per 128.
+// Few-row layers (round 4: conv5 / conv5_1 with T = 320 tile rows at 16 pairs, conv6_1 with T = 96): BM = 160 or 96 rows x 128 columns on
+// FOUR waves, every wave one 32-column strip of ALL the rows (TM = 5 or 3 accumulators).  The 64 x 64 tile they ran on does 16 MFMAs
+// per wave between two barriers (0.54 of the peak: the staging, the barrier and the fragment reads of a chunk are the same whatever the
+// tile holds) and pads 96 rows to 128; these do 80 / 48, with no row padding at 320 / 96 rows.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN == 256 ? 2 : 4, 8))) void wino_gemm_kernel(WGemmArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN == 256 || BM == 160 ? 2 : (BM == 96 ? 3 : 4), 8))) void wino_gemm_kernel(WGemmArgs a) {
   constexpr int BK = 32;
   constexpr int NT = WM * WN * 64;
   constexpr int RP = NT / 8;   // rows staged per pass (8 threads x float4 = one 32-float row)
   constexpr int LDK = BK + 4;  // conflict-free for ds_write_b128 staging and ds_read_b128 fragments (see conv.hip)
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
-  static_assert(BM / RP == 2, "two staging loads per thread");
+  constexpr int NSTG = BM / RP;  // staging loads per thread and chunk
+  static_assert(BM % RP == 0 && NSTG >= 2 && NSTG <= 5, "two to five staging loads per thread");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;  // [2][BM][LDK]
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN
 
   const int RS = a.P * a.K;  // V row stride (floats)
   const int a_voff0 = (srow * RS + q * 4) * 4;
-  const int a_voff1 = a_voff0 + RP * RS * 4;
+  const int a_vstep = RP * RS * 4;  // next staging pass: RP rows further down
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V), 0, a.v_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.U), 0, a.u_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, a.m_bytes, 0x00020000);
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN
   // three cursors into the chunk list: L = next A chunk to load (runs two ahead), Bc = next B fragments (one ahead), C = compute
   WCur L = wcur_decode(c_begin, a), Bc = L, C = L;
 
-  float4 ra0, ra1;  // staging registers of the A chunk (named: arrays ended up in scratch)
+  float4 ra0, ra1, ra2, ra3, ra4;  // staging registers of the A chunk (named: arrays ended up in scratch); NSTG of them are live
   // rows past T read as zeros through the descriptor's range check (offset 0xFFFFFFFF); so does every load past the range's end.
   // The scalar offset is NOT range-checked, which is fine: it is only ever added to an in-range or a rejected vector offset.
 #define W_LOAD_CHUNK(PF_OK)                                                            \
@@ -95,7 +100,10 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN
     const int mb = L.mt * BM;                                                          \
     const int soff = (int)((unsigned)(mb * RS + L.p * a.K + L.ch * BK) * 4u);          \
     ra0 = buf_load16_nt(rv, (pf && mb + srow < a.T) ? a_voff0 : -1, soff);             \
-    ra1 = buf_load16_nt(rv, (pf && mb + srow + RP < a.T) ? a_voff1 : -1, soff);        \
+    ra1 = buf_load16_nt(rv, (pf && mb + srow + RP < a.T) ? a_voff0 + a_vstep : -1, soff);        \
+    if constexpr (NSTG > 2) ra2 = buf_load16_nt(rv, (pf && mb + srow + 2 * RP < a.T) ? a_voff0 + 2 * a_vstep : -1, soff); \
+    if constexpr (NSTG > 3) ra3 = buf_load16_nt(rv, (pf && mb + srow + 3 * RP < a.T) ? a_voff0 + 3 * a_vstep : -1, soff); \
+    if constexpr (NSTG > 4) ra4 = buf_load16_nt(rv, (pf && mb + srow + 4 * RP < a.T) ? a_voff0 + 4 * a_vstep : -1, soff); \
     wcur_advance(L, a);                                                                \
   }
 #define W_STORE_CHUNK(BUF)                                                             \
@@ -103,6 +111,9 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN
     float* dA = sA + (BUF) * BM * LDK;                                                 \
     *reinterpret_cast<float4*>(dA + srow * LDK + q * 4) = ra0;                         \
     *reinterpret_cast<float4*>(dA + (srow + RP) * LDK + q * 4) = ra1;                  \
+    if constexpr (NSTG > 2) *reinterpret_cast<float4*>(dA + (srow + 2 * RP) * LDK + q * 4) = ra2; \
+    if constexpr (NSTG > 3) *reinterpret_cast<float4*>(dA + (srow + 3 * RP) * LDK + q * 4) = ra3; \
+    if constexpr (NSTG > 4) *reinterpret_cast<float4*>(dA + (srow + 4 * RP) * LDK + q * 4) = ra4; \
   }
 
   f32x16 acc[TM][TN];
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN
       int ov = o_voff, orow = o_row; /* opaque copies: keeps the 32 store offsets from being hoisted out of the K loop */ \
       asm volatile("" : "+v"(ov), "+v"(orow));                                                                         \
       const int soff = (int)((unsigned)(mb * ldc + cb) * 4u);                                                          \
-      const bool plain = whole && item_end;                                                                            \
+      const bool plain = (whole && item_end) || a.dbg_plain;                                                           \
       _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                               \
           const int dr = 32 * i + (r & 3) + 8 * (r >> 2);                                                              \
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN
 // zero the output tile of every item that two workgroups share (only when the transform kernel in front did not do it)
 __global__ __launch_bounds__(256) void wino_gemm_zero_kernel(WGemmArgs a) { wino_gemm_zero_tile(a, blockIdx.x + 1); }
 
+static int g_wino_cus = 0;  // compute units of the device (set with the first occupancy query)
 template <int BM, int BN, int WM, int WN>
 static int wino_gemm_slots() {
   // as many workgroups as are resident at once (occupancy x CUs)
@@ -234,15 +246,17 @@ static int wino_gemm_slots() {
                                                        WM * WN * 64, 2 * BM * 36 * sizeof(float));
     if (e != hipSuccess || cus <= 0 || occ <= 0) return set_err(DIM_ERR_LAUNCH, "winograd gemm occupancy query: %s", hipGetErrorString(e));
     slots = cus * occ;
+    g_wino_cus = cus;
   }
   return slots;
 }
 
-// tile: 5 = 128x256 (8 waves, 64x64 per wave), 4 = 128x128 (8 waves), anything else = 64x64 (4 waves)
+// tile: 5 = 128x256 (8 waves, 64x64 per wave), 4 = 128x128 (8 waves), 6 = 160x128 and 7 = 96x128 (4 waves, every wave a 32-column strip
+// of all the rows: the few-row layers), anything else = 64x64 (4 waves)
 int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile) {
   if (tile == 5 && Cout % 256 != 0) tile = 4;
-  if ((tile != 4 && tile != 5) || Cout % 128 != 0) tile = 3;
-  const int BM = tile == 3 ? 64 : 128, BN = tile == 5 ? 256 : BM;
+  if ((tile < 4 || tile > 7) || Cout % 128 != 0) tile = 3;
+  const int BM = tile == 3 ? 64 : tile == 6 ? 160 : tile == 7 ? 96 : 128, BN = tile == 5 ? 256 : tile == 3 ? 64 : 128;
   DIM_REQUIRE(K % 32 == 0 && Cout % BN == 0 && T > 0, "winograd gemm: K %% 32 == 0 and Cout %% 64 == 0 required");
   const long MT = (T + BM - 1) / BM;
   const long items = MT * (Cout / BN) * P;
@@ -269,13 +283,21 @@ int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, in
   a.d_MT = make_fastdiv((unsigned)MT);
   static const int order = getenv("DIM_WINO_PLANE_MAJOR") ? atoi(getenv("DIM_WINO_PLANE_MAJOR")) : 1;  // A/B switch (0 = first version)
   a.plane_major = order;
+  static const int dbg_plain = getenv("DIM_WINO_DBG_PLAIN") ? atoi(getenv("DIM_WINO_DBG_PLAIN")) : 0;  // timing only: WRONG sums
+  a.dbg_plain = dbg_plain;
   a.BM = BM;
   a.BN = BN;
   a.tile = tile;
   // never more workgroups than items: every range is then at least one item long and an item is shared by at most two workgroups
-  const int slots = tile == 5 ? wino_gemm_slots<128, 256, 2, 4>() : tile == 4 ? wino_gemm_slots<128, 128, 2, 4>() : wino_gemm_slots<64, 64, 2, 2>();
+  const int slots = tile == 5 ? wino_gemm_slots<128, 256, 2, 4>() : tile == 4 ? wino_gemm_slots<128, 128, 2, 4>()
+                  : tile == 6 ? wino_gemm_slots<160, 128, 1, 4>() : tile == 7 ? wino_gemm_slots<96, 128, 1, 4>() : wino_gemm_slots<64, 64, 2, 2>();
   if (slots <= 0) return slots;
   a.G = items < slots ? (int)items : slots;
+  // fewer items than slots: the hardware deals workgroups to the CUs one by one, so 288 workgroups on 256 CUs leave 32 CUs with twice the
+  // work of the others (conv5_1 / conv6_1 on the few-row tiles: 90 / 103 us against 70 / 107 on the 64 x 64 tile before this rule).  A
+  // whole number of workgroups per CU, each with a slightly longer range, balances them.  DIM_WINO_G_ROUND=0: off (A/B timing).
+  static const int g_round = getenv("DIM_WINO_G_ROUND") ? atoi(getenv("DIM_WINO_G_ROUND")) : 1;
+  if (g_round && g_wino_cus > 0 && a.G > g_wino_cus && a.G < slots) a.G = a.G / g_wino_cus * g_wino_cus;
   const long total = items * a.nch;
   a.per = (int)(total / a.G);
   a.rem = (int)(total % a.G);
@@ -289,6 +311,10 @@ int wino_gemm_run(const WGemmArgs& a, bool zeroed, hipStream_t st) {
     hipLaunchKernelGGL((wino_gemm_kernel<128, 256, 2, 4>), dim3(a.G), dim3(512), 2 * 128 * 36 * sizeof(float), st, a);
   else if (a.tile == 4)
     hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 4>), dim3(a.G), dim3(512), 2 * 128 * 36 * sizeof(float), st, a);
+  else if (a.tile == 6)
+    hipLaunchKernelGGL((wino_gemm_kernel<160, 128, 1, 4>), dim3(a.G), dim3(256), 2 * 160 * 36 * sizeof(float), st, a);
+  else if (a.tile == 7)
+    hipLaunchKernelGGL((wino_gemm_kernel<96, 128, 1, 4>), dim3(a.G), dim3(256), 2 * 96 * 36 * sizeof(float), st, a);
   else
     hipLaunchKernelGGL((wino_gemm_kernel<64, 64, 2, 2>), dim3(a.G), dim3(256), 2 * 64 * 36 * sizeof(float), st, a);
   return check_launch("winograd_gemm");

@@ -574,7 +574,8 @@ def test_conv3x3_winograd_vs_f64(hip_lib, shape, m):
     ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=1, padding=1), 0.1).permute(0, 2, 3, 1).numpy()
     xd = x.permute(0, 2, 3, 1).contiguous().to("cuda:0")
     wp = ops.winograd_pack_weight(w.to("cuda:0"), m=m)
-    for tile in ((3, 4, 5) if Cout % 256 == 0 else (3, 4)) if Cout % 128 == 0 else (3,):  # 5 = 128 x 256 workgroup tile
+    # 5 = 128 x 256 workgroup tile; 6 / 7 = 160 x 128 / 96 x 128 (the few-row layers: four waves, a 32-column strip of all rows each)
+    for tile in ((3, 4, 5, 6, 7) if Cout % 256 == 0 else (3, 4, 6, 7)) if Cout % 128 == 0 else (3,):
         y = ops.conv2d_fwd_winograd(xd, Cin, wp, b.to("cuda:0"), Cout, slope=0.1, tile=tile, m=m).cpu().numpy()
         err = np.abs(y - ref).max()
         assert err <= 1e-4 * np.abs(ref).max() + 2e-5, (tile, err)
@@ -603,7 +604,7 @@ def test_conv5x5s2_winograd_vs_f64(hip_lib, shape):
     ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=2), 0.1).permute(0, 2, 3, 1).numpy()
     xd = x.permute(0, 2, 3, 1).contiguous().to("cuda:0")
     wp = ops.winograd5x5s2_pack_weight(w.to("cuda:0"))
-    for tile in ((3, 4, 5) if Cout % 256 == 0 else (3, 4)) if Cout % 128 == 0 else (3,):
+    for tile in ((3, 4, 5, 6, 7) if Cout % 256 == 0 else (3, 4, 6, 7)) if Cout % 128 == 0 else (3,):
         y = ops.conv2d_fwd_winograd5x5s2(xd, Cin, wp, b.to("cuda:0"), Cout, slope=0.1, tile=tile).cpu().numpy()
         assert y.shape == ref.shape
         err = np.abs(y - ref).max()
@@ -772,7 +773,10 @@ def test_copy_add_rows_and_fill(hip_lib):
 
 
 @pytest.mark.parametrize("shape", [(2, 60, 80, 64, 128, 0), (1, 30, 40, 256, 512, 0), (2, 15, 20, 128, 64, 3), (1, 29, 37, 32, 64, 0),
-                                   (3, 9, 11, 96, 192, 4), (2, 8, 8, 64, 256, 5), (5, 16, 24, 32, 128, 0)])
+                                   (3, 9, 11, 96, 192, 4), (2, 8, 8, 64, 256, 5), (5, 16, 24, 32, 128, 0),
+                                   # the few-row GEMM tiles: 16 x (4 x 5) = 320 rows = two 160-row tiles (conv5 at 16 pairs), 7 x 20 = 140
+                                   # rows (one partly empty tile), 96-row tiles with 100 and 96 rows
+                                   (16, 30, 40, 64, 512, 6), (7, 30, 40, 32, 128, 6), (5, 30, 40, 32, 256, 7), (16, 16, 20, 64, 128, 7)])
 def test_conv_winograd3x3s2_vs_f64(hip_lib, shape, monkeypatch):
     """3x3 / stride-2 / pad-1 layers through their phase images (minimal filtering: F(4,1) on the even, F(4,2) on the odd phase; 81 plane
     GEMMs) vs torch-CPU float64 and vs the direct kernel: odd and even maps (tiles hanging over both edges), padded channel strides, an
@@ -805,7 +809,11 @@ def test_conv_winograd3x3s2_vs_f64(hip_lib, shape, monkeypatch):
     if N >= 3:   # the batch in slices of two images through the same workspace
         monkeypatch.setenv("DIM_WINO_MAX_SLICE", "2")
         y2 = ops.conv2d_fwd_winograd3x3s2(xd, Cin, wp, None, Cout, slope=1.0, tile=tile)
-        assert torch.equal(y2, y0)
+        if N * Cout <= 1024:
+            assert torch.equal(y2, y0)
+        else:   # more (tile, plane) items than resident workgroups: the stream-K ranges cut items at other K chunks in a slice than in
+            #     the whole batch, so the two partial sums of a cut item differ in the last bit
+            assert (y2 - y0).abs().max().item() <= 2e-6 * y0.abs().max().item()
 
 
 @pytest.mark.parametrize("shape", [(16, 256, 1024, 8, 10), (1, 256, 1024, 8, 10), (17, 256, 1024, 8, 10), (32, 70, 32, 3, 5), (3, 64, 48, 1, 1)])

@@ -23,9 +23,9 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 y = torch.empty((B, h, w, cout), device="cuda:0")
-for m in (2, 4):
+for m in (4,):
     wp = ops.winograd_pack_weight(wt, m=m)
-    for tile in (3, 4):
+    for tile in (4, 5, 6, 7):
         ev = []
         ops.conv2d_fwd_winograd(x, c, wp, bias, cout, tile=tile, out=y, workspace=ws, m=m, events=ev); torch.cuda.synchronize()
         parts = " ".join("%s %.1f us" % (t, 1e3 * a.elapsed_time(b)) for t, a, b in ev)

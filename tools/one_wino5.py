@@ -24,7 +24,7 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 y = torch.empty((B, ho, wo, cout), device="cuda:0")
-for tile in (3, 4):
+for tile in (4, 5, 6, 7):
     ev = []
     ops.conv2d_fwd_winograd5x5s2(x, c, wp, bias, cout, tile=tile, out=y, workspace=ws, events=ev); torch.cuda.synchronize()
     parts = " ".join("%s %.1f us" % (t, 1e3 * a.elapsed_time(b)) for t, a, b in ev)
