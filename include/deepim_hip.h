@@ -178,7 +178,9 @@ int dim_point_clouds(const float* table, const int* table_off, const int* idx, c
  * Mesh table in HBM: verts (sumV,3), uvs (sumV,2), faces (sumF,3 int32, indices local to the mesh),
  * mesh_table (C,4 int32) = {vert_off, nvert, face_off, nface}; textures = concatenated uint8 RGB images
  * (row 0 = top of texture_map.png), tex_table (C,3 int32) = {byte_off, Ht, Wt}.
- * class_index (B int32) in [0, n_classes), poses (B,3,4).  workspace: dim_raster_workspace_bytes() (z-buffer, projected vertices,
+ * class_index (B int32) in [0, n_classes), poses (B,3,4).  workspace: dim_raster_workspace_bytes(), 8-byte aligned (16 for the fast
+ * resolve); its first 256 bytes are a header that remembers "the z-buffer behind me is clear" from one render to the next (no clear
+ * pass): the OWNER ZEROES THOSE 256 BYTES when the memory is allocated or has been used for anything else.  (header, z-buffer, projected vertices,
  * covered-pixel list).  status (B int32, may be NULL): DIM_STATUS_BAD_CLASS / DIM_STATUS_BAD_FACE are OR-ed in.
  * Outputs (each may be NULL): image (B,3,H,W) = RGB - plane_means3 (the next iteration's image_rendered
  * blob), depth (B,1,H,W) metres, mask (B,1,H,W) = depth > mask_thr, bgr (B,H,W,3) as Render_Py.render
@@ -200,6 +202,17 @@ int dim_raster_render_lit(const float* verts, const float* normals, const float*
                           const float* light_pos, const float* light_int, float brightness_ratio, const float* plane_means3,
                           float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox, int* status,
                           void* stream);
+/* The same render -- unlit when normals is NULL -- for a caller that re-renders into planes it knows: clean_bbox (B,4) {min x, max x,
+ * min y, max y} (the bbox array a previous render into the SAME image / depth / mask / bgr planes returned; a different array than
+ * `bbox`) promises that those planes hold background (image = -plane_means, depth = mask = bgr = 0) outside the box; pixels outside it
+ * that this render does not cover are then not written again (the refinement loop's 2nd and 3rd render: tester.py:563-590 re-renders
+ * the same object a few pixels away).  NULL = dim_raster_render / dim_raster_render_lit. */
+int dim_raster_render_dirty(const float* verts, const float* normals, const float* uvs, const int* faces, const int* mesh_table,
+                            int n_classes, int vmax, int fmax, const unsigned char* textures, const int* tex_table, const int* class_index,
+                            const float* poses, const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear,
+                            const float* light_pos, const float* light_int, float brightness_ratio, const float* plane_means3,
+                            float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox, int* status,
+                            const int* clean_bbox, void* stream);
 
 /* deepim/core/tester.py:204-225 (and batch_updater_py_multi.py:233-255): light_pos[b] = 0.5*(dx,dy,dz) + (tx,-ty,-tz) of poses[b]. */
 int dim_modelnet_light_position(const float* poses, float dx, float dy, float dz, float* light_pos, int B, void* stream);

@@ -66,13 +66,46 @@ struct MeshRef {
   int vert_off, nvert, face_off, nface;
 };
 
+// First 256 bytes of the workspace.  `magic` + the geometry say: "the z-buffer behind this header holds only clear keys" -- every render
+// leaves it that way (the pass that consumes a covered key resets it), so the next render of the same geometry needs no clear pass
+// (39 MB of stores per 16 frames, and a launch).  Anything else in these words (a fresh or recycled allocation whose first 256 bytes
+// the owner zeroed, another batch size on the same memory) makes the vertex pass clear the whole z-buffer first.
+struct ResolveHdr {
+  unsigned count;  // covered pixels appended so far
+  unsigned magic0, magic1;
+  int B, H, W, vmax;
+  unsigned pad[57];
+};
+constexpr unsigned kZbMagic0 = 0x44494d5au, kZbMagic1 = 0x62756621u;
+__device__ __forceinline__ bool zbuf_known_clear(const ResolveHdr* hdr, int B, int H, int W, int vmax) {
+  return hdr->magic0 == kZbMagic0 && hdr->magic1 == kZbMagic1 && hdr->B == B && hdr->H == H && hdr->W == W && hdr->vmax == vmax;
+}
+
 // scr[b][i] = (u, v, Zc) for vertex i of the sample's mesh
 __global__ __launch_bounds__(256) void raster_vertex_kernel(const float* __restrict__ verts, const int* __restrict__ mesh_table,
                                                             const int* __restrict__ class_index, const float* __restrict__ poses,
                                                             float fx, float fy, float cx, float cy, int vmax, int n_classes,
-                                                            int* __restrict__ status, float* __restrict__ scr) {
+                                                            int* __restrict__ status, float* __restrict__ scr, ResolveHdr* __restrict__ hdr,
+                                                            unsigned long long* __restrict__ zbuf, int B, int H, int W, int* __restrict__ bbox,
+                                                            int wide) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // ---- what the separate clear / init launches did.  (The header is only READ here -- every block must see the same answer; the
+  // triangle pass, which runs when all of these blocks are done, stamps it.)
+  if (!zbuf_known_clear(hdr, B, H, W, vmax)) {
+    const long n = (long)B * H * W, stride = (long)gridDim.x * gridDim.y * blockDim.x;
+    const long k0 = ((long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    if (wide) {   // 16-byte stores (the workspace is 16-byte aligned, B H W even)
+      ulonglong2* z2 = reinterpret_cast<ulonglong2*>(zbuf);
+      for (long k = k0; k < n / 2; k += stride) z2[k] = make_ulonglong2(0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull);
+    } else {
+      for (long k = k0; k < n; k += stride) zbuf[k] = 0xFFFFFFFFFFFFFFFFull;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (b == 0) hdr->count = 0;                                                          // empty covered-pixel list
+    if (bbox) { bbox[4 * b + 0] = W; bbox[4 * b + 1] = -1; bbox[4 * b + 2] = H; bbox[4 * b + 3] = -1; }   // empty box (one-pass resolve)
+  }
   const int cls = class_index[b];
   if ((unsigned)cls >= (unsigned)n_classes) {  // no such mesh: the sample renders as background and says so
     if (i == 0 && status) atomicOr(status + b, DIM_STATUS_BAD_CLASS);
@@ -195,9 +228,13 @@ __global__ __launch_bounds__(256) void raster_tri_kernel(const int* __restrict__
                                                          const int* __restrict__ class_index, const float* __restrict__ scr,
                                                          const float* __restrict__ verts, const float* __restrict__ poses, float fx,
                                                          float fy, float cx, float cy, int vmax, int H, int W, float znear, float zfar,
-                                                         int n_classes, unsigned long long* __restrict__ zbuf) {
+                                                         int n_classes, unsigned long long* __restrict__ zbuf, ResolveHdr* __restrict__ hdr,
+                                                         int B) {
   const int b = blockIdx.y;
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0 && f == 0) {   // the z-buffer was clear when this pass started; the resolve passes of this render restore that
+    hdr->magic0 = kZbMagic0; hdr->magic1 = kZbMagic1; hdr->B = B; hdr->H = H; hdr->W = W; hdr->vmax = vmax;
+  }
   const int cls = class_index[b];
   if ((unsigned)cls >= (unsigned)n_classes) return;
   const int* mt = mesh_table + 4 * cls;
@@ -375,17 +412,12 @@ __device__ __forceinline__ bool shade_pixel(const LitArgs& lit, const float* __r
 // appended to a compact list (one atomicAdd per wave).  The first version resolved in one pass with one thread per pixel: an object
 // covers 2-6 % of a 480x640 frame, so the edge set-up and the three dependent gathers ran on nearly empty waves (102 us per 16 frames
 // with the object in view against 23 us without).
-struct ResolveHdr {
-  unsigned count;  // covered pixels appended so far
-  unsigned pad[63];
-};
-
 __global__ __launch_bounds__(256) void raster_resolve_stream_kernel(const unsigned long long* __restrict__ zbuf, int H, int W, float pm0,
                                                                     float pm1, float pm2, float mask_thr, float* __restrict__ image,
                                                                     float* __restrict__ depth, float* __restrict__ mask,
                                                                     float* __restrict__ bgr, int4* __restrict__ wave_ext,
                                                                     int waves_per_sample, ResolveHdr* __restrict__ hdr,
-                                                                    unsigned* __restrict__ list) {
+                                                                    unsigned* __restrict__ list, const int* __restrict__ clean) {
   const int b = blockIdx.y;
   const int plane = H * W;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;  // quad index inside the image
@@ -393,6 +425,14 @@ __global__ __launch_bounds__(256) void raster_resolve_stream_kernel(const unsign
   const bool live = pix < plane;
   float z[4] = {0.f, 0.f, 0.f, 0.f};
   unsigned cov = 0;
+  // `clean` (B,4) {min x, max x, min y, max y}: the caller's promise that the output planes already hold background outside that box
+  // (the bbox the previous render into the same planes returned): a quad outside it with nothing covered is not written again
+  bool in_dirty = true;
+  if (clean && live) {
+    const int y = pix / W, x0 = pix - y * W;
+    const int* c = clean + 4 * b;
+    in_dirty = y >= c[2] && y <= c[3] && x0 + 3 >= c[0] && x0 <= c[1];
+  }
   if (live) {
     const ulonglong2* zp = reinterpret_cast<const ulonglong2*>(zbuf + (long)b * plane + pix);
     const ulonglong2 k01 = zp[0], k23 = zp[1];
@@ -404,17 +444,18 @@ __global__ __launch_bounds__(256) void raster_resolve_stream_kernel(const unsign
         cov |= 1u << k;
       }
     const long o = (long)b * plane + pix;
-    if (depth) *reinterpret_cast<float4*>(depth + o) = make_float4(z[0], z[1], z[2], z[3]);
-    if (mask)
+    const bool wr = in_dirty || cov != 0;
+    if (depth && wr) *reinterpret_cast<float4*>(depth + o) = make_float4(z[0], z[1], z[2], z[3]);
+    if (mask && wr)
       *reinterpret_cast<float4*>(mask + o) = make_float4(z[0] > mask_thr ? 1.f : 0.f, z[1] > mask_thr ? 1.f : 0.f, z[2] > mask_thr ? 1.f : 0.f,
                                                          z[3] > mask_thr ? 1.f : 0.f);
-    if (image) {  // background everywhere; pass 2 overwrites the covered pixels
+    if (image && wr) {  // background everywhere; pass 2 overwrites the covered pixels
       float* im = image + (long)b * 3 * plane + pix;
       *reinterpret_cast<float4*>(im) = make_float4(-pm0, -pm0, -pm0, -pm0);
       *reinterpret_cast<float4*>(im + plane) = make_float4(-pm1, -pm1, -pm1, -pm1);
       *reinterpret_cast<float4*>(im + 2 * (long)plane) = make_float4(-pm2, -pm2, -pm2, -pm2);
     }
-    if (bgr) {
+    if (bgr && wr) {
       float4* qd = reinterpret_cast<float4*>(bgr + o * 3);
       qd[0] = qd[1] = qd[2] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -470,9 +511,8 @@ __global__ __launch_bounds__(256) void raster_resolve_stream_kernel(const unsign
 
 // bbox[b] = (min x, max x, min y, max y) over the wave extents of sample b; (W, -1, H, -1) when the mask is empty, as raster_init_kernel
 // leaves it for the one-pass path
-__global__ __launch_bounds__(256) void raster_bbox_reduce_kernel(const int4* __restrict__ wave_ext, int waves_per_sample, int H, int W,
-                                                                 int* __restrict__ bbox) {
-  const int b = blockIdx.x;
+__device__ __forceinline__ void raster_bbox_reduce(const int4* __restrict__ wave_ext, int waves_per_sample, int H, int W,
+                                                   int* __restrict__ bbox, int b) {
   int lo = 0x7FFFFFFF, hi = -1, ylo = 0x7FFFFFFF, yhi = -1;
   for (int i = threadIdx.x; i < waves_per_sample; i += 256) {
     const int4 e = wave_ext[(long)b * waves_per_sample + i];
@@ -495,24 +535,32 @@ __global__ __launch_bounds__(256) void raster_bbox_reduce_kernel(const int4* __r
 }
 
 // ---- resolve, pass 2: one thread per LISTED pixel (full waves), grid-stride over the list whose length lives on the device
-template <bool LIT>
+// The last pass of a render.  SHADE = false: no colour output was asked for -- only the two duties below.
+//   * the first B blocks fold the wave extents of the stream pass into bbox[b] (was a launch of its own);
+//   * EVERY listed key is reset to "clear" by the thread that consumed it, so the z-buffer is clear again when the render ends and the
+//     next one needs no clear pass (ResolveHdr).
+template <bool LIT, bool SHADE>
 __global__ __launch_bounds__(256) void raster_resolve_shade_kernel(LitArgs lit, const float* __restrict__ uvs, const int* __restrict__ faces,
                                                                    const int* __restrict__ mesh_table,
                                                                    const unsigned char* __restrict__ tex, const int* __restrict__ tex_table,
                                                                    const int* __restrict__ class_index, const float* __restrict__ scr,
-                                                                   const unsigned long long* __restrict__ zbuf, int vmax, int H, int W,
+                                                                   unsigned long long* __restrict__ zbuf, int vmax, int H, int W,
                                                                    int tex_bilinear, float pm0, float pm1, float pm2,
                                                                    float* __restrict__ image, float* __restrict__ bgr,
                                                                    int* __restrict__ status, const ResolveHdr* __restrict__ hdr,
-                                                                   const unsigned* __restrict__ list) {
+                                                                   const unsigned* __restrict__ list, const int4* __restrict__ wave_ext,
+                                                                   int waves_per_sample, int B, int* __restrict__ bbox) {
+  if (bbox && (int)blockIdx.x < B) raster_bbox_reduce(wave_ext, waves_per_sample, H, W, bbox, (int)blockIdx.x);
   const unsigned n = hdr->count;
   const unsigned plane = (unsigned)(H * W);
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const unsigned e = list[i];
+    const unsigned long long key = zbuf[e];
+    zbuf[e] = 0xFFFFFFFFFFFFFFFFull;
+    if (!SHADE) continue;
     const int b = (int)(e / plane);
     const unsigned pix = e - (unsigned)b * plane;
     const int y = (int)(pix / (unsigned)W), x = (int)(pix - (unsigned)y * (unsigned)W);
-    const unsigned long long key = zbuf[e];
     const float z = __uint_as_float((unsigned)(key >> 32));
     float r = 0.f, g = 0.f, bl = 0.f;
     // (class_index was range-checked by the vertex pass: a sample with a bad class has no covered pixel)
@@ -537,7 +585,7 @@ template <bool LIT>
 __global__ __launch_bounds__(256) void raster_resolve_kernel(LitArgs lit, const float* __restrict__ uvs, const int* __restrict__ faces,
                                                              const int* __restrict__ mesh_table, const unsigned char* __restrict__ tex,
                                                              const int* __restrict__ tex_table, const int* __restrict__ class_index,
-                                                             const float* __restrict__ scr, const unsigned long long* __restrict__ zbuf,
+                                                             const float* __restrict__ scr, unsigned long long* __restrict__ zbuf,
                                                              int vmax, int H, int W, int tex_bilinear, float pm0, float pm1, float pm2,
                                                              float mask_thr, float* __restrict__ image, float* __restrict__ depth,
                                                              float* __restrict__ mask, float* __restrict__ bgr, int* __restrict__ bbox,
@@ -551,6 +599,7 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(LitArgs lit, const 
   if (in_img) {
     unsigned long long key = zbuf[(long)b * plane + (long)y * W + x];
     if (key != 0xFFFFFFFFFFFFFFFFull) {
+      zbuf[(long)b * plane + (long)y * W + x] = 0xFFFFFFFFFFFFFFFFull;   // leave the z-buffer clear (ResolveHdr)
       z = __uint_as_float((unsigned)(key >> 32));
       const bool ok = shade_pixel<LIT>(lit, uvs, faces, mesh_table, tex, tex_table, class_index[b], scr + (long)b * vmax * 3, b, x, y,
                                        (unsigned)(key & 0xFFFFFFFFu), z, tex_bilinear, r, g, bl);
@@ -625,36 +674,14 @@ __global__ void modelnet_light_kernel(const float* __restrict__ poses, float dx,
   light_pos[3 * b + 2] = (float)(0.5 * (double)dz - (double)P[11]);
 }
 
-__global__ __launch_bounds__(256) void zbuf_clear_kernel(unsigned long long* __restrict__ zbuf, long n, int wide) {
-  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (wide && i + 3 < n) {  // two 16-byte stores (wide = the workspace is 16-byte aligned); four 8-byte stores ran at 2.6 TB/s
-    const ulonglong2 ff = make_ulonglong2(0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull);
-    ulonglong2* p = reinterpret_cast<ulonglong2*>(zbuf + i);
-    p[0] = ff;
-    p[1] = ff;
-  } else {
-    for (int k = 0; k < 4; ++k)
-      if (i + k < n) zbuf[i + k] = 0xFFFFFFFFFFFFFFFFull;
-  }
-}
-
-// empty boxes + an empty covered-pixel list
-__global__ void raster_init_kernel(int* bbox, int n, int H, int W, ResolveHdr* hdr) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bbox && i < n) {
-    bbox[4 * i + 0] = W; bbox[4 * i + 1] = -1; bbox[4 * i + 2] = H; bbox[4 * i + 3] = -1;
-  }
-  if (i == 0) hdr->count = 0;
-}
-
 }  // namespace dim
 
 using namespace dim;
 
 extern "C" {
 
-// workspace layout: z-buffer (u64 per pixel) | projected vertices (3 floats each, padded to 256 B) | header (256 B) | covered-pixel list |
-// wave extents (one int4 per wave of the stream pass)
+// workspace layout: header (256 B, ResolveHdr) | z-buffer (u64 per pixel) | projected vertices (3 floats each, padded to 256 B) |
+// covered-pixel list | wave extents (one int4 per wave of the stream pass)
 static long raster_scr_bytes(int B, int vmax) { return ((long)B * vmax * 3 * 4 + 255) / 256 * 256; }
 static int raster_waves_per_sample(int H, int W) { return (int)(ceil_div((long)H * W / 4, 256) * 4); }   // workgroups of 256 quads x 4 waves
 
@@ -668,50 +695,56 @@ static int raster_render_impl(const float* verts, const float* normals, const fl
                               const int* class_index, const float* poses, const float* K9, int B, int H, int W, float znear, float zfar,
                               int tex_bilinear, const float* light_pos, const float* light_int, float ratio, const float* plane_means3,
                               float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox, int* status,
-                              void* stream) {
+                              const int* clean_bbox, void* stream) {
   if (B == 0) return DIM_OK;  // empty batch: nothing to do, pointers may be NULL
   DIM_REQUIRE(verts && uvs && faces && mesh_table && textures && tex_table && class_index && poses && K9 && workspace, "null pointer");
   DIM_REQUIRE(vmax > 0 && fmax > 0 && H > 0 && W > 0 && n_classes > 0, "bad sizes");
   DIM_REQUIRE((long)B * H * W < (1L << 32), "B * H * W must fit 32 bits (covered-pixel list entries)");
   DIM_REQUIRE(!image || plane_means3, "image output needs plane_means3");
+  DIM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "workspace must be 8-byte aligned");
   hipStream_t st = as_stream(stream);
   char* ws = reinterpret_cast<char*>(workspace);
-  unsigned long long* zbuf = reinterpret_cast<unsigned long long*>(ws);
-  float* scr = reinterpret_cast<float*>(ws + (long)B * H * W * 8);
-  ResolveHdr* hdr = reinterpret_cast<ResolveHdr*>(ws + (long)B * H * W * 8 + raster_scr_bytes(B, vmax));
-  unsigned* list = reinterpret_cast<unsigned*>(hdr + 1);
-  // z-buffer clear as a KERNEL, not hipMemsetAsync: inside a captured hipGraph the memset node was seen overlapping the
-  // resolve pass of the same replay (keys half overwritten -> face ids out of range -> memory fault on the 2nd replay)
+  ResolveHdr* hdr = reinterpret_cast<ResolveHdr*>(ws);
+  unsigned long long* zbuf = reinterpret_cast<unsigned long long*>(ws + sizeof(ResolveHdr));
+  float* scr = reinterpret_cast<float*>(ws + sizeof(ResolveHdr) + (long)B * H * W * 8);
+  unsigned* list = reinterpret_cast<unsigned*>(ws + sizeof(ResolveHdr) + (long)B * H * W * 8 + raster_scr_bytes(B, vmax));
   const long nkeys = (long)B * H * W;
-  hipLaunchKernelGGL(zbuf_clear_kernel, dim3(ceil_div(nkeys, 256 * 4)), dim3(256), 0, st, zbuf, nkeys,
-                     (int)((reinterpret_cast<uintptr_t>(workspace) & 15) == 0));
+  auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // No clear pass and no init launch (round 4): the z-buffer is clear when a render ends (the pass that consumes a key resets it) and
+  // the header in front of it says so; a header that does not match this call makes the vertex pass clear the z-buffer first.  (A
+  // clear by hipMemsetAsync was never an option: inside a captured hipGraph the memset node was seen overlapping the resolve pass.)
   hipLaunchKernelGGL(raster_vertex_kernel, dim3(ceil_div(vmax, 256), B), dim3(256), 0, st, verts, mesh_table, class_index, poses,
-                     K9[0], K9[4], K9[2], K9[5], vmax, n_classes, status, scr);
+                     K9[0], K9[4], K9[2], K9[5], vmax, n_classes, status, scr, hdr, zbuf, B, H, W, bbox,
+                     (int)(aligned16(workspace) && nkeys % 2 == 0));
   hipLaunchKernelGGL(raster_tri_kernel, dim3(ceil_div(fmax, 256), B), dim3(256), 0, st, faces, mesh_table, class_index, scr, verts, poses,
-                     K9[0], K9[4], K9[2], K9[5], vmax, H, W, znear, zfar, n_classes, zbuf);
-  hipLaunchKernelGGL(raster_init_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, bbox, B, H, W, hdr);
+                     K9[0], K9[4], K9[2], K9[5], vmax, H, W, znear, zfar, n_classes, zbuf, hdr, B);
   float p0 = plane_means3 ? plane_means3[0] : 0.f, p1 = plane_means3 ? plane_means3[1] : 0.f, p2 = plane_means3 ? plane_means3[2] : 0.f;
   LitArgs lit = {verts, normals, poses, light_pos, light_int, ratio, K9[0], K9[4], K9[2], K9[5], fmaxf(znear, kZClipMin)};
-  auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   // the two-pass resolve moves float4 / 2 x u64: every plane pointer (and the workspace) must be 16-byte aligned; anything else
   // takes the one-thread-per-pixel kernel
   if (W % 4 == 0 && aligned16(workspace) && aligned16(image) && aligned16(depth) && aligned16(mask) && aligned16(bgr)) {
-    // pass 1 streams the z-buffer once and finishes depth / mask / bbox / background; pass 2 colours the listed pixels on full waves
+    // pass 1 streams the z-buffer once and finishes depth / mask / background (only inside the caller's dirty box, if it names one) and
+    // lists the covered pixels; pass 2 folds the bbox, colours the listed pixels on full waves and resets their keys
     const int wps = raster_waves_per_sample(H, W);
     int4* wave_ext = bbox ? reinterpret_cast<int4*>(reinterpret_cast<char*>(list) + (long)B * H * W * 4) : nullptr;
     hipLaunchKernelGGL(raster_resolve_stream_kernel, dim3(ceil_div((long)H * W / 4, 256), B), dim3(256), 0, st, zbuf, H, W, p0, p1, p2,
-                       mask_thr, image, depth, mask, bgr, wave_ext, wps, hdr, list);
-    if (bbox) hipLaunchKernelGGL(raster_bbox_reduce_kernel, dim3(B), dim3(256), 0, st, wave_ext, wps, H, W, bbox);
-    if (image || bgr) {
-      const int grid = (int)(nkeys / 256 < 2048 ? (nkeys + 255) / 256 : 2048);
-      if (normals)
-        hipLaunchKernelGGL(raster_resolve_shade_kernel<true>, dim3(grid), dim3(256), 0, st, lit, uvs, faces, mesh_table, textures, tex_table,
-                           class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, image, bgr, status, hdr, list);
-      else
-        hipLaunchKernelGGL(raster_resolve_shade_kernel<false>, dim3(grid), dim3(256), 0, st, lit, uvs, faces, mesh_table, textures, tex_table,
-                           class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, image, bgr, status, hdr, list);
-    }
+                       mask_thr, image, depth, mask, bgr, wave_ext, wps, hdr, list, clean_bbox);
+    int grid = (int)(nkeys / 256 < 2048 ? (nkeys + 255) / 256 : 2048);
+    if (grid < B) grid = B;
+    if (!(image || bgr))
+      hipLaunchKernelGGL((raster_resolve_shade_kernel<false, false>), dim3(grid), dim3(256), 0, st, lit, uvs, faces, mesh_table, textures,
+                         tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, image, bgr, status, hdr, list, wave_ext,
+                         wps, B, bbox);
+    else if (normals)
+      hipLaunchKernelGGL((raster_resolve_shade_kernel<true, true>), dim3(grid), dim3(256), 0, st, lit, uvs, faces, mesh_table, textures,
+                         tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, image, bgr, status, hdr, list, wave_ext,
+                         wps, B, bbox);
+    else
+      hipLaunchKernelGGL((raster_resolve_shade_kernel<false, true>), dim3(grid), dim3(256), 0, st, lit, uvs, faces, mesh_table, textures,
+                         tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, image, bgr, status, hdr, list, wave_ext,
+                         wps, B, bbox);
   } else {
+    DIM_REQUIRE(!clean_bbox, "clean_bbox needs the two-pass resolve: W %% 4 == 0 and 16-byte aligned planes and workspace");
     if (normals)
       hipLaunchKernelGGL(raster_resolve_kernel<true>, dim3(ceil_div(W, 256), H, B), dim3(256), 0, st, lit, uvs, faces, mesh_table, textures,
                          tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, mask_thr, image, depth, mask, bgr, bbox,
@@ -731,7 +764,7 @@ int dim_raster_render(const float* verts, const float* uvs, const int* faces, co
                       void* stream) {
   return raster_render_impl(verts, nullptr, uvs, faces, mesh_table, n_classes, vmax, fmax, textures, tex_table, class_index, poses, K9, B,
                             H, W, znear, zfar, tex_bilinear, nullptr, nullptr, 0.f, plane_means3, mask_thr, workspace, image, depth, mask,
-                            bgr, bbox, status, stream);
+                            bgr, bbox, status, nullptr, stream);
 }
 
 int dim_raster_render_lit(const float* verts, const float* normals, const float* uvs, const int* faces, const int* mesh_table,
@@ -744,7 +777,21 @@ int dim_raster_render_lit(const float* verts, const float* normals, const float*
   DIM_REQUIRE(normals && light_pos && light_int, "null pointer");
   return raster_render_impl(verts, normals, uvs, faces, mesh_table, n_classes, vmax, fmax, textures, tex_table, class_index, poses, K9, B,
                             H, W, znear, zfar, tex_bilinear, light_pos, light_int, brightness_ratio, plane_means3, mask_thr, workspace,
-                            image, depth, mask, bgr, bbox, status, stream);
+                            image, depth, mask, bgr, bbox, status, nullptr, stream);
+}
+
+int dim_raster_render_dirty(const float* verts, const float* normals, const float* uvs, const int* faces, const int* mesh_table,
+                            int n_classes, int vmax, int fmax, const unsigned char* textures, const int* tex_table, const int* class_index,
+                            const float* poses, const float* K9, int B, int H, int W, float znear, float zfar, int tex_bilinear,
+                            const float* light_pos, const float* light_int, float brightness_ratio, const float* plane_means3,
+                            float mask_thr, void* workspace, float* image, float* depth, float* mask, float* bgr, int* bbox, int* status,
+                            const int* clean_bbox, void* stream) {
+  if (B == 0) return DIM_OK;
+  DIM_REQUIRE(!normals || (light_pos && light_int), "lit render: null light pointer");
+  DIM_REQUIRE(!clean_bbox || clean_bbox != bbox, "clean_bbox and bbox must be different arrays (the stream pass reads one while the last pass writes the other)");
+  return raster_render_impl(verts, normals, uvs, faces, mesh_table, n_classes, vmax, fmax, textures, tex_table, class_index, poses, K9, B,
+                            H, W, znear, zfar, tex_bilinear, light_pos, light_int, brightness_ratio, plane_means3, mask_thr, workspace,
+                            image, depth, mask, bgr, bbox, status, clean_bbox, stream);
 }
 
 int dim_modelnet_light_position(const float* poses, float dx, float dy, float dz, float* light_pos, int B, void* stream) {

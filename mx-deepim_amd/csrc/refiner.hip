@@ -45,7 +45,7 @@ struct dim_refiner {
   LayerPlan L[10];
   float *fc6_w, *fc6_b, *fc7_w, *fc7_b, *rot_w, *rot_b, *trans_w, *trans_b;
   float *X, *workspace, *fc6, *zoom_factor, *image_rendered, *mask_observed, *mask_rendered;
-  int *bbox_obs, *bbox_ren, *bbox_ras, *bbox_box;
+  int *bbox_obs, *bbox_ren, *bbox_ras, *bbox_ras2, *bbox_box;
   void* raster_ws;
   float plane_means[3];
 };
@@ -173,8 +173,13 @@ int dim_refiner_create(dim_refiner** out, const dim_refiner_desc* desc, const ch
   TRY(dev_alloc(r, (void**)&r->bbox_obs, (size_t)B * 16));
   TRY(dev_alloc(r, (void**)&r->bbox_ren, (size_t)B * 16));
   TRY(dev_alloc(r, (void**)&r->bbox_ras, (size_t)B * 16));
+  TRY(dev_alloc(r, (void**)&r->bbox_ras2, (size_t)B * 16));   // the boxes of two consecutive renders: one is the next one's dirty-box hint
   TRY(dev_alloc(r, (void**)&r->bbox_box, (size_t)B * 16));
   TRY(dev_alloc(r, &r->raster_ws, (size_t)dim_raster_workspace_bytes(B, d.vmax, d.H, d.W)));
+  {   // the rasteriser's header must not hold what a previous owner of this memory left there (deepim_hip.h, rasteriser section)
+    hipError_t e = hipMemsetAsync(r->raster_ws, 0, 256, as_stream(stream));
+    if (e != hipSuccess) { dim_refiner_destroy(r); return set_err(DIM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+  }
 #undef TRY
   *out = r;
   return DIM_OK;
@@ -240,15 +245,19 @@ int dim_refiner_run(dim_refiner* r, const float* image_observed, const float* im
     TRY(dim_se3_compose(pose, se3, pose_out, nullptr, B, d.rot_coord, d.T_means, d.T_stds, stream));
     if (it < T - 1) {
       // ---- render + update_data_batch (tester.py:563-590, data_pair.py:103-114)
-      TRY(dim_raster_render(d.verts, d.uvs, d.faces, d.mesh_table, d.n_classes, d.vmax, d.fmax, d.textures, d.tex_table, class_index, pose_out,
-                            d.K9, B, H, W, d.znear, d.zfar, d.tex_bilinear, r->plane_means, 0.2f, r->raster_ws, r->image_rendered, nullptr,
-                            r->mask_rendered, nullptr, r->bbox_ras, status, stream));
-      TRY(dim_box_mask(r->bbox_ras, r->mask_observed, B, H, W, r->bbox_box, stream));
+      // (from the second render on, the planes hold the previous render: background outside ITS box, which is not written again)
+      int* bb_new = (it & 1) ? r->bbox_ras2 : r->bbox_ras;
+      const int* bb_prev = it == 0 ? nullptr : ((it & 1) ? r->bbox_ras : r->bbox_ras2);
+      TRY(dim_raster_render_dirty(d.verts, nullptr, d.uvs, d.faces, d.mesh_table, d.n_classes, d.vmax, d.fmax, d.textures, d.tex_table,
+                                  class_index, pose_out, d.K9, B, H, W, d.znear, d.zfar, d.tex_bilinear, nullptr, nullptr, 0.f, r->plane_means,
+                                  0.2f, r->raster_ws, r->image_rendered, nullptr, r->mask_rendered, nullptr, bb_new, status,
+                                  d.znear > 0.2f ? bb_prev : nullptr, stream));
+      TRY(dim_box_mask(bb_new, r->mask_observed, B, H, W, r->bbox_box, stream));
       img_ren = r->image_rendered;
       m_obs = r->mask_observed;
       m_ren = r->mask_rendered;
       bb_obs = r->bbox_box;
-      bb_ren = r->bbox_ras;
+      bb_ren = bb_new;
       pose = pose_out;
     }
   }

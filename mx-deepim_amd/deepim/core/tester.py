@@ -66,6 +66,7 @@ class Refiner(object):
         self.poses_iter = torch.zeros((self.test_iter, B, 3, 4), dtype=torch.float32, device=d)
         self.se3_iter = torch.zeros((self.test_iter, B, 7), dtype=torch.float32, device=d)
         self.bbox = torch.zeros((B, 4), dtype=torch.int32, device=d)
+        self.bbox2 = torch.zeros((B, 4), dtype=torch.int32, device=d)   # consecutive renders alternate: one box is the next render's dirty-box hint
         self.bbox_obs = torch.zeros((B, 4), dtype=torch.int32, device=d)
         self.status_iter = torch.zeros((self.test_iter, B), dtype=torch.int32, device=d)
         # per-iteration head outputs of the full (not FAST_TEST) graph, read by the reference at tester.py:485-491
@@ -142,15 +143,17 @@ class Refiner(object):
                 # and the depth plane is not materialised -- 1.2 MB per pair and render less to write)
                 if self.input_depth:
                     extra["depth"] = b["depth_rendered"]   # INPUT_DEPTH: the rendered depth is a network input (tester.py:573-574)
+                # from the second render on the planes hold the previous render: background outside ITS box, which is not written again
+                bb_new, bb_prev = (self.bbox, self.bbox2) if it % 2 == 0 else (self.bbox2, self.bbox)
                 self.render_machine.render_batch(b["class_index"], self.poses_iter[it], image=b["image_rendered"],
-                                                 mask=b["mask_rendered"], bbox=self.bbox, plane_means=net.plane_means, mask_thr=0.2,
-                                                 status=self.status_iter[it], **extra)
+                                                 mask=b["mask_rendered"], bbox=bb_new, plane_means=net.plane_means, mask_thr=0.2,
+                                                 status=self.status_iter[it], clean_bbox=bb_prev if it > 0 else None, **extra)
                 if box_update:
                     # data_pair.py:103-114; the rectangle's own bbox comes back with it, so ZoomMask does not scan the mask again
-                    ops.box_mask(self.bbox, b["mask_observed"], bbox_of_mask=self.bbox_obs)
+                    ops.box_mask(bb_new, b["mask_observed"], bbox_of_mask=self.bbox_obs)
                     bbox_obs = self.bbox_obs
                 pose = self.poses_iter[it]
-                bbox_ren = self.bbox
+                bbox_ren = bb_new
         ops.copy(b["src_pose"], pose)  # the blob ends up as the reference leaves it: the pose the last forward used
 
     def refine(self):

@@ -50,6 +50,7 @@ SIGNATURES = {
     "dim_raster_workspace_bytes": (L, [I, I, I, I]),
     "dim_raster_render": (I, [P, P, P, P, I, I, I, P, P, P, P, P, I, I, I, F, F, I, P, F, P, P, P, P, P, P, P, P]),
     "dim_raster_render_lit": (I, [P, P, P, P, P, I, I, I, P, P, P, P, P, I, I, I, F, F, I, P, P, F, P, F, P, P, P, P, P, P, P, P]),
+    "dim_raster_render_dirty": (I, [P, P, P, P, P, I, I, I, P, P, P, P, P, I, I, I, F, F, I, P, P, F, P, F, P, P, P, P, P, P, P, P, P]),
     "dim_modelnet_light_position": (I, [P, F, F, F, P, I, P]),
     "dim_box_mask": (I, [P, P, I, I, I, P, P]),
     "dim_conv2d_packed_weight_floats": (L, [I, I, I, I]),

@@ -111,9 +111,9 @@ class Render_Py_Light_ModelNet_Multi(Render_Py):
         return out
 
     def render_batch(self, class_index, poses, light_position=None, light_intensity=None, brightness_k=0, K=None, image=None,
-                     depth=None, mask=None, bgr=None, bbox=None, plane_means=None, mask_thr=0.2, status=None):
+                     depth=None, mask=None, bgr=None, bbox=None, plane_means=None, mask_thr=0.2, status=None, clean_bbox=None):
         """class_index (B,) int32, poses (B,3,4), light_position / light_intensity (B,3) f32, all cuda.
-        light_position None = the loop's rule (idx 2); light_intensity None = white (1,1,1)."""
+        light_position None = the loop's rule (idx 2); light_intensity None = white (1,1,1).  clean_bbox: as Render_Py.render_batch."""
         B = poses.shape[0]
         if light_position is None:
             light_position = self.light_position(poses)
@@ -122,14 +122,17 @@ class Render_Py_Light_ModelNet_Multi(Render_Py):
         keep, kp = host_f32(self.K if K is None else K, 9)
         pm = host_f32(plane_means, 3) if plane_means is not None else (None, None)
         ws = self._workspace(B)
-        check(lib().dim_raster_render_lit(
+        if clean_bbox is not None and not mask_thr < self.zNear:
+            clean_bbox = None
+        check(lib().dim_raster_render_dirty(
             dptr(self.verts), dptr(self.normals), dptr(self.uvs), dptr(self.faces), dptr(self.mesh_table), int(self.mesh_table.shape[0]),
             self.vmax, self.fmax,
             dptr(self.textures), dptr(self.tex_table), dptr(class_index, torch.int32), dptr(poses, torch.float32), kp, B, self.height,
             self.width, float(self.zNear), float(self.zFar), int(self.tex_bilinear), dptr(light_position, torch.float32),
             dptr(light_intensity, torch.float32), float(self.brightness_ratios[brightness_k]), pm[1], float(mask_thr), ws.data_ptr(),
             dptr(image), dptr(depth), dptr(mask), dptr(bgr), dptr(bbox, torch.int32) if bbox is not None else None,
-            dptr(status, torch.int32) if status is not None else None, current_stream()))
+            dptr(status, torch.int32) if status is not None else None, dptr(clean_bbox, torch.int32) if clean_bbox is not None else None,
+            current_stream()))
 
     def render(self, model_idx, r, t, light_position, light_intensity, brightness_k=0, r_type="quat"):
         """Reference signature (:153-235); returns host numpy (bgr uint8, depth float32) like the glReadPixels path."""

@@ -122,30 +122,39 @@ class Render_Py(object):
         self.mesh_bytes = int(self.verts.numel() * 4 + self.uvs.numel() * 4 + self.faces.numel() * 4)
 
     def _workspace(self, B):
-        if self._ws is None or self._ws_B < B:
+        """one workspace per batch size, zero-filled when allocated: its first 256 bytes are the rasteriser's header ("the z-buffer
+        behind me is clear"), which must not hold what a previous owner of the memory left there (include/deepim_hip.h); the layout
+        behind the header depends on B, so two batch sizes never share one"""
+        if not isinstance(self._ws, dict):
+            self._ws = {}
+        if B not in self._ws:
             n = lib().dim_raster_workspace_bytes(B, self.vmax, self.height, self.width)
-            self._ws = torch.empty((n + 7) // 8, dtype=torch.int64, device=self.device)
-            self._ws_B = B
-        return self._ws
+            self._ws[B] = torch.zeros((n + 7) // 8, dtype=torch.int64, device=self.device)
+        return self._ws[B]
 
     def reserve(self, B):
         """pre-allocate the z-buffer workspace (call before hipGraph capture)."""
         self._workspace(B)
 
     def render_batch(self, class_index, poses, K=None, image=None, depth=None, mask=None, bgr=None, bbox=None,
-                     plane_means=None, mask_thr=0.2, status=None):
+                     plane_means=None, mask_thr=0.2, status=None, clean_bbox=None):
         """class_index (B,) int32 cuda, poses (B,3,4) f32 cuda.  Any of the output tensors may be None.
-        status: optional (B,) int32 cuda; DIM_STATUS_BAD_CLASS (4) / DIM_STATUS_BAD_FACE (8) are OR-ed in."""
+        status: optional (B,) int32 cuda; DIM_STATUS_BAD_CLASS (4) / DIM_STATUS_BAD_FACE (8) are OR-ed in.
+        clean_bbox: optional (B,4) int32 cuda, the bbox a PREVIOUS render_batch into the same output tensors returned (another tensor
+        than `bbox`): the planes hold background outside it, and pixels out there that this render does not cover are not rewritten."""
         B = poses.shape[0]
         keep, kp = host_f32(self.K if K is None else K, 9)
         pm = host_f32(plane_means, 3) if plane_means is not None else (None, None)
         ws = self._workspace(B)
-        check(lib().dim_raster_render(
-            dptr(self.verts), dptr(self.uvs), dptr(self.faces), dptr(self.mesh_table), int(self.mesh_table.shape[0]), self.vmax, self.fmax,
+        if clean_bbox is not None and not mask_thr < self.zNear:
+            clean_bbox = None   # the mask's box is the box of everything drawn only if every fragment passes the mask threshold
+        check(lib().dim_raster_render_dirty(
+            dptr(self.verts), None, dptr(self.uvs), dptr(self.faces), dptr(self.mesh_table), int(self.mesh_table.shape[0]), self.vmax, self.fmax,
             dptr(self.textures), dptr(self.tex_table), dptr(class_index, torch.int32), dptr(poses, torch.float32), kp, B, self.height,
-            self.width, float(self.zNear), float(self.zFar), int(self.tex_bilinear), pm[1], float(mask_thr), ws.data_ptr(), dptr(image),
-            dptr(depth), dptr(mask), dptr(bgr), dptr(bbox, torch.int32) if bbox is not None else None,
-            dptr(status, torch.int32) if status is not None else None, current_stream()))
+            self.width, float(self.zNear), float(self.zFar), int(self.tex_bilinear), None, None, 0.0, pm[1], float(mask_thr), ws.data_ptr(),
+            dptr(image), dptr(depth), dptr(mask), dptr(bgr), dptr(bbox, torch.int32) if bbox is not None else None,
+            dptr(status, torch.int32) if status is not None else None, dptr(clean_bbox, torch.int32) if clean_bbox is not None else None,
+            current_stream()))
 
     def render(self, cls_idx, r, t, r_type="quat", K=None):
         """Reference signature (render_py_multi.py:112-147); returns host numpy like glReadPixels did."""

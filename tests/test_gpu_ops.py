@@ -717,8 +717,14 @@ def test_winograd_batch_slices(hip_lib, monkeypatch):
     whole3 = ops.conv2d_fwd_winograd(x, 64, wp3, b, 128, m=4, workspace=ws).clone()
     whole5 = ops.conv2d_fwd_winograd5x5s2(x, 64, wp5, b, 128, workspace=ws).clone()
     monkeypatch.setenv("DIM_WINO_MAX_SLICE", "2")
-    np.testing.assert_array_equal(ops.conv2d_fwd_winograd(x, 64, wp3, b, 128, m=4, workspace=ws).cpu().numpy(), whole3.cpu().numpy())
-    np.testing.assert_array_equal(ops.conv2d_fwd_winograd5x5s2(x, 64, wp5, b, 128, workspace=ws).cpu().numpy(), whole5.cpu().numpy())
+    # (equal up to where the stream-K ranges cut a (tile, plane) item: a slice has other row counts, so other cuts and another GEMM tile
+    # -- the two partial sums of a cut item then differ in the last bits; the same call twice is bit-identical)
+    s3 = ops.conv2d_fwd_winograd(x, 64, wp3, b, 128, m=4, workspace=ws).clone()
+    s5 = ops.conv2d_fwd_winograd5x5s2(x, 64, wp5, b, 128, workspace=ws).clone()
+    np.testing.assert_allclose(s3.cpu().numpy(), whole3.cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(s5.cpu().numpy(), whole5.cpu().numpy(), atol=2e-5)
+    np.testing.assert_array_equal(ops.conv2d_fwd_winograd(x, 64, wp3, b, 128, m=4, workspace=ws).cpu().numpy(), s3.cpu().numpy())
+    np.testing.assert_array_equal(ops.conv2d_fwd_winograd5x5s2(x, 64, wp5, b, 128, workspace=ws).cpu().numpy(), s5.cpu().numpy())
 
 
 @pytest.mark.parametrize("shape,tile", [((16, 60, 80, 64, 256, 3, 1, 1), 4), ((9, 120, 160, 32, 128, 3, 2, 1), 4), ((6, 96, 128, 32, 64, 3, 1, 1), 3)])
