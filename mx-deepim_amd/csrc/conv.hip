@@ -1796,6 +1796,8 @@ int dim_winograd_gemm_tile(int Cout, long tiles) {
     }
     return best;
   }
+  static const int big = [] { const char* e = getenv("DIM_WINO_BIG_TILE"); return e ? atoi(e) : 0; }();   // A/B timing: 6 or 7 on the big layers
+  if (big == 6 || big == 7) return big;
   return (Cout % 256 == 0 && bn256) ? 5 : 4;
 }
 

@@ -25,3 +25,17 @@ def t(poses, n=100):
 print("render_batch normal: %.1f us" % t(gt))
 far = gt.copy(); far[:, 0, 3] += 50.0
 print("render_batch object out of view: %.1f us" % t(far))
+# the refinement loop's shape: no depth plane, image + mask + bbox; then the same with the previous render's box as the dirty-box hint
+bbox2 = torch.zeros((B, 4), dtype=torch.int32, device=d)
+def t_loop(hint, n=100):
+    p = torch.from_numpy(init.astype(np.float32)).to(d)
+    boxes = [bbox, bbox2]
+    def f(i):
+        rm.render_batch(ci, p, image=img, mask=msk, bbox=boxes[i & 1], plane_means=pm, clean_bbox=boxes[(i + 1) & 1] if hint else None)
+    f(0); f(1); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(n): f(i)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+print("loop-shaped render (image + mask + bbox): %.1f us; with the dirty-box hint: %.1f us" % (t_loop(False), t_loop(True)))
