@@ -115,3 +115,13 @@ def test_bench_gpus_2_one_command_two_ranks_on_one_card(hip_lib):
     assert out["n_gpus"] == 2 and out["config"]["global_pairs"] == 32 and out["value"] > 0
     assert "error" not in out["train"], out["train"]
     assert out["train"]["global_pairs"] == 2 * out["train"]["pairs_per_gpu"] and out["train"]["f32"]["finite"] and out["train"]["bf16"]["finite"]
+    # the line says WHICH devices joined: one identity per rank (rank order), here both on this box's one card -- which the gloo
+    # rehearsal allows and an RCCL run refuses (tests/test_dist_gloo.py) --, every rank's own step time next to the MAX
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and out["dist_backend"] == "gloo" and out["distinct_devices"] == 1
+    assert all(r["cus"] == 256 and "gfx950" in r["arch"] and r["pid"] > 0 for r in out["ranks"]) and out["ranks"][0]["pid"] != out["ranks"][1]["pid"]
+    assert len(out["ms_per_step_per_rank"]) == 2 and max(out["ms_per_step_per_rank"]) == pytest.approx(out["ms_per_step"], rel=1e-3)
+    # and what the gradient sum costs: bytes and time of every bucket (f32 buckets 231 MB in all, bf16 half of it)
+    for dt, nbytes in (("f32", 4), ("bf16", 2)):
+        bk = out["train"][dt]["allreduce_buckets"]
+        assert len(bk) == 3 and all(b["ms"] > 0 and b["bytes"] == (b["end"] - b["begin"]) * nbytes for b in bk), bk
+        assert out["train"][dt]["allreduce_bytes_per_update"] == sum(b["bytes"] for b in bk) and len(out["train"][dt]["iteration_ms_per_rank"]) == 2
