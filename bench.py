@@ -135,7 +135,7 @@ def encoder_roofline(net, b, test_iter, profile_steps):
                         "dim::conv_fwd_kernel<{}, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
                     flops, nbytes = info["flops"], info["min_bytes"]
             elif tag == "fc":  # fc6 weight stream (+ its partial-sum reduce inside the event pair)
-                kname, flops, nbytes = "dim::fc_stream_kernel", info["flops"], info["min_bytes"]
+                kname, flops, nbytes = ("dim::fc_stream16_kernel" if net.B <= 16 else "dim::fc_stream_kernel") + " + fc_reduce_kernel", info["flops"], info["min_bytes"]
             elif tag in ("wino_in", "wino_out"):
                 kname, flops = info["wino_in_kernel" if tag == "wino_in" else "wino_out_kernel"], 0.0
                 nbytes = info["wino_in_bytes" if tag == "wino_in" else "wino_out_bytes"]  # HBM-bound: read x + write V / read M + write y
