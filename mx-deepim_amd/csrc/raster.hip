@@ -710,6 +710,11 @@ static int raster_render_impl(const float* verts, const float* normals, const fl
   unsigned* list = reinterpret_cast<unsigned*>(ws + sizeof(ResolveHdr) + (long)B * H * W * 8 + raster_scr_bytes(B, vmax));
   const long nkeys = (long)B * H * W;
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // the two-pass resolve moves float4 / 2 x u64: every plane pointer (and the workspace) must be 16-byte aligned; anything else
+  // takes the one-thread-per-pixel kernel.  (Every argument check comes BEFORE the first launch: a render that stopped between the
+  // triangle pass and the last pass would leave a dirty z-buffer behind a header that calls it clear.)
+  const bool two_pass = W % 4 == 0 && aligned16(workspace) && aligned16(image) && aligned16(depth) && aligned16(mask) && aligned16(bgr);
+  DIM_REQUIRE(!clean_bbox || two_pass, "clean_bbox needs the two-pass resolve: W %% 4 == 0 and 16-byte aligned planes and workspace");
   // No clear pass and no init launch (round 4): the z-buffer is clear when a render ends (the pass that consumes a key resets it) and
   // the header in front of it says so; a header that does not match this call makes the vertex pass clear the z-buffer first.  (A
   // clear by hipMemsetAsync was never an option: inside a captured hipGraph the memset node was seen overlapping the resolve pass.)
@@ -720,9 +725,7 @@ static int raster_render_impl(const float* verts, const float* normals, const fl
                      K9[0], K9[4], K9[2], K9[5], vmax, H, W, znear, zfar, n_classes, zbuf, hdr, B);
   float p0 = plane_means3 ? plane_means3[0] : 0.f, p1 = plane_means3 ? plane_means3[1] : 0.f, p2 = plane_means3 ? plane_means3[2] : 0.f;
   LitArgs lit = {verts, normals, poses, light_pos, light_int, ratio, K9[0], K9[4], K9[2], K9[5], fmaxf(znear, kZClipMin)};
-  // the two-pass resolve moves float4 / 2 x u64: every plane pointer (and the workspace) must be 16-byte aligned; anything else
-  // takes the one-thread-per-pixel kernel
-  if (W % 4 == 0 && aligned16(workspace) && aligned16(image) && aligned16(depth) && aligned16(mask) && aligned16(bgr)) {
+  if (two_pass) {
     // pass 1 streams the z-buffer once and finishes depth / mask / background (only inside the caller's dirty box, if it names one) and
     // lists the covered pixels; pass 2 folds the bbox, colours the listed pixels on full waves and resets their keys
     const int wps = raster_waves_per_sample(H, W);
@@ -744,7 +747,6 @@ static int raster_render_impl(const float* verts, const float* normals, const fl
                          tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, image, bgr, status, hdr, list, wave_ext,
                          wps, B, bbox);
   } else {
-    DIM_REQUIRE(!clean_bbox, "clean_bbox needs the two-pass resolve: W %% 4 == 0 and 16-byte aligned planes and workspace");
     if (normals)
       hipLaunchKernelGGL(raster_resolve_kernel<true>, dim3(ceil_div(W, 256), H, B), dim3(256), 0, st, lit, uvs, faces, mesh_table, textures,
                          tex_table, class_index, scr, zbuf, vmax, H, W, tex_bilinear, p0, p1, p2, mask_thr, image, depth, mask, bgr, bbox,
