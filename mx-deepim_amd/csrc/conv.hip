@@ -1556,26 +1556,51 @@ __global__ __launch_bounds__(256) void upsample16_x4_kernel(const float* __restr
 
 // Pose head: fc7 + LeakyReLU + rot (4) + trans (3) + inverse ZoomTrans -> se3 (B,7).
 // deepIM_flownet.py:203-208, :956-971; zoom_trans.py:37-41 (b_inv_zoom: dx*wx, dy*wx).
-__global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict__ fc6, const float* __restrict__ w7,
+__global__ __launch_bounds__(1024) void pose_head_kernel(const float* __restrict__ fc6, const float* __restrict__ w7,
                                                          const float* __restrict__ b7, const float* __restrict__ wr,
                                                          const float* __restrict__ br, const float* __restrict__ wt,
                                                          const float* __restrict__ bt, const float* __restrict__ zoom_factor,
                                                          float* __restrict__ se3, float* __restrict__ fc7_out) {
-  __shared__ float s_in[256];
   __shared__ float s_h[256];
   const int b = blockIdx.x, t = threadIdx.x;
-  s_in[t] = fc6[(long)b * 256 + t];
-  __syncthreads();
-  float acc = b7[t];
-  const float* wrow = w7 + (long)t * 256;
-  for (int k = 0; k < 256; ++k) acc = fmaf(s_in[k], wrow[k], acc);
-  acc = acc > 0.f ? acc : 0.1f * acc;
-  s_h[t] = acc;
-  if (fc7_out) fc7_out[(long)b * 256 + t] = acc;
+  const int wave = t >> 6, lane = t & 63;
+  // fc7 (256 x 256): for each output the 64 lanes of a wave read the weight row as one coalesced 1 KB load (a float4 per lane against
+  // the lane's own four fc6 values) and fold their partial dots with a fixed shuffle tree.  (The first version gave every thread one
+  // output and let it walk its row alone: 64 cache lines per wave-load, 256 loads per thread, 15-16 us for 16 samples.)
+  // (16-byte loads when fc6 and w7 are 16-byte aligned; a flat parameter blob may place w7 on any 4-byte boundary: scalar loads then)
+  const bool al = ((reinterpret_cast<uintptr_t>(fc6) | reinterpret_cast<uintptr_t>(w7)) & 15) == 0;
+  const float* xr = fc6 + (long)b * 256 + 4 * lane;
+  const float4 xin = al ? *reinterpret_cast<const float4*>(xr) : make_float4(xr[0], xr[1], xr[2], xr[3]);
+  // 16 waves x 16 outputs: every wave issues its 16 row loads before the first use -- one memory round trip for the layer (with 4 rows
+  // at a time on 4 waves the kernel still took 16 us: sixteen round trips in series)
+  {
+    const int o0 = wave * 16;
+    float4 wv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float* wr_ = w7 + (long)(o0 + u) * 256 + 4 * lane;
+      wv[u] = al ? *reinterpret_cast<const float4*>(wr_) : make_float4(wr_[0], wr_[1], wr_[2], wr_[3]);
+    }
+    float p[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) p[u] = fmaf(xin.w, wv[u].w, fmaf(xin.z, wv[u].z, fmaf(xin.y, wv[u].y, xin.x * wv[u].x)));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) p[u] += __shfl_down(p[u], off, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        float acc = p[u] + b7[o0 + u];
+        acc = acc > 0.f ? acc : 0.1f * acc;
+        s_h[o0 + u] = acc;
+        if (fc7_out) fc7_out[(long)b * 256 + o0 + u] = acc;
+      }
+    }
+  }
   __syncthreads();
   // 7 outputs, one wave each would be overkill: 7 x 64-lane partial dot + shuffle reduce
-  const int wave = t >> 6, lane = t & 63;
-  for (int o = wave; o < 7; o += 4) {
+  for (int o = wave; o < 7; o += 16) {
     const float* wv = (o < 4) ? (wr + o * 256) : (wt + (o - 4) * 256);
     float p = 0.f;
     for (int k = lane; k < 256; k += 64) p = fmaf(s_h[k], wv[k], p);
@@ -2511,7 +2536,7 @@ int dim_pose_head_fwd(const float* fc6, const float* fc7_w, const float* fc7_b, 
                       void* stream) {
   DIM_REQUIRE(fc6 && fc7_w && fc7_b && rot_w && rot_b && trans_w && trans_b && zoom_factor && se3, "null pointer");
   if (B == 0) return DIM_OK;
-  hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(256), 0, as_stream(stream), fc6, fc7_w, fc7_b, rot_w, rot_b, trans_w,
+  hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(1024), 0, as_stream(stream), fc6, fc7_w, fc7_b, rot_w, rot_b, trans_w,
                      trans_b, zoom_factor, se3, fc7_out);
   return check_launch("pose_head");
 }
