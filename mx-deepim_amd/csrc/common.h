@@ -237,6 +237,7 @@ struct WGemmArgs {
   int MT;               // row tiles
   int plane_major;      // item order, see wcur_decode
   int dbg_plain;        // timing-only experiment: every flush a plain store (wrong sums for shared items)
+  int wide_flush;       // whole items leave through LDS as 16-byte stores (0: one-dword stores, A/B timing)
 };
 int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile);
 // zeroed = the shared tiles have been zeroed already (by the transform kernel that ran before): no separate zero launch

@@ -62,10 +62,13 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
   constexpr int NSTG = BM / RP;  // staging loads per thread and chunk
+  constexpr int kTrLd = 32, kTrFloats = 16 * kTrLd;  // row stride / size of a wave's transposing buffer: 16 rows x 32 floats = 2 KB
+  constexpr bool kWide = !(BM == 128 && BN == 128);  // wide flush (below): not on the 128 x 128 tile, whose 126 registers have no room for it (it spills)
   static_assert(BM % RP == 0 && NSTG >= 2 && NSTG <= 5, "two to five staging loads per thread");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;  // [2][BM][LDK]
+  float* sTr = smem + 2 * BM * LDK;  // [waves][32][32]: every wave's own transposing buffer for the flush of a whole item
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -171,6 +174,32 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN
       asm volatile("" : "+v"(ov), "+v"(orow));                                                                         \
       const int soff = (int)((unsigned)(mb * ldc + cb) * 4u);                                                          \
       const bool plain = (whole && item_end) || a.dbg_plain;                                                           \
+      if (kWide && plain && a.wide_flush) {                                                                            \
+        /* whole item: every 32 x 32 accumulator tile goes, 16 rows at a time, through the wave's own 2 KB of LDS (the MFMA result   \
+           has a column per lane and rows in the registers: 16 one-dword stores per tile, 64 on the 128 x 256 tile -- in-kernel     \
+           stamps: 7.5 k cycles per flush there, 10.7 % of a workgroup's life) and leaves as 16-byte stores of 8 rows x 128 B each  \
+           (same box A/B: dominant kernel 110.9 -> 113.7 TFLOP/s, loop +0.6 %) */                                                \
+        float* sT = sTr + wave * kTrFloats;                                                                            \
+        const int trow = lane >> 3, tc4 = (lane & 7) * 4;                                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                   \
+          _Pragma("unroll") for (int h = 0; h < 2; ++h) { /* rows 16 h .. 16 h + 15 of the tile = registers 8 h .. 8 h + 7 */ \
+            _Pragma("unroll") for (int r = 0; r < 8; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * khalf) * kTrLd + frow] = acc[i][j][8 * h + r]; \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+            /* both reads first, then the two stores (8 LDS writes and a wait lie between a store and the next read into its registers) */ \
+            const float4 t0 = *reinterpret_cast<const float4*>(sT + trow * kTrLd + tc4);                               \
+            const float4 t1 = *reinterpret_cast<const float4*>(sT + (trow + 8) * kTrLd + tc4);                         \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+            const int gr = wm * (BM / WM) + 32 * i + 16 * h + trow;                                                    \
+            const int vo0 = (gr < lim) ? (gr * ldc + wn * (BN / WN) + 32 * j + tc4) * 4 : -1;                          \
+            const int vo1 = (gr + 8 < lim) ? ((gr + 8) * ldc + wn * (BN / WN) + 32 * j + tc4) * 4 : -1;                \
+            u32x4 u0, u1;                                                                                              \
+            u0.x = __float_as_uint(t0.x); u0.y = __float_as_uint(t0.y); u0.z = __float_as_uint(t0.z); u0.w = __float_as_uint(t0.w); \
+            u1.x = __float_as_uint(t1.x); u1.y = __float_as_uint(t1.y); u1.z = __float_as_uint(t1.z); u1.w = __float_as_uint(t1.w); \
+            __builtin_amdgcn_raw_buffer_store_b128(u0, rm, vo0, soff, 2);                                              \
+            __builtin_amdgcn_raw_buffer_store_b128(u1, rm, vo1, soff, 2);                                              \
+            asm volatile("" ::: "memory");                                                                             \
+          }                                                                                                            \
+      } else                                                                                                           \
       _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                               \
           const int dr = 32 * i + (r & 3) + 8 * (r >> 2);                                                              \
@@ -243,7 +272,7 @@ static int wino_gemm_slots() {
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e == hipSuccess)
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(&wino_gemm_kernel<BM, BN, WM, WN>),
-                                                       WM * WN * 64, 2 * BM * 36 * sizeof(float));
+                                                       WM * WN * 64, (2 * BM * 36 + WM * WN * 512) * sizeof(float));
     if (e != hipSuccess || cus <= 0 || occ <= 0) return set_err(DIM_ERR_LAUNCH, "winograd gemm occupancy query: %s", hipGetErrorString(e));
     slots = cus * occ;
     g_wino_cus = cus;
@@ -285,6 +314,8 @@ int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, in
   a.plane_major = order;
   static const int dbg_plain = getenv("DIM_WINO_DBG_PLAIN") ? atoi(getenv("DIM_WINO_DBG_PLAIN")) : 0;  // timing only: WRONG sums
   a.dbg_plain = dbg_plain;
+  static const int wide = getenv("DIM_WINO_WIDE_FLUSH") ? atoi(getenv("DIM_WINO_WIDE_FLUSH")) : 1;   // A/B timing: 0 = one-dword stores
+  a.wide_flush = wide;
   a.BM = BM;
   a.BN = BN;
   a.tile = tile;
@@ -305,19 +336,23 @@ int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, in
   return DIM_OK;
 }
 
+template <int BM, int BN, int WM, int WN>
+static int wino_gemm_launch(const WGemmArgs& a, hipStream_t st) {
+  constexpr size_t lds = (2 * BM * 36 + WM * WN * 512) * sizeof(float);   // A double buffer + every wave's transposing buffer
+  // measured this round: with 69.6 KB of dynamic LDS (4 KB transposing buffers on the 128 x 256 tile) the launch succeeded after
+  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the addresses above 64 KB read back other waves' data -- stay below it
+  static_assert(lds <= 65536, "dynamic LDS of a plane-GEMM workgroup stays within 64 KB");
+  hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN>), dim3(a.G), dim3(WM * WN * 64), lds, st, a);
+  return check_launch("winograd_gemm");
+}
+
 int wino_gemm_run(const WGemmArgs& a, bool zeroed, hipStream_t st) {
   if (!zeroed && a.G > 1) hipLaunchKernelGGL(wino_gemm_zero_kernel, dim3(a.G - 1), dim3(256), 0, st, a);
-  if (a.tile == 5)
-    hipLaunchKernelGGL((wino_gemm_kernel<128, 256, 2, 4>), dim3(a.G), dim3(512), 2 * 128 * 36 * sizeof(float), st, a);
-  else if (a.tile == 4)
-    hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 4>), dim3(a.G), dim3(512), 2 * 128 * 36 * sizeof(float), st, a);
-  else if (a.tile == 6)
-    hipLaunchKernelGGL((wino_gemm_kernel<160, 128, 1, 4>), dim3(a.G), dim3(256), 2 * 160 * 36 * sizeof(float), st, a);
-  else if (a.tile == 7)
-    hipLaunchKernelGGL((wino_gemm_kernel<96, 128, 1, 4>), dim3(a.G), dim3(256), 2 * 96 * 36 * sizeof(float), st, a);
-  else
-    hipLaunchKernelGGL((wino_gemm_kernel<64, 64, 2, 2>), dim3(a.G), dim3(256), 2 * 64 * 36 * sizeof(float), st, a);
-  return check_launch("winograd_gemm");
+  if (a.tile == 5) return wino_gemm_launch<128, 256, 2, 4>(a, st);
+  if (a.tile == 4) return wino_gemm_launch<128, 128, 2, 4>(a, st);
+  if (a.tile == 6) return wino_gemm_launch<160, 128, 1, 4>(a, st);
+  if (a.tile == 7) return wino_gemm_launch<96, 128, 1, 4>(a, st);
+  return wino_gemm_launch<64, 64, 2, 2>(a, st);
 }
 
 int launch_wino_gemm(const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile, hipStream_t st) {
