@@ -252,6 +252,12 @@ int dim_conv2d_tail_plan(int M, int Cout, int Cin, int KH, int KW, int tile, int
  * workgroup tile of a Winograd layer's plane GEMMs (3 / 4 / 5 = 64 x 64 / 128 x 128 / 128 x 256) for `tiles` transform tiles. */
 int dim_conv_auto_plan(long M, int Cout, int nchunks, int cin, int* tile, int* splits);
 int dim_winograd_gemm_tile(int Cout, long tiles);
+/* Arithmetic of the Winograd layers' plane GEMMs.  1 (default): every f32 operand enters the matrix pipe as the exact sum of three
+ * bf16 terms and a product keeps the six largest term products, accumulated in f32 (error <= 3 * 2^-27 per product, below f32's own
+ * rounding of the sums); 0: v_mfma_f32_32x32x2_f32 on the f32 operands.  Every packed Winograd weight buffer carries both images
+ * (dim_winograd*_packed_weight_floats counts them).  Takes effect when a layer is next planned (launch or graph capture). */
+int dim_set_winograd_split(int on);
+int dim_get_winograd_split(void);
 int dim_conv2d_fwd_ex(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int in_cstride,
                       int Cout, int KH, int KW, int stride, int pad, float slope, int tile, int out_cstride, int out_coff, int OH,
                       int OW, int osy, int osx, int ooy, int oox, int Ho, int Wo, int pad_w, int accumulate, void* stream);

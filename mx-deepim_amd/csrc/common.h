@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <utility>
 
 #include "../../include/deepim_hip.h"
 
@@ -52,6 +53,16 @@ inline FastDiv make_fastdiv(unsigned d) {
 __device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
   unsigned t = __umulhi(n, f.mul);
   return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -238,7 +249,18 @@ struct WGemmArgs {
   int plane_major;      // item order, see wcur_decode
   int dbg_plain;        // timing-only experiment: every flush a plain store (wrong sums for shared items)
   int wide_flush;       // whole items leave through LDS as 16-byte stores (0: one-dword stores, A/B timing)
+  const void* U3;       // the three-term bf16 image of U behind it in the same buffer (wino_gemm_split.hip)
+  unsigned u3_bytes;
+  int split;            // run wino_gemm_split_kernel (f32 operands as three bf16 terms, six MFMA products)
 };
+// wino_gemm_split.hip.  Every packed Winograd weight buffer is [U f32][U3]: floats -> floats * 5 / 2
+inline long wino_packed_with_split(long u_floats) { return u_floats + (u_floats * 3 + 1) / 2; }
+int wino_split_weights(float* U, long chunks, int Cout, hipStream_t st);
+void wino_set_split(int on);
+int wino_get_split();
+bool wino_gemm_split_has(int tile);
+int wino_gemm_split_slots(int tile);
+int wino_gemm_split_run(const WGemmArgs& a, hipStream_t st);
 int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, int T, int K, int Cout, int P, int tile);
 // zeroed = the shared tiles have been zeroed already (by the transform kernel that ran before): no separate zero launch
 int wino_gemm_run(const WGemmArgs& plan, bool zeroed, hipStream_t st);

@@ -941,16 +941,6 @@ __global__ __launch_bounds__(256) void conv_bf16_halo_kernel(ConvArgs a) {
   }
 }
 
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
 // ---------------------------------------------------------------------------------------------------------------- bf16, stride-1 patch
 // Tile 9: every stride-1 bf16 convolution with a small rectangular tap set (KH, KW <= 3) on a large map -- the 3x3 forward layers,
 // their input gradients, and the stride-1 phase convolutions a stride-2 input gradient or a 4x4 / stride-2 deconvolution splits into
@@ -1800,6 +1790,14 @@ int dim_conv_auto_plan(long M, int Cout, int nchunks, int cin, int* tile, int* s
   *splits = tiles >= n_cu ? 0 : best_split(tiles, 8);
   return DIM_OK;
 }
+
+// Plane GEMMs with every f32 operand as three bf16 terms and six MFMA products (wino_gemm_split.hip; default on, DIM_WINO_SPLIT=0 or
+// dim_set_winograd_split(0) = the f32 matrix pipe).  Read when a layer is planned, i.e. at the next launch / graph capture.
+int dim_set_winograd_split(int on) {
+  wino_set_split(on ? 1 : 0);
+  return DIM_OK;
+}
+int dim_get_winograd_split(void) { return wino_get_split(); }
 
 // workgroup tile of a Winograd layer's plane GEMMs (wino_gemm.hip): 5 = 128 rows x 256 output channels (V is streamed once per 256
 // channels: conv3, conv3_1, conv4_1), 4 = 128 x 128 (conv2: Cout = 128); for the few-row layers (under 1024 tile rows: conv5 .. conv6_1)
@@ -3018,7 +3016,7 @@ __global__ __launch_bounds__(256) void wino4_wgrad_output_kernel(const float* __
 
 extern "C" {
 
-long dim_winograd_packed_weight_floats(int Cout, int Cin, int m) { return (long)(m + 2) * (m + 2) * Cout * Cin; }
+long dim_winograd_packed_weight_floats(int Cout, int Cin, int m) { return wino_packed_with_split((long)(m + 2) * (m + 2) * Cout * Cin); }
 
 // images per slice: tiles * planes * max(K, Cout) floats of one slice stay below 2^32 bytes (32-bit buffer offsets in the plane GEMMs)
 static long wino_slice_images(long tiles_per_image, int planes, long K, long Cout) {
@@ -3043,7 +3041,8 @@ int dim_winograd_pack_weight(const float* w_oihw, float* w_packed, int Cout, int
     hipLaunchKernelGGL(wino_pack_weight_kernel<false>, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin);
   else
     hipLaunchKernelGGL(wino4_pack_weight_kernel<false>, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin);
-  return check_launch("winograd_pack_weight");
+  int rc = check_launch("winograd_pack_weight");
+  return rc != DIM_OK ? rc : wino_split_weights(w_packed, (long)(m + 2) * (m + 2) * (Cin / 32), Cout, as_stream(stream));
 }
 
 // transformed weights of the INPUT gradient of a 3x3 / stride-1 / pad-1 layer, straight from its forward (Cout, Cin, 3, 3) array:
@@ -3057,7 +3056,8 @@ int dim_winograd_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cou
     hipLaunchKernelGGL(wino_pack_weight_kernel<true>, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cin, Cout);
   else
     hipLaunchKernelGGL(wino4_pack_weight_kernel<true>, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cin, Cout);
-  return check_launch("winograd_dgrad_pack_weight");
+  int rc = check_launch("winograd_dgrad_pack_weight");
+  return rc != DIM_OK ? rc : wino_split_weights(w_packed, (long)(m + 2) * (m + 2) * (Cout / 32), Cin, as_stream(stream));
 }
 
 // one slice of the batch: T * planes * max(K, Cout) floats must stay below 2^32 bytes (32-bit buffer offsets in the GEMM)
@@ -3148,7 +3148,7 @@ int dim_conv2d_fwd_winograd(const float* x, const float* w_packed, const float* 
                        stream);
 }
 
-long dim_winograd5x5s2_packed_weight_floats(int Cout, int Cin) { return 36L * Cout * 4 * Cin; }
+long dim_winograd5x5s2_packed_weight_floats(int Cout, int Cin) { return wino_packed_with_split(36L * Cout * 4 * Cin); }
 
 long dim_winograd5x5s2_workspace_floats(int N, int H, int W, int Cin, int Cout) {
   const long per = (long)(((H + 1) / 2 + 3) / 4) * (((W + 1) / 2 + 3) / 4);
@@ -3163,7 +3163,8 @@ int dim_winograd5x5s2_pack_weight(const float* w_oihw, float* w_packed, int Cout
   long total = 4L * Cout * Cin;
   hipLaunchKernelGGL(wino4_pack_weight_5x5s2_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout,
                      Cin);
-  return check_launch("winograd5x5s2_pack_weight");
+  int rc = check_launch("winograd5x5s2_pack_weight");
+  return rc != DIM_OK ? rc : wino_split_weights(w_packed, 36L * (4 * Cin / 32), Cout, as_stream(stream));
 }
 
 int dim_winograd5x5s2_dgrad_pack_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream) {
@@ -3172,7 +3173,8 @@ int dim_winograd5x5s2_dgrad_pack_weight(const float* w_oihw, float* w_packed, in
   long total = 4L * Cout * Cin;
   hipLaunchKernelGGL(wino4_pack_weight_5x5s2_dgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed,
                      Cout, Cin);
-  return check_launch("winograd5x5s2_dgrad_pack_weight");
+  int rc = check_launch("winograd5x5s2_dgrad_pack_weight");
+  return rc != DIM_OK ? rc : wino_split_weights(w_packed, 36L * (Cout / 32), 4 * Cin, as_stream(stream));
 }
 
 int dim_conv2d_dgrad_winograd5x5s2(const float* dy, const float* w_packed, float* dx, float* workspace, int N, int H, int W, int Cin,

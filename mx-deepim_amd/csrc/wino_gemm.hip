@@ -261,6 +261,10 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN
 // zero the output tile of every item that two workgroups share (only when the transform kernel in front did not do it)
 __global__ __launch_bounds__(256) void wino_gemm_zero_kernel(WGemmArgs a) { wino_gemm_zero_tile(a, blockIdx.x + 1); }
 
+// DIM_WINO_SPLIT=0 / dim_set_winograd_split(0): every plane GEMM on the f32 matrix pipe (wino_gemm_kernel)
+static int g_wino_split = getenv("DIM_WINO_SPLIT") ? atoi(getenv("DIM_WINO_SPLIT")) : 1;
+void wino_set_split(int on) { g_wino_split = on; }
+int wino_get_split() { return g_wino_split; }
 static int g_wino_cus = 0;  // compute units of the device (set with the first occupancy query)
 template <int BM, int BN, int WM, int WN>
 static int wino_gemm_slots() {
@@ -319,8 +323,13 @@ int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, in
   a.BM = BM;
   a.BN = BN;
   a.tile = tile;
+  // f32 operands as three bf16 terms on the bf16 matrix pipe (wino_gemm_split.hip) where a split kernel of this tile shape exists
+  a.split = g_wino_split && wino_gemm_split_has(tile) && (long)P * K * Cout * 6 < (1L << 31);
+  a.U3 = U + (long)P * K * Cout;
+  a.u3_bytes = (unsigned)((long)P * K * Cout * 6);
+  if (a.split) a.plane_major = 1;
   // never more workgroups than items: every range is then at least one item long and an item is shared by at most two workgroups
-  const int slots = tile == 5 ? wino_gemm_slots<128, 256, 2, 4>() : tile == 4 ? wino_gemm_slots<128, 128, 2, 4>()
+  const int slots = a.split ? wino_gemm_split_slots(tile) : tile == 5 ? wino_gemm_slots<128, 256, 2, 4>() : tile == 4 ? wino_gemm_slots<128, 128, 2, 4>()
                   : tile == 6 ? wino_gemm_slots<160, 128, 1, 4>() : tile == 7 ? wino_gemm_slots<96, 128, 1, 4>() : wino_gemm_slots<64, 64, 2, 2>();
   if (slots <= 0) return slots;
   a.G = items < slots ? (int)items : slots;
@@ -328,6 +337,10 @@ int wino_gemm_plan(WGemmArgs* plan, const float* V, const float* U, float* M, in
   // work of the others (conv5_1 / conv6_1 on the few-row tiles: 90 / 103 us against 70 / 107 on the 64 x 64 tile before this rule).  A
   // whole number of workgroups per CU, each with a slightly longer range, balances them.  DIM_WINO_G_ROUND=0: off (A/B timing).
   static const int g_round = getenv("DIM_WINO_G_ROUND") ? atoi(getenv("DIM_WINO_G_ROUND")) : 1;
+  if (g_wino_cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_wino_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) g_wino_cus = 0;
+  }
   if (g_round && g_wino_cus > 0 && a.G > g_wino_cus && a.G < slots) a.G = a.G / g_wino_cus * g_wino_cus;
   const long total = items * a.nch;
   a.per = (int)(total / a.G);
@@ -348,6 +361,7 @@ static int wino_gemm_launch(const WGemmArgs& a, hipStream_t st) {
 
 int wino_gemm_run(const WGemmArgs& a, bool zeroed, hipStream_t st) {
   if (!zeroed && a.G > 1) hipLaunchKernelGGL(wino_gemm_zero_kernel, dim3(a.G - 1), dim3(256), 0, st, a);
+  if (a.split) return wino_gemm_split_run(a, st);
   if (a.tile == 5) return wino_gemm_launch<128, 256, 2, 4>(a, st);
   if (a.tile == 4) return wino_gemm_launch<128, 128, 2, 4>(a, st);
   if (a.tile == 6) return wino_gemm_launch<160, 128, 1, 4>(a, st);

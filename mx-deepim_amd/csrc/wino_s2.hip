@@ -229,7 +229,7 @@ static long s2_slice_images(long tiles_per_image, long K, long Cout) {
 
 extern "C" {
 
-long dim_winograd3x3s2_packed_weight_floats(int Cout, int Cin) { return (long)kPlanes * Cout * Cin; }
+long dim_winograd3x3s2_packed_weight_floats(int Cout, int Cin) { return wino_packed_with_split((long)kPlanes * Cout * Cin); }
 
 // the one rule for every caller (FlowNetHip, dim_refiner_create): a 3x3 / stride-2 / pad-1 layer takes this path when its OUTPUT map has
 // at least 300 pixels -- conv4 (30 x 40: 0.36 vs 0.40 ms at 16 pairs) and conv5 (15 x 20: 0.20 vs 0.22), not conv6 (8 x 10: its 2 x 3 tiles
@@ -255,7 +255,8 @@ int dim_winograd3x3s2_pack_weight(const float* w_oihw, float* w_packed, int Cout
   const long total = (long)Cout * Cin;
   hipLaunchKernelGGL(wino_s2_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w_oihw, w_packed, Cout,
                      Cin);
-  return check_launch("winograd3x3s2_pack_weight");
+  int rc = check_launch("winograd3x3s2_pack_weight");
+  return rc != DIM_OK ? rc : wino_split_weights(w_packed, (long)kPlanes * (Cin / 32), Cout, as_stream(stream));
 }
 
 // y (N,Ho,Wo,out_cstride)[out_coff:+Cout] = LeakyReLU_slope(conv3x3 / stride 2 / pad 1 (x (N,H,W,in_cstride)[:Cin]) + bias), Ho = floor((H - 1) / 2) + 1.

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "libdeepim_hip.so"))
+# DIM_HIP_LIB: another build of the same library (kernel experiments: tools/split_exp.sh); there is no fallback either way
+LIB_PATH = os.environ.get("DIM_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "libdeepim_hip.so"))
 
 P = ctypes.c_void_p  # device pointer / host array / stream
 I = ctypes.c_int
@@ -94,6 +95,8 @@ SIGNATURES = {
     "dim_conv2d_tail_plan": (I, [I, I, I, I, I, I, P, P]),
     "dim_conv_auto_plan": (I, [L, I, I, I, P, P]),
     "dim_winograd_gemm_tile": (I, [I, L]),
+    "dim_set_winograd_split": (I, [I]),
+    "dim_get_winograd_split": (I, []),
     "dim_winograd_packed_weight_floats": (L, [I, I, I]),
     "dim_winograd_workspace_floats": (L, [I, I, I, I, I, I]),
     "dim_winograd_pack_weight": (I, [P, P, I, I, I, P]),

@@ -342,6 +342,16 @@ def copy_channels(dst_oihw, dst_c0, src_oihw, src_c0, nch):
     return dst_oihw
 
 
+def set_winograd_split(on):
+    """arithmetic of the Winograd layers' plane GEMMs: True = f32 operands as three bf16 terms, six MFMA products (default);
+    False = the f32 matrix pipe.  Read when a layer is next planned (launch / graph capture)."""
+    check(lib().dim_set_winograd_split(1 if on else 0))
+
+
+def get_winograd_split():
+    return bool(lib().dim_get_winograd_split())
+
+
 def winograd_pack_weight(w_oihw, m=2):
     """(Cout,Cin,3,3) -> the (m+2)^2 transformed 1x1 weight sets of the Winograd F(m x m, 3x3) path, m = 2 or 4"""
     Cout, Cin, KH, KW = w_oihw.shape

@@ -24,12 +24,13 @@ def test_pure_host_queries(hip_lib):
     # z-buffer (8 B / pixel) + projected vertices (padded to 256 B) + 256-byte header + covered-pixel list (4 B / pixel)
     assert hip_lib.dim_raster_workspace_bytes(2, 100, 480, 640) == 2 * 480 * 640 * 8 + 2560 + 256 + 2 * 480 * 640 * 4 + 2 * 1200 * 16
     # Winograd paths: packed weights = planes x K x Cout, workspace = planes x tiles x (K + Cout)
-    assert hip_lib.dim_winograd_packed_weight_floats(256, 128, 4) == 36 * 256 * 128
-    assert hip_lib.dim_winograd_packed_weight_floats(256, 128, 2) == 16 * 256 * 128
+    # f32 image + the three-term bf16 image behind it (6 bytes per weight): x 5 / 2
+    assert hip_lib.dim_winograd_packed_weight_floats(256, 128, 4) == 36 * 256 * 128 * 5 // 2
+    assert hip_lib.dim_winograd_packed_weight_floats(256, 128, 2) == 16 * 256 * 128 * 5 // 2
     assert hip_lib.dim_winograd_workspace_floats(16, 60, 80, 256, 256, 4) == 36 * (16 * 15 * 20) * 512
     assert hip_lib.dim_winograd_workspace_floats(16, 60, 80, 256, 256, 2) == 16 * (16 * 30 * 40) * 512
     assert hip_lib.dim_winograd_workspace_floats(1, 7, 9, 32, 64, 3) == 0  # unsupported tile size
-    assert hip_lib.dim_winograd5x5s2_packed_weight_floats(128, 64) == 36 * 128 * 256
+    assert hip_lib.dim_winograd5x5s2_packed_weight_floats(128, 64) == 36 * 128 * 256 * 5 // 2
     assert hip_lib.dim_winograd5x5s2_workspace_floats(16, 240, 320, 64, 128) == 36 * (16 * 30 * 40) * (256 + 128)
     # batches whose transformed tiles would overflow 32-bit byte offsets run in slices: the workspace stops growing with N
     big = hip_lib.dim_winograd5x5s2_workspace_floats(512, 240, 320, 64, 128)

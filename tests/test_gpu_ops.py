@@ -555,13 +555,23 @@ def test_fc6_and_pose_head(ops):
     np.testing.assert_allclose(se3.cpu().numpy(), ref, atol=5e-5, rtol=1e-4)
 
 
+@pytest.fixture(params=[1, 0], ids=["split3xbf16", "f32pipe"])
+def wino_split(request, hip_lib):
+    """both arithmetics of the Winograd plane GEMMs: f32 operands as three bf16 terms / six MFMA products (the default), and the f32 pipe"""
+    from lib.hip import ops
+
+    ops.set_winograd_split(bool(request.param))
+    yield request.param
+    ops.set_winograd_split(True)
+
+
 @pytest.mark.parametrize("m", [2, 4])
 # the last shape has more (tile, plane) items than resident workgroups: stream-K ranges that start / end inside an item
 @pytest.mark.parametrize("shape", [(2, 15, 20, 64, 128), (1, 8, 10, 96, 64), (3, 30, 40, 256, 256), (2, 7, 9, 32, 64), (1, 3, 5, 32, 64),
                                    (16, 58, 80, 64, 128),
                                    # few tiles, many weights (conv6_1-like): fewer rows than one workgroup tile
                                    (2, 8, 10, 512, 512), (7, 7, 10, 256, 1024), (16, 8, 10, 256, 1024)])
-def test_conv3x3_winograd_vs_f64(hip_lib, shape, m):
+def test_conv3x3_winograd_vs_f64(hip_lib, shape, m, wino_split):
     """Winograd F(2x2,3x3) / F(4x4,3x3) paths (odd and even H/W, partial edge tiles, bias + LeakyReLU) vs torch-CPU float64 conv2d"""
     import torch.nn.functional as F
     from lib.hip import ops
@@ -590,7 +600,7 @@ def test_conv3x3_winograd_vs_f64(hip_lib, shape, m):
 
 
 @pytest.mark.parametrize("shape", [(2, 30, 40, 64, 128), (1, 16, 24, 32, 64), (2, 15, 21, 64, 64), (1, 6, 9, 32, 128), (3, 60, 80, 128, 256)])
-def test_conv5x5s2_winograd_vs_f64(hip_lib, shape):
+def test_conv5x5s2_winograd_vs_f64(hip_lib, shape, wino_split):
     """5x5 / stride-2 / pad-2 layer (conv2, conv3) as four phase images through Winograd F(4x4,3x3): even and odd H/W, partial
     tiles, bias + LeakyReLU, strided output, padded input channels -- vs torch-CPU float64 conv2d and vs the direct MFMA kernel"""
     import torch.nn.functional as F
@@ -621,7 +631,7 @@ def test_conv5x5s2_winograd_vs_f64(hip_lib, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 30, 40, 64, 128), (1, 15, 21, 32, 64), (2, 60, 80, 128, 256), (1, 7, 10, 16, 32), (16, 60, 78, 32, 64)])
-def test_conv5x5s2_winograd_dgrad_vs_f64(hip_lib, shape):
+def test_conv5x5s2_winograd_dgrad_vs_f64(hip_lib, shape, wino_split):
     """input gradient of the 5x5 / stride-2 / pad-2 layer through Winograd (one transform of dY, K = Cout, N = 4 Cin, phase scatter)
     vs torch-CPU float64 autograd and vs the direct dgrad path; even / odd H and W; padded channel strides on both sides"""
     import torch.nn.functional as F
@@ -783,7 +793,7 @@ def test_copy_add_rows_and_fill(hip_lib):
                                    # the few-row GEMM tiles: 16 x (4 x 5) = 320 rows = two 160-row tiles (conv5 at 16 pairs), 7 x 20 = 140
                                    # rows (one partly empty tile), 96-row tiles with 100 and 96 rows
                                    (16, 30, 40, 64, 512, 6), (7, 30, 40, 32, 128, 6), (5, 30, 40, 32, 256, 7), (16, 16, 20, 64, 128, 7)])
-def test_conv_winograd3x3s2_vs_f64(hip_lib, shape, monkeypatch):
+def test_conv_winograd3x3s2_vs_f64(hip_lib, shape, monkeypatch, wino_split):
     """3x3 / stride-2 / pad-1 layers through their phase images (minimal filtering: F(4,1) on the even, F(4,2) on the odd phase; 81 plane
     GEMMs) vs torch-CPU float64 and vs the direct kernel: odd and even maps (tiles hanging over both edges), padded channel strides, an
     output channel offset, every GEMM tile, no bias, batch slices"""
