@@ -10,8 +10,10 @@ zoom x4), inputs resident in HBM, whole loop replayed as one hipGraph.  Pairs ar
 shard them with no data-path collective ("weak" scaling: 16 pairs per GPU).
 
 Prints ONE JSON line (rank 0) with the contract keys plus
-  "roofline":     dominant kernel's algorithmic TFLOP/s vs the dense f32 MFMA peak (HIP events on the
-                  launch stream, averaged over the timed launches of that kernel),
+  "roofline":     dominant kernel's algorithmic TFLOP/s vs its matrix-pipe roof -- the dense f32 MFMA peak for the f32-pipe
+                  kernels; for the three-term plane GEMMs (f32 operands split into three bf16 terms, six MFMA products per
+                  multiply, f32 accumulate: csrc/wino_gemm_split.hip) the dense bf16 peak / 6 -- from HIP events on the
+                  launch stream, averaged over the timed launches of that kernel,
   "cpu_baseline": the CPU oracle (torch-CPU convs + numpy zoom + C rasteriser, batch 1 like the reference
                   loop) timed on this box's host cores on a bounded sample (rank 0, N == 1 only).
 """
@@ -64,6 +66,8 @@ def parse_args():
                     "DeepIM; 0 = seeded initialisation with a scaled random pose head that moves the pose 3-12 deg per iteration")
     ap.add_argument("--parity-pairs", type=int, default=4, help="pairs of the benchmark batch checked against the oracle loop after the timed region "
                     "(teacher-forced + free-running): the `parity` object; a value over its bar makes the exit code non-zero")
+    ap.add_argument("--f32-pipe", action="store_true", help="Winograd plane GEMMs on the f32 matrix pipe (v_mfma_f32_32x32x2_f32) instead of "
+                    "the default three-bf16-term arithmetic (csrc/wino_gemm_split.hip); the default run reports this variant as `f32_pipe`")
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-layer HIP events for the roofline object")
     return ap.parse_args()
 
@@ -121,6 +125,9 @@ def encoder_roofline(net, b, test_iter, profile_steps):
     per_kernel = {}
     TILE_SYM = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 128, 2, 4", 5: "128, 256, 2, 4", 6: "160, 128, 1, 4",
                 7: "96, 128, 1, 4"}
+    SPLIT_SYM = {5: "128, 8", 4: "128, 4", 7: "96, 4"}
+    from lib.hip import ops as _ops
+    split_on = _ops.get_winograd_split()
     for name, evs in events.items():
         info = net.layer_info[name]
         for ev in evs:
@@ -128,7 +135,10 @@ def encoder_roofline(net, b, test_iter, profile_steps):
             n_launch = ev[3] if len(ev) > 3 else 1  # auto mode: two conv launches (+ a reduce) inside one event pair
             if tag == "conv":  # the symbol rocprofv3 --kernel-trace reports for this launch
                 if info.get("winograd"):  # batched GEMM of the Winograd path: the multiply-adds that launch really executes
-                    kname = "dim::wino_gemm_kernel<{}>".format(TILE_SYM[info["wino_tile"]])
+                    if split_on and info["wino_tile"] in SPLIT_SYM:   # f32 operands as three bf16 terms (csrc/wino_gemm_split.hip)
+                        kname = "dim::wino_gemm_split_kernel<{}>".format(SPLIT_SYM[info["wino_tile"]])
+                    else:
+                        kname = "dim::wino_gemm_kernel<{}>".format(TILE_SYM[info["wino_tile"]])
                     flops, nbytes = info["wino_flops"], info["wino_gemm_bytes"]
                 else:
                     kname = "dim::conv1_halo_kernel<7, 7>" if info["tile"] == 6 else \
@@ -160,8 +170,13 @@ def encoder_roofline(net, b, test_iter, profile_steps):
         if rec:
             traffic, traffic_src = rec["hbm_bytes_per_launch"], os.path.relpath(cand, ROOT)
             break
+    # the matrix-pipe roof of the dominant kernel.  wino_gemm_kernel / conv kernels: the dense f32 MFMA peak.  wino_gemm_split_kernel
+    # multiplies f32 operands as three bf16 terms each and keeps six term products per multiply on v_mfma_f32_32x32x16_bf16: its roof
+    # for ALGORITHMIC flops is the dense bf16 peak / 6 (it executes 6 x the algorithmic flops on the bf16 pipe)
+    is_split = "wino_gemm_split_kernel" in dom_name
+    peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if is_split else F32_MFMA_PEAK_TFLOPS
     roofline = {"bound": "mfma", "kernel": dom_name, "layers": dom["layers"], "achieved": round(achieved, 2),
-                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": "bytes/launch (PMC, 2*FETCH_SIZE+WRITE_SIZE)", "traffic_source": traffic_src,
                 "min_bytes_per_launch_avg": round(dom["bytes"] / dom["launches"]),
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 4), "launches_timed": dom["launches"],
@@ -170,6 +185,14 @@ def encoder_roofline(net, b, test_iter, profile_steps):
                                     "avg_launch_ms": round(v["ms"] / v["launches"], 4),
                                     "ms_per_forward": round(v["ms"] / nfwd, 4)} for k, v in per_kernel.items()},
                 "conv_stack_ms_per_forward": round(sum(v["ms"] for v in per_kernel.values()) / nfwd, 3)}
+    if is_split:
+        roofline.update({"arithmetic": "f32 operands, each the exact sum of three bf16 terms; six term products per multiply on "
+                                       "v_mfma_f32_32x32x16_bf16, f32 accumulate (error <= 3 * 2^-27 per product; DIM_WINO_SPLIT=0 = f32 pipe)",
+                         "peak_is": "dense bf16 MFMA peak {} / 6 products".format(BF16_MFMA_PEAK_TFLOPS),
+                         "mfma_executed_TFLOP/s": round(6 * achieved, 1), "mfma_executed_frac_of_bf16_peak": round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                         "f32_pipe_peak": F32_MFMA_PEAK_TFLOPS, "achieved_over_f32_pipe_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                         "hbm_algorithmic_GB/s": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
+                         "hbm_frac_of_peak": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
 
     return roofline
 
@@ -682,6 +705,7 @@ def main():
         params["trans_weight"] = (_rng.randn(3, 256) * 0.02).astype(np.float32)
         params["rot_weight"][1:] = (_rng.randn(3, 256) * 0.2).astype(np.float32)
         weights_info = {"kind": "seeded initialisation + scaled random pose head (3-12 deg per iteration)"}
+    ops.set_winograd_split(not args.f32_pipe)   # read when the layers are planned (here) and when the graph is captured
     pred = Predictor(cfg, params, B, device=dev, winograd=not args.no_winograd)
     batch = syn.build_device_batch(rm, B, seed=1000 + rank, n_classes=len(models), pixel_means=cfg.network.PIXEL_MEANS, device=dev)
     if args.autotune:  # untimed: choose tile / split-K per layer on this GPU before the graph is captured
@@ -731,6 +755,9 @@ def main():
                    "pairs_per_gpu": B, "global_pairs": B * world, "test_iter": test_iter, "hipgraph": not args.no_graph, "winograd": "off" if args.no_winograd else "F(4x4,3x3): {}; phase images + F(4x4,3x3): {}{}".format(
                        " ".join(net.wino), " ".join(net.wino5),
                        "; phase images + minimal filtering F(4,1) x F(4,2): " + " ".join(net.wino3s2) if net.wino3s2 else ""),
+                   "plane_gemm_arithmetic": "f32 pipe (v_mfma_f32_32x32x2_f32)" if args.f32_pipe or args.no_winograd else
+                   "f32 operands as three bf16 terms, six products per multiply on v_mfma_f32_32x32x16_bf16, f32 accumulate (f32 in HBM, "
+                   "f32-level error: tests/test_split_terms.py, parity object below)",
                    "gflop_per_refinement": round(net.flops_per_forward() * test_iter / B / 1e9, 2), "status_flags": status,
                    "conv_plan": {k: list(v) for k, v in net.conv_plan.items()}},
         "roofline": roofline,
@@ -738,6 +765,32 @@ def main():
         "ranks": ranks, "ms_per_step_per_rank": per_rank_ms, "dist_backend": args.dist_backend if world > 1 else None,
         "distinct_devices": len({(r["host"], r["uuid"] or r["pci_bus_id"] or r["device"]) for r in ranks}),
     }
+    if world == 1 and not args.no_variants and not args.no_graph and not args.f32_pipe and not args.no_winograd:
+        # the same loop, same batch, same weights with every plane GEMM on the f32 matrix pipe: the A/B of the default arithmetic in
+        # the same process (timed like the headline), and how far the two arithmetics' poses lie apart
+        try:
+            ops.set_winograd_split(False)
+            pred_f = Predictor(cfg, params, B, device=dev, winograd=True)
+            ref_f = Refiner(cfg, pred_f, rm, B, capture_graph=True)
+            ref_f.load(batch["image_observed"], batch["image_rendered"], batch["mask_observed"], batch["mask_rendered"], batch["src_pose"],
+                       batch["class_index"])
+            for _ in range(args.warmup):
+                ref_f.refine()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                ref_f.refine()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            se3_f = ref_f.se3_iter.cpu().numpy()
+            out["f32_pipe"] = {"value": round(B * args.steps / dt, 2), "unit": "pose-refinements/sec", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                               "headline_over_this": round(value / (B * args.steps / dt), 4),
+                               "first_iteration_se3_max_abs_diff_to_headline": float(np.abs(se3_f[0] - se3_hip[0]).max())}
+            del ref_f, pred_f
+        except Exception as e:
+            out["f32_pipe"] = {"error": "{}: {}".format(type(e).__name__, e)}
+        finally:
+            ops.set_winograd_split(True)
     if world == 1 and not args.no_fresh_batch and not args.no_graph:
         try:
             out["fresh_batch"] = fresh_batch_bench(cfg, rm, refiner, B, dev, args.steps, args.warmup)

@@ -251,7 +251,8 @@ int dim_conv2d_tail_plan(int M, int Cout, int Cin, int KH, int KW, int tile, int
  * (tile, splits) of a direct layer with M GEMM rows and `nchunks` K chunks of 32 (splits 0 = the "auto" tail plan above), and the
  * workgroup tile of a Winograd layer's plane GEMMs (3 / 4 / 5 = 64 x 64 / 128 x 128 / 128 x 256) for `tiles` transform tiles. */
 int dim_conv_auto_plan(long M, int Cout, int nchunks, int cin, int* tile, int* splits);
-int dim_winograd_gemm_tile(int Cout, long tiles);
+int dim_winograd_gemm_tile(int Cout, long tiles);                          /* = ..._planes(Cout, tiles, 36) */
+int dim_winograd_gemm_tile_planes(int Cout, long tiles, int planes);      /* planes: 36 (F(4x4,3x3), 5x5 / s2) or 81 (3x3 / s2) */
 /* Arithmetic of the Winograd layers' plane GEMMs.  1 (default): every f32 operand enters the matrix pipe as the exact sum of three
  * bf16 terms and a product keeps the six largest term products, accumulated in f32 (error <= 3 * 2^-27 per product, below f32's own
  * rounding of the sums); 0: v_mfma_f32_32x32x2_f32 on the f32 operands.  Every packed Winograd weight buffer carries both images

@@ -1804,12 +1804,30 @@ int dim_get_winograd_split(void) { return wino_get_split(); }
 // the tile that wastes the fewest MFMA cycles on padded rows -- 6 = 160 x 128 (conv5, conv5_1: 320 rows at 16 pairs), 7 = 96 x 128
 // (conv6_1: 96 rows), 3 = 64 x 64 -- weighted by what each reaches of the matrix peak (measured: 0.54 / 0.70 / 0.74).
 // DIM_WINO_BN256=0 keeps the 128 x 128 tile everywhere, DIM_WINO_FEWROW=0 the 64 x 64 tile on the few-row layers (A/B timing).
-int dim_winograd_gemm_tile(int Cout, long tiles) {
+int dim_winograd_gemm_tile_planes(int Cout, long tiles, int planes) {
   static const int bn256 = [] { const char* e = getenv("DIM_WINO_BN256"); return e ? atoi(e) : 1; }();
   static const int fewrow = [] { const char* e = getenv("DIM_WINO_FEWROW"); return e ? atoi(e) : 1; }();
   if (Cout % 128) return 3;
   if (tiles < 1024) {
     if (!fewrow) return 3;
+    if (wino_get_split()) {
+      // three-term kernels (wino_gemm_split.hip): 128 x 128 (tile 4) or 96 x 128 (tile 7), two 4-wave workgroups per CU.  Cost = rows a
+      // workgroup multiplies: items per workgroup (whole workgroups per CU when there are fewer items than slots, as wino_gemm_plan
+      // deals them) x tile rows / what the tile reaches (measured at 16 pairs: conv5_1 51.8 us on 7 against 57.2 on 4 and 73.7 on the
+      // f32 pipe; conv5, 81 planes, 93.6 on 4 against 110.0 on 7 and 140.8 on the f32 pipe)
+      const struct { int tile, bm; double eff; } cand[2] = {{4, 128, 1.0}, {7, 96, 0.85}};
+      const int cus = 256, slots = 512;
+      int best = 7;
+      double best_cost = 1e30;
+      for (const auto& c : cand) {
+        const long items = (tiles + c.bm - 1) / c.bm * (Cout / 128) * planes;
+        long G = items < slots ? items : slots;
+        if (G > cus && G < slots) G = G / cus * cus;
+        const double cost = (double)items / (double)G * c.bm / c.eff;
+        if (cost < best_cost) { best_cost = cost; best = c.tile; }
+      }
+      return best;
+    }
     const struct { int tile, bm; double eff; } cand[3] = {{3, 64, 0.54}, {7, 96, 0.70}, {6, 160, 0.74}};
     int best = 3;
     double best_cost = 1e30;
@@ -1823,6 +1841,7 @@ int dim_winograd_gemm_tile(int Cout, long tiles) {
   if (big == 6 || big == 7) return big;
   return (Cout % 256 == 0 && bn256) ? 5 : 4;
 }
+int dim_winograd_gemm_tile(int Cout, long tiles) { return dim_winograd_gemm_tile_planes(Cout, tiles, 36); }
 
 int dim_conv2d_tail_plan(int M, int Cout, int Cin, int KH, int KW, int tile, int* tail_begin_tile, int* tail_splits) {
   DIM_REQUIRE(tail_begin_tile && tail_splits, "null pointer");

@@ -128,7 +128,7 @@ int dim_refiner_create(dim_refiner** out, const dim_refiner_desc* desc, const ch
       max_ws = std::max(max_ws, dim_winograd5x5s2_workspace_floats(B, h, w, c, ly.cout));
     } else if (ly.k == 3 && ly.s == 2 && ly.p == 1 && dim_winograd3x3s2_use(h, w, c, ly.cout)) {
       P.kind = 3;
-      P.tile = dim_winograd_gemm_tile(ly.cout, (long)B * ((P.ho + 3) / 4) * ((P.wo + 3) / 4));
+      P.tile = dim_winograd_gemm_tile_planes(ly.cout, (long)B * ((P.ho + 3) / 4) * ((P.wo + 3) / 4), 81);
       P.splits = 1;
       TRY(dev_alloc(r, (void**)&P.w_packed, (size_t)dim_winograd3x3s2_packed_weight_floats(ly.cout, c) * 4));
       TRY(dim_winograd3x3s2_pack_weight(wsrc, P.w_packed, ly.cout, c, stream));

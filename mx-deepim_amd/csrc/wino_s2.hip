@@ -298,7 +298,7 @@ int dim_conv2d_fwd_winograd3x3s2(const float* x, const float* w_packed, const fl
     if (e != hipSuccess) return set_err(DIM_ERR_LAUNCH, "hipEventRecord: %s", hipGetErrorString(e)); \
   }
     int gt = tile;
-    if (gt == 0) gt = dim_winograd_gemm_tile(Cout, T);
+    if (gt == 0) gt = dim_winograd_gemm_tile_planes(Cout, T, kPlanes);
     WGemmArgs plan;
     int rc = wino_gemm_plan(&plan, V, w_packed, M, (int)T, Cin, Cout, kPlanes, gt);
     if (rc != DIM_OK) return rc;

@@ -305,7 +305,7 @@ class FlowNetHip(object):
                 max_ws = max(max_ws, ops.lib().dim_winograd5x5s2_workspace_floats(B, h, w, c, cout))
             if name in self.wino3s2:
                 tiles = B * (-(-ho // 4)) * (-(-wo // 4))
-                wt = (wino_tile or {}).get(name, self._wino_tile(cout, tiles))
+                wt = (wino_tile or {}).get(name, self._wino_tile(cout, tiles, 81))
                 info = self._wino_info(4, 1, wt, tiles, c, cout, B * h * w * c, B * ho * wo * cout, planes=81)
                 info.update(wino_in_kernel="dim::wino_s2_input_kernel", wino_out_kernel="dim::wino_s2_output_kernel")
                 self.layer_info[name].update(info)
@@ -353,9 +353,9 @@ class FlowNetHip(object):
         return ops.deconv4x4s2_pack_weight(w_iohw, as_bf16=self.bf16)
 
     @staticmethod
-    def _wino_tile(cout, tiles):
-        """workgroup tile of a layer's plane GEMMs: dim_winograd_gemm_tile, the one copy of the rule (shared with csrc/refiner.hip)"""
-        return int(ops.lib().dim_winograd_gemm_tile(int(cout), int(tiles)))
+    def _wino_tile(cout, tiles, planes=36):
+        """workgroup tile of a layer's plane GEMMs: dim_winograd_gemm_tile_planes, the one copy of the rule (shared with csrc/refiner.hip)"""
+        return int(ops.lib().dim_winograd_gemm_tile_planes(int(cout), int(tiles), int(planes)))
 
     @staticmethod
     def _wino_info(m, S, tile, tiles, cin, cout, x_floats, y_floats, planes=None):

@@ -95,6 +95,7 @@ SIGNATURES = {
     "dim_conv2d_tail_plan": (I, [I, I, I, I, I, I, P, P]),
     "dim_conv_auto_plan": (I, [L, I, I, I, P, P]),
     "dim_winograd_gemm_tile": (I, [I, L]),
+    "dim_winograd_gemm_tile_planes": (I, [I, L, I]),
     "dim_set_winograd_split": (I, [I]),
     "dim_get_winograd_split": (I, []),
     "dim_winograd_packed_weight_floats": (L, [I, I, I]),
