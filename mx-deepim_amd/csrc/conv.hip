@@ -621,6 +621,219 @@ __global__ __launch_bounds__(512) void conv1_halo_bf16_kernel(ConvArgs a, int ti
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- first layer, three terms
+// flow_conv1 with f32 operands on the bf16 matrix pipe: every weight and every input value is the exact sum of three bf16 terms and a
+// product keeps the six largest term products, accumulated in f32 -- the arithmetic of wino_gemm_split.hip (error <= 3 * 2^-27 per
+// product, below f32's own rounding of the sum).  On the f32 pipe this layer is bound by its 392 MFMAs of 64 cycles per 32 x 64 block
+// (conv1_halo_kernel: 0.60 ms at 16 pairs, 102 TFLOP/s); six MFMAs of 32 cycles per tap pair are 2.2x fewer pipe cycles.
+// The three-term weights of all 64 output channels (150 KB) do not fit LDS beside a patch, and streamed per wave from L2 they are the
+// bound (conv1_halo_bf16_kernel's note).  So a PERSISTENT 8-wave workgroup owns HALF the output channels: its 76.8 KB of weights stay in
+// LDS, [tap pair 25][term 3][k half 2][channel 32][8 bf16] (a wave's A fragment = 1 KB contiguous, conflict-free), and it walks a range
+// of 16 x 16 pixel blocks whose 37 x 37 x 8 patch is split on the way into LDS: three images of 16 B per pixel, the even and the odd
+// input columns in separate planes with a 24-slot row pitch -- with stride 2 the 16 lanes that ds_read_b128 serves together read one
+// tap of 16 consecutive output pixels = 16 consecutive slots of one column parity (two rows apart: 48 slots = a multiple of the 16
+// slots the 64 banks hold) -- conflict-free.  The workgroups 2 j and 2 j + 1 (one XCD) walk the same blocks for the two channel halves:
+// the second read of a patch comes out of L2.  One wave = 32 pixels x 32 channels, 150 MFMAs per block on two accumulators.
+#ifndef DIM_C1_EXP   // timing experiments on conv1_halo_split_kernel (tools/split_exp.sh FILE=conv.hip): 1 no MFMAs, 2 no fragment reads,
+#define DIM_C1_EXP 0 // 4 no patch split / store, 8 no output stores -- WRONG results with any bit set
+#endif
+constexpr int kC1Pairs = 25;
+constexpr size_t kC1SplitBytes = 2 * (size_t)kC1Pairs * 3 * 2 * 32 * 16;   // both halves: 153 600 B behind the packed f32 weights
+
+struct C1Split {
+  uint4 h, m, l;
+};
+__device__ __forceinline__ C1Split c1_split8(const float4 lo, const float4 hi) {
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  const f32x8 x = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  const bf16x8 bh = __builtin_convertvector(x, bf16x8);
+  const f32x8 r1 = x - __builtin_convertvector(bh, f32x8);
+  const bf16x8 bm = __builtin_convertvector(r1, bf16x8);
+  const f32x8 r2 = r1 - __builtin_convertvector(bm, f32x8);
+  const bf16x8 bl = __builtin_convertvector(r2, bf16x8);
+  C1Split s;
+  s.h = __builtin_bit_cast(uint4, bh);
+  s.m = __builtin_bit_cast(uint4, bm);
+  s.l = __builtin_bit_cast(uint4, bl);
+  return s;
+}
+
+// packed f32 weights [13 chunks][64][4 taps x 8 channels] -> the three-term image (layout above); one thread per (channel, tap slot)
+__global__ __launch_bounds__(256) void conv1_split_weights_kernel(const float* __restrict__ wp, unsigned char* __restrict__ w3) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 64 * 2 * kC1Pairs) return;
+  const int co = t & 63, slot = t >> 6;   // slot = 2 pair + k half = the tap (49 = padding)
+  float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+  if (slot < 49) {
+    const float* src = wp + ((slot >> 2) * 64 + co) * 32 + (slot & 3) * 8;
+    lo = *reinterpret_cast<const float4*>(src);
+    hi = *reinterpret_cast<const float4*>(src + 4);
+  }
+  const C1Split sp = c1_split8(lo, hi);
+  const int pair = slot >> 1, kh = slot & 1, half = co >> 5;
+  unsigned char* dst = w3 + ((((size_t)(half * kC1Pairs + pair) * 3) * 2 + kh) * 32 + (co & 31)) * 16;
+  *reinterpret_cast<uint4*>(dst) = sp.h;
+  *reinterpret_cast<uint4*>(dst + 1024) = sp.m;
+  *reinterpret_cast<uint4*>(dst + 2048) = sp.l;
+}
+
+template <int KH, int KW>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv1_halo_split_kernel(ConvArgs a, const unsigned char* __restrict__ w3, int tiles, int per_pair) {
+  constexpr int TH = 16, TW = 16, S = 2;
+  constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;   // 37 x 37 input pixels
+  constexpr int NPIX = PH * PW, NT = KH * KW, NPAIR = (NT + 1) / 2;
+  constexpr int PITCH = 24;                  // 16-byte slots per patch row of one column parity (19 used)
+  constexpr int PLANE = PH * PITCH;          // slots of one parity plane
+  constexpr int TERM = 2 * PLANE;            // slots of one term's image
+  constexpr int ITEMS = (NPIX + 511) / 512;
+  constexpr int WBYTES = NPAIR * 3 * 2 * 32 * 16;
+  static_assert(NPAIR == kC1Pairs, "7 x 7 taps");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_c1[];
+  unsigned char* sw = smem_c1;                       // this half's weights
+  uint4* sp = reinterpret_cast<uint4*>(smem_c1 + WBYTES);   // [3 terms][2 parities][PH][PITCH]
+  float* sbias = reinterpret_cast<float*>(smem_c1 + WBYTES + 3 * TERM * 16);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = wg_xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  const int half = wg & 1, pr = wg >> 1;
+  const int t_begin = pr * per_pair, t_end = min(tiles, t_begin + per_pair);
+  if (t_begin >= t_end) return;
+  const int tiles_w = (a.Wo + TW - 1) / TW, tiles_h = (a.Ho + TH - 1) / TH;
+  if (tid < 32) sbias[tid] = a.has_bias ? a.bias[half * 32 + tid] : 0.f;
+
+  for (int it = tid; it < WBYTES / 16; it += 512)
+    *reinterpret_cast<uint4*>(sw + it * 16) = *reinterpret_cast<const uint4*>(w3 + (size_t)half * WBYTES + it * 16);
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  float4 lo[ITEMS], hi[ITEMS];
+  auto tile_origin = [&](int t, int& n, int& ho0, int& wo0) {
+    const int twi = t % tiles_w;
+    const int r = t / tiles_w;
+    n = r / tiles_h;
+    ho0 = (r - n * tiles_h) * TH;
+    wo0 = twi * TW;
+  };
+  auto patch_load = [&](int t) {   // pixels outside the image read zeros (= the padding)
+    int n, ho0, wo0;
+    tile_origin(t, n, ho0, wo0);
+    const int hi0 = ho0 * S - a.pad_h, wi0 = wo0 * S - a.pad_w;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int pix = it * 512 + tid;
+      const int py = pix / PW, px = pix - py * PW;
+      const int hy = hi0 + py, wx = wi0 + px;
+      const bool ok = pix < NPIX && (unsigned)hy < (unsigned)a.H && (unsigned)wx < (unsigned)a.W;
+      const int off = ok ? (((n * a.H + hy) * a.W + wx) * a.in_cstride) * 4 : -1;
+      lo[it] = buf_load16(rx, off, 0);
+      hi[it] = buf_load16(rx, ok ? off + 16 : -1, 0);
+    }
+  };
+  // the split of the next block's pixels happens in registers while this block multiplies (the VALU work hides under the MFMAs of the
+  // SIMD's other wave); after the barrier that ends the block only the LDS stores are left
+  C1Split s3[ITEMS];
+  auto patch_split = [&]() {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) s3[it] = c1_split8(lo[it], hi[it]);
+  };
+  auto patch_store = [&]() {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int pix = it * 512 + tid;
+      if (pix < NPIX) {
+        const int py = pix / PW, px = pix - py * PW;
+        const int slot = (px & 1) * PLANE + py * PITCH + (px >> 1);
+        sp[slot] = s3[it].h;
+        sp[TERM + slot] = s3[it].m;
+        sp[2 * TERM + slot] = s3[it].l;
+      }
+    }
+  };
+  const int frow = lane & 31, khalf = lane >> 5;
+  const int p = wave * 32 + frow;               // output pixel = this lane's B column inside the block
+  const int ty = p / TW, tx = p - ty * TW;
+  const uint4* pb = sp + (ty * S) * PITCH + tx;
+  const unsigned char* wa = sw + (khalf * 32 + frow) * 16;
+
+  // stores through a descriptor: a pixel outside the output gets offset 0xFFFFFFFF, which the range check drops -- no branch around
+  // the stores (with one, hipcc waits vmcnt(0) for the next block's patch loads and thereby for these stores: one in-order counter)
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+  // (Measured and not kept: different orders for the two waves of a SIMD -- waves 4 .. 7 splitting late in the tap loop and writing their
+  // outputs during the next block's first taps -- 407 us against 363: the wave-uniform branches inside the unrolled tap loop cost more
+  // than the overlap returned.  Ablations of this form at 16 pairs: MFMAs 200 us of the 363, fragment reads 75, patch split + store 52,
+  // output 46, roughly additive: the eight waves of the one workgroup a CU holds move through a block in step.)
+  auto epilogue = [&](const f32x16& sum, int tt) {
+    // D layout: col = lane & 31 -> pixel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> channel of this half
+    int n, ho0, wo0;
+    tile_origin(tt, n, ho0, wo0);
+    const int oy = ho0 + ty, ox = wo0 + tx;
+    const int o_off = (oy < a.Ho && ox < a.Wo) ? (a.out_coff + ((n * a.Ho + oy) * a.Wo + ox) * a.out_cstride + half * 32 + 4 * khalf) * 4 : -1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bv = *reinterpret_cast<const float4*>(&sbias[8 * g + 4 * khalf]);
+      float4 v = make_float4(sum[4 * g] + bv.x, sum[4 * g + 1] + bv.y, sum[4 * g + 2] + bv.z, sum[4 * g + 3] + bv.w);
+      v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+      v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+      u32x4 u;
+      u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+      if constexpr (DIM_C1_EXP & 8) asm volatile("" ::"v"(u)); else
+      __builtin_amdgcn_raw_buffer_store_b128(u, ry, o_off == -1 ? -1 : o_off + 32 * g, 0, 0);
+    }
+  };
+  patch_load(t_begin);
+  patch_split();
+  patch_store();
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    const bool more = t + 1 < t_end;
+    patch_load(more ? t + 1 : t);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    // fragments of tap pair i + 1 are requested before the six MFMAs of pair i are issued (two register sets; fenced, or hipcc sinks
+    // every read to its first use; a third set changed nothing)
+    bf16x8 fx[2][3], fw[2][3];
+    auto frags = [&](auto I_, auto SET_) {
+      constexpr int i = decltype(I_)::value, set = decltype(SET_)::value;
+      constexpr int t0 = 2 * i, t1 = (2 * i + 1 < NT) ? 2 * i + 1 : NT - 1;   // tap 49: zero weights, its pixel operand re-reads tap 48
+      constexpr int o0 = ((t0 % KW) & 1) * PLANE + (t0 / KW) * PITCH + ((t0 % KW) >> 1);
+      constexpr int o1 = ((t1 % KW) & 1) * PLANE + (t1 / KW) * PITCH + ((t1 % KW) >> 1);
+      const uint4* ppx = pb + (khalf ? o1 : o0);
+      const unsigned char* wr = wa + i * 3 * 1024;
+#pragma unroll
+      for (int tm = 0; tm < 3; ++tm) {
+        fx[set][tm] = __builtin_bit_cast(bf16x8, ppx[tm * TERM]);
+        fw[set][tm] = *reinterpret_cast<const bf16x8*>(wr + tm * 1024);
+      }
+    };
+    frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    static_for<NPAIR>([&](auto I_) {
+      constexpr int i = decltype(I_)::value, set = i & 1;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (i + 1 < NPAIR && !(DIM_C1_EXP & 2)) frags(std::integral_constant<int, i + 1>{}, std::integral_constant<int, 1 - set>{});
+      __builtin_amdgcn_sched_barrier(0);
+#if DIM_C1_EXP & 1   // timing experiment: no MFMAs, the operands stay loaded
+#pragma unroll
+      for (int tm = 0; tm < 3; ++tm) asm volatile("" ::"v"(fw[set][tm]), "v"(fx[set][tm]));
+#else
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set][2], fx[set][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set][0], fx[set][2], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set][1], fx[set][1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set][1], fx[set][0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set][0], fx[set][1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set][0], fx[set][0], acc1, 0, 0, 0);
+#endif
+      if constexpr (i == NPAIR / 2 && !(DIM_C1_EXP & 4)) patch_split();   // the loads were issued a dozen tap pairs ago
+    });
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
+    epilogue(acc0, t);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave has read this block's patch (LDS-only barrier)
+    if constexpr (!(DIM_C1_EXP & 4)) patch_store();             // (after the last block: the same block again, unused)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+}
+
 template <int BM, int BN, int WM, int WN, bool CIN8>
 __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(ConvArgs a) {
   constexpr int BK = 32;
@@ -1648,7 +1861,8 @@ using namespace dim;
 extern "C" {
 
 long dim_conv2d_packed_weight_floats(int Cout, int Cin, int KH, int KW) {
-  if (Cin == 8) return (long)((KH * KW + 3) / 4) * 32 * Cout;  // 4 taps x 8 channels per chunk, taps flat over KH x KW
+  if (Cin == 8)  // 4 taps x 8 channels per chunk, taps flat over KH x KW; the first layer's three-term image behind it
+    return (long)((KH * KW + 3) / 4) * 32 * Cout + (KH == 7 && KW == 7 && Cout == 64 ? (long)(kC1SplitBytes / 4) : 0);
   return (long)KH * KW * Cin * Cout;
 }
 
@@ -1678,7 +1892,13 @@ int dim_conv2d_pack_weight(const float* w_oihw, float* w_packed, int Cout, int C
   DIM_REQUIRE(w_oihw && w_packed, "null weight pointer");
   DIM_REQUIRE(Cin == 8 || Cin % 32 == 0, "Cin must be 8 or a multiple of 32 (got %d)", Cin);
   DIM_REQUIRE(Cin != 8 || KW <= 8, "Cin==8 path needs KW<=8 (got %d)", KW);
-  return pack_conv_weight_any(w_oihw, w_packed, Cout, Cout, Cin, KH, KW, stream);
+  int rc = pack_conv_weight_any(w_oihw, w_packed, Cout, Cout, Cin, KH, KW, stream);
+  if (rc == DIM_OK && Cin == 8 && KH == 7 && KW == 7 && Cout == 64) {   // flow_conv1: + the image conv1_halo_split_kernel reads
+    hipLaunchKernelGGL(conv1_split_weights_kernel, dim3((64 * 2 * kC1Pairs + 255) / 256), dim3(256), 0, as_stream(stream), w_packed,
+                       reinterpret_cast<unsigned char*>(w_packed + 13 * 32 * 64));
+    rc = check_launch("conv1_split_weights");
+  }
+  return rc;
 }
 
 // same, with the output-channel count padded with zero rows up to CoutPad (a multiple of 64): w_oihw has Cout rows
@@ -2047,6 +2267,20 @@ static int conv2d_fwd_impl(const float* x, const float* w_packed, const float* b
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
       DIM_REQUIRE(attr_ok, "cannot reserve %zu bytes of LDS for the first-layer kernel", lds);
       hipLaunchKernelGGL((conv1_halo_bf16_kernel<7, 7>), dim3((tiles16 + per_wg - 1) / per_wg), dim3(512), lds, st, a, tiles16, per_wg);
+    } else if (wino_get_split()) {  // three-term arithmetic: persistent, one 8-wave workgroup per CU, channel halves in pairs
+      const int tiles16 = N * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);
+      static const int n_cu2 = [] {
+        int dev = 0, cus = 0;
+        return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 1) ? cus : 256;
+      }();
+      const int pairs = tiles16 < n_cu2 / 2 ? tiles16 : n_cu2 / 2;
+      const int per_pair = (tiles16 + pairs - 1) / pairs;
+      constexpr size_t lds = (size_t)kC1Pairs * 3 * 2 * 32 * 16 + 3 * 2 * (size_t)37 * 24 * 16 + 32 * sizeof(float);
+      static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_halo_split_kernel<7, 7>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      DIM_REQUIRE(attr_ok, "cannot reserve %zu bytes of LDS for the first-layer kernel", lds);
+      hipLaunchKernelGGL((conv1_halo_split_kernel<7, 7>), dim3(2 * ((tiles16 + per_pair - 1) / per_pair)), dim3(512), lds, st, a,
+                         reinterpret_cast<const unsigned char*>(a.w + 13 * 32 * 64), tiles16, per_pair);
     } else {
       hipLaunchKernelGGL((conv1_halo_kernel<7, 7>), dim3(tiles), dim3(256), 0, st, a);
     }

@@ -18,7 +18,7 @@ def test_header_symbols_exported(hip_lib):
 
 def test_pure_host_queries(hip_lib):
     # no GPU needed: size queries are plain host arithmetic
-    assert hip_lib.dim_conv2d_packed_weight_floats(64, 8, 7, 7) == 13 * 32 * 64  # 49 taps, 4 per chunk
+    assert hip_lib.dim_conv2d_packed_weight_floats(64, 8, 7, 7) == 13 * 32 * 64 + 153600 // 4  # 49 taps, 4 per chunk; + flow_conv1's three-term image
     assert hip_lib.dim_conv2d_packed_weight_floats(128, 64, 5, 5) == 25 * 64 * 128
     assert hip_lib.dim_conv2d_workspace_floats(2, 8, 10, 512, 1024, 3, 3, 1, 1, 4) == 4 * 2 * 8 * 10 * 1024
     # z-buffer (8 B / pixel) + projected vertices (padded to 256 B) + 256-byte header + covered-pixel list (4 B / pixel)

@@ -75,7 +75,8 @@ def test_wgrad_first_layer_cin8_and_fc6(ops):
     dwp = torch.zeros_like(ops.conv2d_pack_weight(w.detach().float().to(DEV)))
     ops.conv2d_wgrad(nhwc(x.float()), 8, nhwc(dy.float()), 64, 7, 7, 2, 3, dwp, splits=4)
     ref = ops.conv2d_pack_weight(w.grad.float().to(DEV))
-    assert (dwp - ref).abs().max().item() <= 3e-5 * w.grad.abs().max().item() + 1e-5
+    n = 13 * 32 * 64   # the packed f32 weights; behind them the buffer holds flow_conv1's three-term image (forward only)
+    assert (dwp[:n] - ref[:n]).abs().max().item() <= 3e-5 * w.grad.abs().max().item() + 1e-5
     # fc6 as an 8x10 "convolution": wgrad in the fc packed layout
     B = 3
     feat = torch.randn((B, 1024, 8, 10), generator=g, dtype=torch.float64)

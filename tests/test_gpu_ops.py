@@ -499,7 +499,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_vs_torch_cpu(ops, case):
+def test_conv2d_vs_torch_cpu(ops, case, wino_split):
     import torch.nn.functional as F
 
     N, H, W, Cin, Cout, k, s, p, tile, splits = case

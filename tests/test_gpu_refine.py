@@ -334,7 +334,9 @@ def test_graph_variants_images_only_and_depth_input(hip_lib):
         if cin == 10:   # the mask lanes live in the second 8-lane group
             np.testing.assert_array_equal(pred.net.X2[..., :2].cpu().numpy(), ref["data"].transpose(0, 2, 3, 1)[..., 8:])
             assert float(pred.net.X2[..., 2:].abs().max()) == 0.0
-        np.testing.assert_allclose(out["se3_output"].cpu().numpy(), ref["se3"], atol=5e-5)
+        # the repo's step bar, 2e-5 * max(1, |step|) (tests/loop_parity.py): the head's raw quaternion is ~10 long here
+        se3_bar = 2e-5 * max(1.0, float(np.abs(ref["se3"]).max()))
+        assert float(np.abs(out["se3_output"].cpu().numpy() - ref["se3"]).max()) <= se3_bar
         if True:   # the loop re-renders images, masks and -- INPUT_DEPTH -- the rendered depth plane
             rm = Render_Py(None, cfg.dataset.class_name, scene["K"], meshes=scene["models"])
             refiner = Refiner(cfg, pred, rm, B, capture_graph=True)

@@ -5,7 +5,10 @@ set -e
 cd "$(dirname "$0")/../mx-deepim_amd/csrc"
 make -s
 mkdir -p ../../gpurun_exp
-OTHERS=$(ls build/*.o | grep -v wino_gemm_split.o)
+# FILE=conv.hip MACRO=DIM_C1_EXP tools/split_exp.sh 1 2 ... : the same for another source file / experiment macro
+FILE=${FILE:-wino_gemm_split.hip}
+MACRO=${MACRO:-DIM_SPLIT_EXP}
+OTHERS=$(ls build/*.o | grep -v "/${FILE%.hip}.o")
 # a value "oN" builds -DDIM_SPLIT_OPT=N (schedule options) instead of an experiment; "eXoN" both
 for v in "$@"; do
   e=0; o=0
@@ -14,7 +17,7 @@ for v in "$@"; do
     o*) o=${v#o};;
     *) e=$v;;
   esac
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -DDIM_SPLIT_EXP=$e -DDIM_SPLIT_OPT=$o $EXTRA -c wino_gemm_split.hip -o /tmp/wgs_exp_$v.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -D$MACRO=$e -DDIM_SPLIT_OPT=$o $EXTRA -c $FILE -o /tmp/wgs_exp_$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../gpurun_exp/libdeepim_hip_exp$v.so $OTHERS /tmp/wgs_exp_$v.o
   echo built exp $v
 done
