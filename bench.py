@@ -141,7 +141,7 @@ def encoder_roofline(net, b, test_iter, profile_steps):
                         kname = "dim::wino_gemm_kernel<{}>".format(TILE_SYM[info["wino_tile"]])
                     flops, nbytes = info["wino_flops"], info["wino_gemm_bytes"]
                 else:
-                    kname = "dim::conv1_halo_kernel<7, 7>" if info["tile"] == 6 else \
+                    kname = ("dim::conv1_halo_split_kernel<7, 7>" if split_on else "dim::conv1_halo_kernel<7, 7>") if info["tile"] == 6 else \
                         "dim::conv_fwd_kernel<{}, {}>".format(TILE_SYM[info["tile"]], "true" if info["cin"] == 8 else "false")
                     flops, nbytes = info["flops"], info["min_bytes"]
             elif tag == "fc":  # fc6 weight stream (+ its partial-sum reduce inside the event pair)
@@ -173,7 +173,7 @@ def encoder_roofline(net, b, test_iter, profile_steps):
     # the matrix-pipe roof of the dominant kernel.  wino_gemm_kernel / conv kernels: the dense f32 MFMA peak.  wino_gemm_split_kernel
     # multiplies f32 operands as three bf16 terms each and keeps six term products per multiply on v_mfma_f32_32x32x16_bf16: its roof
     # for ALGORITHMIC flops is the dense bf16 peak / 6 (it executes 6 x the algorithmic flops on the bf16 pipe)
-    is_split = "wino_gemm_split_kernel" in dom_name
+    is_split = "_split_kernel" in dom_name
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if is_split else F32_MFMA_PEAK_TFLOPS
     roofline = {"bound": "mfma", "kernel": dom_name, "layers": dom["layers"], "achieved": round(achieved, 2),
                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
