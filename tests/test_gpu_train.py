@@ -164,6 +164,22 @@ def test_adam_two_steps_and_optimizer_state_checkpoint(setup, tmp_path):
                 assert np.abs(new[k] - p_ref[k]).max() <= 2e-3 * 1e-4 + 1e-9, (k, t)
             # the oracle continues from the module's parameters so that step 2 sees identical gradients
             p_ref = {k: v.copy() for k, v in new.items()}
+        # the flat layout the gradient buckets and the vector kernels rely on: every tensor starts on a 128-byte boundary,
+        # the buckets tile [0, n_weight + n_bias) exactly and in order, and the padding between tensors is still zero in the weights,
+        # the gradients and both Adam states after two updates
+        n_live = mod.n_weight + mod.n_bias
+        assert mod.buckets[0][0] == 0 and mod.buckets[-1][1] == n_live
+        assert all(b0[1] == b1[0] for b0, b1 in zip(mod.buckets, mod.buckets[1:])) and all(b > a and a % 32 == 0 for a, b in mod.buckets)
+        used = torch.zeros(mod.flat_w.numel(), dtype=torch.bool, device=DEV)
+        for n, off in mod.offset_of.items():
+            assert off % 32 == 0, n
+            sz = int(np.prod(mod.shapes[n]))
+            assert not bool(used[off:off + sz].any()), n      # no two tensors overlap
+            used[off:off + sz] = True
+        gaps = ~used
+        assert int(gaps.sum()) > 0     # the head + decoder + fc6 sizes are not multiples of 32: there IS padding to check
+        for vec in (mod.flat_w, mod.flat_g, mod.flat_m, mod.flat_v):
+            assert float(vec[gaps].abs().max()) == 0.0
         f = str(tmp_path / "opt.npz")
         mod.save_optimizer_states(f)
         mod2 = MutableModule(cfg, mod.get_params(), B)
