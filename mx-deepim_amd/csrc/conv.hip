@@ -757,6 +757,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // stores through a descriptor: a pixel outside the output gets offset 0xFFFFFFFF, which the range check drops -- no branch around
   // the stores (with one, hipcc waits vmcnt(0) for the next block's patch loads and thereby for these stores: one in-order counter)
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+  // (Measured and not kept, same-box A/B: the split dealt in fifteen steps behind the MFMAs of tap pairs 8 .. 22 and the outputs of a
+  // block written during the next block's first four pairs -- 379 / 383 us against 368 / 397: inside the noise.)
   // (Measured and not kept: different orders for the two waves of a SIMD -- waves 4 .. 7 splitting late in the tap loop and writing their
   // outputs during the next block's first taps -- 407 us against 363: the wave-uniform branches inside the unrolled tap loop cost more
   // than the overlap returned.  Ablations of this form at 16 pairs: MFMAs 200 us of the 363, fragment reads 75, patch split + store 52,
@@ -2035,7 +2037,7 @@ int dim_winograd_gemm_tile_planes(int Cout, long tiles, int planes) {
       // workgroup multiplies: items per workgroup (whole workgroups per CU when there are fewer items than slots, as wino_gemm_plan
       // deals them) x tile rows / what the tile reaches (measured at 16 pairs: conv5_1 51.8 us on 7 against 57.2 on 4 and 73.7 on the
       // f32 pipe; conv5, 81 planes, 93.6 on 4 against 110.0 on 7 and 140.8 on the f32 pipe)
-      const struct { int tile, bm; double eff; } cand[2] = {{4, 128, 1.0}, {7, 96, 0.85}};
+      const struct { int tile, bm; double eff; } cand[2] = {{4, 128, 1.0}, {7, 96, planes > 36 ? 0.75 : 0.85}};   // (conv6, 81 planes x 96 rows: 102 us on 4, 116 on 7)
       const int cus = 256, slots = 512;
       int best = 7;
       double best_cost = 1e30;

@@ -238,7 +238,9 @@ long dim_winograd3x3s2_packed_weight_floats(int Cout, int Cin) { return wino_pac
 int dim_winograd3x3s2_use(int H, int W, int Cin, int Cout) {
   static const int on = [] { const char* e = getenv("DIM_WINO_S2K3"); return e ? atoi(e) : 1; }();
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  return on && Cin % 32 == 0 && Cout % 64 == 0 && Ho * Wo >= 300;
+  // with the three-term plane GEMMs (wino_gemm_split.hip) conv6 gains too: 102 us for its three launches at 16 pairs against 128-135
+  // direct (the 81 weight planes are then 255 MB of bf16 terms per forward: it is bound by reading them)
+  return on && Cin % 32 == 0 && Cout % 64 == 0 && (Ho * Wo >= 300 || (wino_get_split() && Ho * Wo >= 80 && Cout % 128 == 0));
 }
 
 long dim_winograd3x3s2_workspace_floats(int N, int H, int W, int Cin, int Cout) {

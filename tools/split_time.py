@@ -25,7 +25,7 @@ print(" ".join(out))
 '''
 for v in sys.argv[1:]:
     env = dict(os.environ)
-    if v != "lib":
+    if v != "lib" and not os.environ.get("DIM_HIP_LIB_KEEP"):
         env["DIM_HIP_LIB"] = os.path.join(ROOT, "gpurun_exp", "libdeepim_hip_exp{}.so".format(v))
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, capture_output=True, text=True, timeout=300)
     print("exp {:>4}: {}".format(v, r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "FAILED " + r.stderr[-400:]), flush=True)
