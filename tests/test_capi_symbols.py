@@ -40,6 +40,27 @@ def test_pure_host_queries(hip_lib):
     assert hip_lib.dim_fc_fwd_workspace_floats(1024, 8, 10, 256) == 256 * 32 * 256
 
 
+def test_plane_gemm_arithmetic_switch_and_tile_rule(hip_lib):
+    """host-only: the switch between the three-term arithmetic and the f32 pipe, and what it changes in the launch plans of the
+    encoder's Winograd layers at 16 pairs (Cout, tile rows, planes) -- the rule of csrc/conv.hip, shared by FlowNetHip and dim_refiner"""
+    keep = hip_lib.dim_get_winograd_split()
+    try:
+        assert hip_lib.dim_set_winograd_split(1) == 0 and hip_lib.dim_get_winograd_split() == 1
+        three = {(256, 4800, 36): 5, (512, 1280, 36): 5, (128, 19200, 36): 4,    # conv3 / conv3_1, conv4_1, conv2
+                 (512, 1200, 81): 5, (512, 320, 81): 4, (512, 320, 36): 7,       # conv4, conv5, conv5_1
+                 (1024, 96, 36): 7, (1024, 96, 81): 4, (64, 4800, 36): 3}        # conv6_1, conv6, a 64-channel layer (f32 pipe tile)
+        for (cout, rows, planes), tile in three.items():
+            assert hip_lib.dim_winograd_gemm_tile_planes(cout, rows, planes) == tile, (cout, rows, planes)
+        assert hip_lib.dim_winograd_gemm_tile(512, 320) == hip_lib.dim_winograd_gemm_tile_planes(512, 320, 36)
+        assert hip_lib.dim_winograd3x3s2_use(15, 20, 512, 1024) == 1      # conv6 through phase images (255 MB of weight planes)
+        assert hip_lib.dim_set_winograd_split(0) == 0 and hip_lib.dim_get_winograd_split() == 0
+        assert hip_lib.dim_winograd_gemm_tile_planes(512, 320, 36) == 6 and hip_lib.dim_winograd_gemm_tile_planes(1024, 96, 36) == 7
+        assert hip_lib.dim_winograd_gemm_tile_planes(256, 4800, 36) == 5
+        assert hip_lib.dim_winograd3x3s2_use(15, 20, 512, 1024) == 0 and hip_lib.dim_winograd3x3s2_use(30, 40, 512, 512) == 1
+    finally:
+        hip_lib.dim_set_winograd_split(keep)
+
+
 def test_product_never_imports_oracle():
     import subprocess
     pkg = os.path.join(ROOT, "mx-deepim_amd")
