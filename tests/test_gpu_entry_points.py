@@ -1,5 +1,6 @@
 """deepim/test.py and deepim/train.py (the reference's command lines) end to end on tiny synthetic runs, as child processes."""
 import glob
+import json
 import os
 import subprocess
 import sys
@@ -125,3 +126,21 @@ def test_bench_gpus_2_one_command_two_ranks_on_one_card(hip_lib):
         bk = out["train"][dt]["allreduce_buckets"]
         assert len(bk) == 3 and all(b["ms"] > 0 and b["bytes"] == (b["end"] - b["begin"]) * nbytes for b in bk), bk
         assert out["train"][dt]["allreduce_bytes_per_update"] == sum(b["bytes"] for b in bk) and len(out["train"][dt]["iteration_ms_per_rank"]) == 2
+
+
+def test_bench_line_names_the_arithmetic_and_times_the_f32_pipe_beside_it(hip_lib):
+    """one rank, short run: the dominant kernel is a three-term kernel priced against the bf16 peak / 6, the same loop on the f32 pipe
+    is timed in the same process, both arithmetics give the same first step to f32 rounding, and the parity object is green"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--head-epochs", "0", "--no-train",
+                        "--no-train-files", "--no-fresh-batch", "--cpu-pairs", "2", "--parity-pairs", "2", "--profile-steps", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["dtype"] == "f32" and "three bf16 terms" in out["config"]["plane_gemm_arithmetic"]
+    rf = out["roofline"]
+    assert "_split_kernel" in rf["kernel"] and rf["peak"] == pytest.approx(2500.0 / 6, rel=1e-3) and 0.05 < rf["frac"] < 1.0
+    assert rf["mfma_executed_TFLOP/s"] == pytest.approx(6 * rf["achieved"], rel=1e-2) and rf["f32_pipe_peak"] == pytest.approx(157.3)
+    f32 = out["f32_pipe"]
+    assert "error" not in f32 and f32["value"] > 0 and out["value"] > f32["value"]          # the three-term arithmetic is the faster one
+    assert f32["first_iteration_se3_max_abs_diff_to_headline"] < 1e-4                         # ... and the same one, to f32 rounding
+    assert out["parity"]["ok"] and out["parity"]["max_step_err"] <= out["parity"]["step_err_bar"]
