@@ -124,6 +124,10 @@ __global__ __launch_bounds__(WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int NSTG = BM / RP;  // staging loads per thread and chunk
   constexpr int PL = BM * 64;    // bytes of one term's image of a chunk
   constexpr int kTrLd = 32, kTrFloats = 16 * kTrLd;
+  // cache policy of the wide M stores: non-temporal on the big layers (M = 94-354 MB streams past the caches); plain on the 96-row tile
+  // (conv5_1, conv6_1: M = 14-24 MB stays cached for the output transform -- conv5_1's GEMM 66.8 -> 55.5 us, same-box A/B; on the big
+  // layers plain stores make the output transform 7 % faster and the next input transform 15 % slower: a wash)
+  constexpr int kMAux = ((DIM_SPLIT_OPT & 2) || BM == 96) ? 0 : 2;
   static_assert(BM % 32 == 0 && BM % RP == 0 && RP % 32 == 0 && NSTG >= 2 && NSTG <= 4, "two to four staging loads per thread");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
@@ -253,8 +257,8 @@ __global__ __launch_bounds__(WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
           if constexpr (DIM_SPLIT_OPT & 8) { /* timing: no global stores */                                            \
             if constexpr (!(DIM_SPLIT_OPT & 64)) asm volatile("" ::"v"(u0), "v"(u1));                                  \
           } else {                                                                                                     \
-            __builtin_amdgcn_raw_buffer_store_b128(u0, rm, vo0, soff, (DIM_SPLIT_OPT & 2) ? 0 : 2);                    \
-            __builtin_amdgcn_raw_buffer_store_b128(u1, rm, vo1, soff, (DIM_SPLIT_OPT & 2) ? 0 : 2);                    \
+            __builtin_amdgcn_raw_buffer_store_b128(u0, rm, vo0, soff, kMAux);                                          \
+            __builtin_amdgcn_raw_buffer_store_b128(u1, rm, vo1, soff, kMAux);                                          \
           }                                                                                                            \
         }                                                                                                              \
       } else                                                                                                           \
