@@ -5,7 +5,8 @@
 // each exact in the f32 accumulator's input (8 x 8 significant bits), accumulated in f32 by v_mfma_f32_32x32x16_bf16.  Six MFMAs
 // of 32 cycles replace the sixteen 64-cycle v_mfma_f32_32x32x2_f32 of a 32 x 32 x 32 block: 2.67x the f32 matrix rate at an error
 // below f32's own rounding of the sum -- the parity bars of tests/ (2e-5 on a pose step against the f64-accumulating oracle) hold
-// unchanged, see tests/test_gpu_ops.py::test_winograd_split_*.  (deepim/symbols/deepIM_flownet.py:95-191 are the layers.)
+// unchanged; every Winograd test of tests/test_gpu_ops.py runs both arithmetics (`wino_split` fixture), tests/test_split_terms.py
+// asserts the bounds on the CPU.  (deepim/symbols/deepIM_flownet.py:95-191 are the layers.)
 //
 // Operands:
 //   V [T][P][K] f32  as in wino_gemm.hip; split by the staging threads on the way into LDS (11 VALU ops per pair of floats)
@@ -28,7 +29,8 @@
 #ifndef DIM_SPLIT_EXP
 #define DIM_SPLIT_EXP 0
 #endif
-// schedule / cache-policy options under test (bit set = new form): 1 split + LDS store ahead of MFMA step 0, 2 plain (not nt) M stores
+// timing / cache-policy options of the flush (bit set = variant): 2 plain (not non-temporal) M stores on every tile, 8 no global stores,
+// 16 no LDS round trip, 32 accumulators not cleared, 64 results not kept alive -- 8 .. 64 give WRONG results (tools/split_exp.sh oN)
 #ifndef DIM_SPLIT_OPT
 #define DIM_SPLIT_OPT 0
 #endif
